@@ -1,0 +1,445 @@
+#!/usr/bin/env python
+"""Mint the golden fixtures under tests/golden/ by running the REAL reference host code.
+
+Runs only in the build container: it imports ``/root/reference`` (read-only) with the five
+stub modules SURVEY.md 8(c) lists injected into ``sys.modules`` (funcsigs, tensorflow's
+HParams, cv2, robonet's VPredEvaluation, and the removed ``np.int`` alias), drives the
+reference's own ``get_policy_args`` / ``CEMBaseController`` / ``PixelCostController`` /
+samplers / ``controller_utils`` / ``pred_util`` on seeded synthetic inputs, and stores the
+inputs' seeds plus the observed outputs.  Nothing of the reference travels: the fixtures are
+numbers only.  The tests then require this repo's host code (and the oracle restatement of
+the cost) to reproduce the outputs from the same inputs.
+
+    python tools/make_golden.py        # rewrites tests/golden/*.npz|json
+
+The TF ``HParams`` class does not exist in this image; the stub is this repo's own
+``visual_foresight_amd.hparams.HParams`` - so fixtures pin the *reference's override
+protocol* (policy.py:51-63, cem_base_controller.py:66-76) on top of it, not TF's class.
+"""
+import io
+import json
+import os
+import sys
+import types
+import contextlib
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = '/root/reference'
+OUT = os.path.join(REPO, 'tests', 'golden')
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+from tests.helpers.fake_predictor import make_fake_predictor_class  # noqa: E402
+from visual_foresight_amd.hparams import HParams  # noqa: E402
+
+
+def install_stubs():
+    import inspect
+    if not hasattr(np, 'int'):
+        np.int = int        # pixel_cost_controller.py:208 uses the removed alias
+
+    funcsigs = types.ModuleType('funcsigs')
+    funcsigs.signature, funcsigs.Parameter = inspect.signature, inspect.Parameter
+    sys.modules['funcsigs'] = funcsigs
+
+    tf = types.ModuleType('tensorflow')
+    contrib = types.ModuleType('tensorflow.contrib')
+    training = types.ModuleType('tensorflow.contrib.training')
+    training.HParams = HParams
+    tf.contrib, contrib.training = contrib, training
+    sys.modules.update({'tensorflow': tf, 'tensorflow.contrib': contrib,
+                        'tensorflow.contrib.training': training})
+
+    cv2 = types.ModuleType('cv2')
+    cv2.circle = lambda *a, **k: None
+    sys.modules['cv2'] = cv2
+
+    robonet = types.ModuleType('robonet')
+    vp = types.ModuleType('robonet.video_prediction')
+    testing = types.ModuleType('robonet.video_prediction.testing')
+    testing.VPredEvaluation = make_fake_predictor_class(5, 16, 16)
+    robonet.video_prediction, vp.testing = vp, testing
+    sys.modules.update({'robonet': robonet, 'robonet.video_prediction': vp,
+                        'robonet.video_prediction.testing': testing})
+
+    import matplotlib
+    matplotlib.use('Agg')
+    sys.path.insert(0, REFERENCE)
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def jsonable(x):
+    if isinstance(x, dict):
+        return {str(k): jsonable(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [jsonable(v) for v in x]
+    if isinstance(x, np.ndarray):
+        return x.tolist()
+    if isinstance(x, (np.floating, np.integer)):
+        return x.item()
+    if isinstance(x, type):
+        return 'class:' + x.__name__
+    return x
+
+
+# ----------------------------------------------------------------------------- a1
+def golden_policy_args(ref):
+    from visual_mpc.policy.policy import get_policy_args
+    PCC = ref['PixelCostController']
+    pol = PCC.__new__(PCC)          # only the signature of act() matters
+    rs = np.random.RandomState(11)
+    obs = {'images': rs.randint(0, 256, (3, 1, 8, 8, 3)).astype(np.uint8),
+           'state': rs.normal(size=(3, 5))}
+    agent_data = {'desig_pix': [[3, 4]], 'goal_pix': [[6, 1]], 'verbose_worker': 'queue-handle'}
+    got = get_policy_args(pol, obs, 2, 7, agent_data)
+    out = {'keys': sorted(got.keys()), 't': got['t'], 'i_tr': got['i_tr'],
+           'desig_pix': got['desig_pix'], 'goal_pix': got['goal_pix'],
+           'verbose_worker': got['verbose_worker'],
+           'images_is_obs': bool(got['images'] is obs['images']),
+           'state_is_obs': bool(got['state'] is obs['state'])}
+
+    class NeedsGoal(object):
+        def act(self, t, goal_image):
+            pass
+    try:
+        get_policy_args(NeedsGoal(), obs, 0, 0, agent_data)
+        out['missing_required'] = None
+    except ValueError as e:
+        out['missing_required'] = str(e)
+    return out
+
+
+# ----------------------------------------------------------------------------- a2
+AG = {'adim': 4, 'sdim': 5, 'image_height': 16, 'image_width': 16}
+
+
+def policy_dicts():
+    """The `policy` dicts of three experiment files, minus 'type' (values copied as data)."""
+    return {
+        # experiments/sim/cartgripper_2d_grasping/pixel_cost/hparams.py:31-39
+        'sim_cartgripper': {'action_order': ['x', 'z', 'grasp'], 'initial_std_lift': 0.5,
+                            'rejection_sampling': False, 'replan_interval': 10, 'num_samples': 800},
+        # experiments/robonet/pixel_cost/hparams.py:31-42
+        'robonet_pixel_cost': {'replan_interval': 13, 'num_samples': 600, 'selection_frac': 0.05,
+                               'predictor_propagation': True, 'initial_std_lift': 0.2,
+                               'initial_std_rot': np.pi / 10, 'rejection_sampling': False,
+                               'nactions': 13, 'repeat': 1},
+        # experiments/robonet/robotiq/zero_shot.py:24-38
+        'robotiq_zero_shot': {'replan_interval': 13, 'zeros_for_start_frames': False,
+                              'num_samples': 600, 'selection_frac': 0.05,
+                              'predictor_propagation': True, 'initial_std_lift': 0.2,
+                              'initial_std_rot': np.pi / 10, 'rejection_sampling': False,
+                              'nactions': 13, 'repeat': 1,
+                              'model_path': '~/models/sawyer_only/checkpoint_210000'},
+    }
+
+
+def golden_hparams(ref):
+    PCC = ref['PixelCostController']
+    out = {'ag_params': AG, 'cases': {}}
+    for name, pdict in policy_dicts().items():
+        with quiet():
+            ctrl = PCC(dict(AG), dict(pdict), 0, 1)
+        vals = ctrl._hp.values()
+        vals.pop('predictor_class')     # class object of the stub, not comparable
+        out['cases'][name] = {'policy': jsonable(pdict), 'values': jsonable(vals),
+                              'start_planning_after_ctor': ctrl._hp.start_planning}
+    errs = {}
+    for label, pdict in [('identical_to_default', {'iterations': 3}),
+                         ('unknown_key', {'no_such_param': 1}),
+                         ('list_for_scalar', {'T': [400, 200]}),
+                         ('wrong_type', {'num_samples': 'many'})]:
+        try:
+            with quiet():
+                PCC(dict(AG), dict(pdict), 0, 1)
+            errs[label] = None
+        except Exception as e:      # noqa
+            errs[label] = type(e).__name__
+    out['errors'] = errs
+    return out
+
+
+# ----------------------------------------------------------------------------- a5
+def golden_sampler(ref):
+    from visual_mpc.policy.cem_controllers.samplers import GaussianCEMSampler, CorrelatedNoiseSampler
+    from visual_mpc.policy.utils import controller_utils as cu
+    arrays, meta = {}, {'cases': []}
+
+    def hp_for(sampler_cls, **over):
+        hp = HParams(replan_interval=0)
+        for k, v in sampler_cls.get_default_hparams().items():
+            hp.add_hparam(k, v)
+        for k, v in over.items():
+            setattr(hp, k, v)
+        return hp
+
+    cases = [
+        ('gauss_a4', dict(rejection_sampling=False), 4, 0),
+        ('gauss_a3_order', dict(rejection_sampling=False, action_order=['x', 'z', 'grasp'],
+                                initial_std_lift=0.5), 3, 0),
+        ('gauss_a5_t2', dict(rejection_sampling=False, reduce_std_dev=0.2), 5, 2),
+        ('gauss_a4_h13', dict(rejection_sampling=False, nactions=13, repeat=1,
+                              initial_std_lift=0.2, initial_std_rot=np.pi / 10), 4, 1),
+        ('gauss_blockdiag_smooth', dict(rejection_sampling=False, cov_blockdiag=True,
+                                        smooth_cov=True), 4, 0),
+        ('gauss_discrete_zero', dict(rejection_sampling=False, discrete_ind=[3],
+                                     add_zero_action=True), 4, 0),
+        ('gauss_rejection', dict(rejection_sampling=True, stochastic_planning=None), 4, 0),
+    ]
+    for name, over, adim, t in cases:
+        hp = hp_for(GaussianCEMSampler, **over)
+        with quiet():
+            sigma0 = cu.construct_initial_sigma(hp, adim, t)
+            smp = GaussianCEMSampler(hp, adim, 5)
+            np.random.seed(100 + len(meta['cases']))
+            a0 = smp.sample_initial_actions(t, 32, np.zeros(5))
+            elites = a0[np.argsort(np.abs(a0).sum((1, 2)))[:10]].copy()
+            a1 = smp.sample_next_actions(32, elites, np.arange(10.))
+        arrays[name + '/sigma0'] = sigma0
+        arrays[name + '/a0'] = a0
+        arrays[name + '/a1'] = a1
+        arrays[name + '/mean'] = smp._mean
+        arrays[name + '/sigma'] = smp._sigma
+        meta['cases'].append({'name': name, 'over': jsonable(over), 'adim': adim, 't': t,
+                              'seed': 100 + len(meta['cases'])})
+
+    # reuse_mean across two planning calls (uses the logged best plan tails)
+    hp = hp_for(GaussianCEMSampler, rejection_sampling=False, reuse_mean=True, reduce_std_dev=0.5)
+    with quiet():
+        smp = GaussianCEMSampler(hp, 4, 5)
+        np.random.seed(7)
+        a0 = smp.sample_initial_actions(1, 16, np.zeros(5))
+        smp.log_best_action(a0[0, 0], a0[:5, 1:])
+        b0 = smp.sample_initial_actions(2, 16, np.zeros(5))
+    arrays['gauss_reuse_mean/a0'] = a0
+    arrays['gauss_reuse_mean/b0'] = b0
+    arrays['gauss_reuse_mean/mean'] = smp._mean
+
+    # correlated noise sampler
+    for name, over in [('corr_default', {}), ('corr_refit', dict(refit_cov=True, kappa=2)),
+                       ('corr_bias', dict(mean_bias=np.array([0.01, 0., 0., 0.]), nactions=6))]:
+        hp = hp_for(CorrelatedNoiseSampler, **over)
+        with quiet():
+            smp = CorrelatedNoiseSampler(hp, 4, 5)
+            np.random.seed(55)
+            a0 = smp.sample_initial_actions(0, 24, None)
+            elites = a0[:8].copy()
+            a1 = smp.sample_next_actions(24, elites, np.linspace(1., 3., 8))
+        arrays[name + '/a0'] = a0
+        arrays[name + '/a1'] = a1
+        meta['cases'].append({'name': name, 'over': jsonable(over), 'seed': 55, 'kind': 'corr'})
+
+    # helper functions on their own
+    hp = hp_for(GaussianCEMSampler)
+    x3 = np.random.RandomState(3).normal(0, 0.3, (6, 5, 4))
+    x2 = np.random.RandomState(4).normal(0, 0.3, (6, 4))
+    arrays['helpers/trunc3_in'], arrays['helpers/trunc2_in'] = x3.copy(), x2.copy()
+    arrays['helpers/trunc3_out'] = cu.truncate_movement(x3.copy(), hp)
+    arrays['helpers/trunc2_out'] = cu.truncate_movement(x2.copy(), hp)
+    hp_o = hp_for(GaussianCEMSampler, action_order=['x', 'y', 'z', 'theta'])
+    arrays['helpers/trunc3_order_out'] = cu.truncate_movement(x3.copy(), hp_o)
+    cov = np.random.RandomState(5).normal(size=(20, 20))
+    arrays['helpers/cov_in'] = cov
+    arrays['helpers/blockdiag_out'] = cu.make_blockdiagonal(cov, 5, 4)
+    d = np.random.RandomState(6).normal(2, 3, (4, 5, 4))
+    arrays['helpers/disc_in'] = d.copy()
+    arrays['helpers/disc_out'] = cu.discretize(d.copy(), 4, 5, [2, 3])
+    hp_r = hp_for(GaussianCEMSampler, reuse_cov=0.25)
+    hp_r.replan_interval = 3
+    sig = np.random.RandomState(8).normal(size=(20, 20))
+    arrays['helpers/reuse_cov_in'] = sig
+    # with the sampler defaults present, reuse_cov calls construct_initial_sigma(t=None), which
+    # compares None >= 2 (controller_utils.py:78): the stock path raises
+    try:
+        with quiet():
+            cu.reuse_cov(sig, 4, hp_r)
+        meta['reuse_cov_with_defaults'] = 'ok'
+    except TypeError:
+        meta['reuse_cov_with_defaults'] = 'TypeError'
+    hp_r.del_hparam('reduce_std_dev')
+    with quiet():
+        arrays['helpers/reuse_cov_out'] = cu.reuse_cov(sig, 4, hp_r)
+    return arrays, meta
+
+
+# ----------------------------------------------------------------------------- a8 a9 a10 a11
+def golden_cost(ref):
+    PCC = ref['PixelCostController']
+    arrays, meta = {}, {'numpy': np.__version__, 'cases': []}
+    cases = [  # name, H, W, ncam(=1 in ref), ndesig, M, T, finalweight, only_first
+        ('small', 16, 16, 1, 8, 5, 10., False),
+        ('two_desig', 16, 20, 2, 8, 5, 10., False),
+        ('four_desig', 12, 16, 4, 6, 4, 3., False),
+        # with ndesig > 1 the reference's own logging indexes past the sliced score matrix
+        # (pixel_cost_controller.py:158-159 -> IndexError), so the flag is only usable at ndesig=1
+        ('first_view_nd1', 12, 16, 1, 6, 4, 3., True),
+        ('c2_shape', 64, 64, 1, 32, 13, 10., False),
+    ]
+    for name, H, W, nd, M, T, fw, first in cases:
+        fake = make_fake_predictor_class(T, H, W)
+        pol = {'predictor_class': fake, 'designated_pixel_count': nd, 'nactions': T, 'repeat': 1,
+               'rejection_sampling': False, 'verbose': False, 'num_samples': M + 1}
+        if nd == 1:
+            pol.pop('designated_pixel_count')
+        if T == 5:
+            pol.pop('nactions')         # equal-to-default overrides raise (policy.py:57-58)
+        if fw != 10.:
+            pol['finalweight'] = fw
+        if first:
+            pol['only_take_first_view'] = True
+        ag = dict(AG, image_height=H, image_width=W)
+        with quiet():
+            ctrl = PCC(ag, pol, 0, 1)
+            ctrl.reset()
+        seed = 1000 + len(meta['cases'])
+        rs = np.random.RandomState(seed)
+        distrib = rs.uniform(0.0, 1.0, (M, T, 1, H, W, nd)).astype(np.float32)
+        goal = rs.randint(-3, max(H, W) + 3, (1, nd, 2))
+        desig = rs.randint(-3, max(H, W) + 3, (1, nd, 2))
+        ctrl._goal_pix, ctrl._desig_pix = goal, desig
+        with quiet():
+            scores = ctrl._eval_pixel_cost(0, distrib, None)
+            per_task = np.stack([ctrl._expected_distance(0, p, distrib[:, :, 0, :, :, p],
+                                                         ctrl._get_distancegrid(goal[0, p]))
+                                 for p in range(nd)], axis=1)
+            grid0 = ctrl._get_distancegrid(goal[0, 0])
+            onehot = ctrl._switch_on_pix(desig)
+        arrays[name + '/goal'], arrays[name + '/desig'] = goal, desig
+        arrays[name + '/scores'] = scores
+        arrays[name + '/scores_per_task'] = per_task
+        arrays[name + '/argsort'] = scores.argsort()
+        arrays[name + '/grid0'] = grid0
+        arrays[name + '/onehot_nonzero'] = np.argwhere(onehot != 0)
+        meta['cases'].append({'name': name, 'H': H, 'W': W, 'ndesig': nd, 'M': M, 'T': T,
+                              'finalweight': fw, 'only_take_first_view': first, 'seed': seed,
+                              'scores_dtype': str(scores.dtype), 'onehot_shape': list(onehot.shape)})
+    return arrays, meta
+
+
+# ----------------------------------------------------------------------------- a3 a4
+def golden_act(ref):
+    PCC = ref['PixelCostController']
+    arrays, meta = {}, {'cases': []}
+    H = W = 16
+    T = 5
+    cases = [
+        ('replan_every_step', dict(num_samples=40), 4),
+        ('replan_interval3', dict(num_samples=40, replan_interval=3, selection_frac=0.2), 6),
+        ('propagation', dict(num_samples=30, predictor_propagation=True, iterations=2,
+                             replan_interval=2), 5),
+        ('correlated', dict(num_samples=40, sampler='corr', nactions=5), 4),
+        ('append_action', dict(num_samples=24, append_action=[0.25]), 3),
+    ]
+    for name, over, n_steps in cases:
+        from visual_mpc.policy.cem_controllers.samplers import CorrelatedNoiseSampler
+        fake = make_fake_predictor_class(T, H, W)
+        pol = {'predictor_class': fake, 'verbose': False}
+        if over.get('sampler') == 'corr':
+            pol['sampler'] = CorrelatedNoiseSampler
+            over = {k: v for k, v in over.items() if k != 'sampler'}
+            pol.update(over)
+            pol.pop('nactions')     # 5 != default 15 is set below
+            pol['nactions'] = T
+        else:
+            pol.update(dict(rejection_sampling=False, repeat=1))   # nactions: default 5 == T
+            pol.update(over)
+        adim = 4 + (1 if 'append_action' in over else 0)
+        sampler_adim = 4
+        ag = dict(AG, adim=adim, image_height=H, image_width=W)
+        with quiet():
+            ctrl = PCC(ag, pol, 0, 1)
+            if 'append_action' in over:
+                ctrl._adim = sampler_adim       # sampler draws 4 dims, the 5th is appended
+            ctrl.reset()
+        seed = 2000 + len(meta['cases'])
+        np.random.seed(seed)
+        rs = np.random.RandomState(seed)
+        images = rs.randint(0, 256, (n_steps + 1, 1, H, W, 3)).astype(np.uint8)
+        states = rs.normal(0, 0.1, (n_steps + 1, 5))
+        desig, goal = [[8, 8]], [[3, 12]]
+        trace = []
+        for t in range(n_steps):
+            with quiet():
+                out = ctrl.act(t=t, i_tr=0, desig_pix=desig, goal_pix=goal,
+                               images=images[:t + 1], state=states[:t + 1])
+            arrays['%s/t%d/action' % (name, t)] = np.array(out['actions'])
+            for k, v in out['plan_stat'].items():
+                arrays['%s/t%d/%s' % (name, t, k)] = np.array(v)
+            if ctrl._best_indices is not None:
+                arrays['%s/t%d/best_indices' % (name, t)] = np.array(ctrl._best_indices)
+            trace.append(ctrl._t_since_replan)
+        meta['cases'].append({'name': name, 'over': jsonable(over), 'n_steps': n_steps, 'seed': seed,
+                              'T': T, 'H': H, 'W': W, 'adim': adim, 'sampler_adim': sampler_adim,
+                              't_since_replan': trace, 'desig': desig, 'goal': goal,
+                              'correlated': 'sampler' in pol,
+                              'predictor_calls': list(fake.calls)})
+    return arrays, meta
+
+
+# ----------------------------------------------------------------------------- a13
+def golden_pred_util(ref):
+    from visual_mpc.video_prediction.pred_util import get_context, rollout_predictions
+    arrays, meta = {}, {}
+    rs = np.random.RandomState(31)
+    images = rs.randint(0, 256, (5, 1, 6, 8, 3)).astype(np.uint8)
+    state = rs.normal(size=(5, 3))
+    hp = types.SimpleNamespace(state_append=[0.5, -1.0])
+    f, s = get_context(2, 4, state, images, hp)
+    arrays['ctx/images'], arrays['ctx/state'] = images, state
+    arrays['ctx/frames_out'], arrays['ctx/states_out'] = f, s
+    f2, s2 = get_context(2, 3, state, images, None)
+    arrays['ctx/frames_out_t3'], arrays['ctx/states_out_t3'] = f2, s2
+
+    seen = []
+
+    def recording_predictor(input_images=None, input_state=None, input_actions=None,
+                            input_one_hot_images=None):
+        seen.append(np.array(input_actions))
+        b = input_actions.shape[0]
+        tag = input_actions.sum((1, 2))
+        return tag[:, None] * np.ones((b, 2)), tag[:, None] + np.ones((b, 3)), None
+
+    actions = rs.normal(size=(450, 3, 2))
+    gi, gd, gs = rollout_predictions(recording_predictor, 200, actions, f, s, None)
+    arrays['roll/actions'] = actions
+    meta['chunk_shapes'] = [list(x.shape) for x in seen]
+    arrays['roll/last_chunk_sum_padded_rows'] = np.array([np.abs(seen[-1][50:]).sum()])
+    arrays['roll/gen_images'] = np.concatenate(gi, 0)
+    arrays['roll/gen_distrib'] = np.concatenate(gd, 0)
+    meta['gen_state_all_none'] = all(x is None for x in gs)
+    meta['n_runs'] = len(seen)
+    return arrays, meta
+
+
+def main():
+    install_stubs()
+    from visual_mpc.policy.cem_controllers import PixelCostController, CEMBaseController
+    ref = {'PixelCostController': PixelCostController, 'CEMBaseController': CEMBaseController}
+    os.makedirs(OUT, exist_ok=True)
+
+    def dump(name, arrays, meta):
+        if arrays:
+            np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
+        with open(os.path.join(OUT, name + '.json'), 'w') as f:
+            json.dump(jsonable(meta), f, indent=1, sort_keys=True)
+
+    dump('policy_args', None, golden_policy_args(ref))
+    dump('hparams', None, golden_hparams(ref))
+    dump('sampler', *golden_sampler(ref))
+    dump('cost', *golden_cost(ref))
+    dump('act', *golden_act(ref))
+    dump('pred_util', *golden_pred_util(ref))
+    print('wrote fixtures to', OUT, 'with numpy', np.__version__)
+    for fn in sorted(os.listdir(OUT)):
+        print('  %-20s %8d B' % (fn, os.path.getsize(os.path.join(OUT, fn))))
+
+
+if __name__ == '__main__':
+    main()
