@@ -1,0 +1,111 @@
+/* vf_hip.h - C ABI of libvf_hip.so, the MI355X (gfx950) video-prediction + cost engine.
+ *
+ * The reference (SudeepDasari/visual_foresight) has no FFI: its planner crosses to the device
+ * through one Python call into a TensorFlow-1 session.  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference root).  All bulk pointers
+ * are DEVICE pointers owned by the caller (PyTorch-ROCm tensors are the usual carrier); small
+ * control data (config, goal pixels) is passed by value / host pointer.  Every function
+ * returns 0 on success or a negative vf_status; vf_last_error() describes the last failure of
+ * the calling thread.  No exception crosses this boundary, nothing is allocated after
+ * vf_create(), and all work is enqueued on the caller's HIP stream (hipStream_t passed as
+ * void*; NULL = the default stream) without synchronising it.
+ *
+ * Tensor layouts (C order, float32 unless noted):
+ *   context frames   uint8  [n_context][H][W][3]
+ *   context distrib         [n_context][H][W][ndesig]
+ *   context states          [n_context][sdim]
+ *   context actions         [n_context-1][adim]
+ *   actions                 [B][T][adim]              T = sequence_length - n_context
+ *   predicted frames        [B][T][H][W][3]           in [0,1]
+ *   predicted distrib       [B][T][H][W][ndesig]      each (b,t,.,.,p) plane sums to 1
+ *   predicted states        [B][T][sdim]
+ *   scores                  [B], scores_per_task [B][ndesig]
+ */
+#ifndef VF_HIP_H
+#define VF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VF_ABI_VERSION 1
+
+typedef enum vf_status {
+    VF_OK = 0,
+    VF_ERR_INVALID = -1,   /* bad argument / shape / state */
+    VF_ERR_HIP = -2,       /* a HIP runtime call failed */
+    VF_ERR_NOMEM = -3,     /* device allocation failed */
+    VF_ERR_NOWEIGHTS = -4, /* rollout before vf_load_weights */
+    VF_ERR_NOCONTEXT = -5  /* rollout before vf_set_context */
+} vf_status;
+
+/* Static shape of one predictor instance.  Replaces the `conf` dict + placeholders of
+ * visual_mpc/video_prediction/setup_predictor.py:98-114 (orig_size, adim, sdim, ndesig,
+ * context_frames, sequence_length, batch_size) and the predictor hparams of
+ * visual_mpc/policy/cem_controllers/pixel_cost_controller.py:29-33
+ * (designated_pixel_count, run_batch_size). */
+typedef struct vf_config {
+    int32_t height, width;      /* multiples of 8 */
+    int32_t adim, sdim;
+    int32_t ndesig;             /* designated pixels per view (1..4) */
+    int32_t n_context;          /* context frames (>= 1) */
+    int32_t sequence_length;    /* n_context + T */
+    int32_t num_masks;          /* CDNA kernels K (masks = K + 1) */
+    int32_t max_batch;          /* run_batch_size: most samples per vf_rollout call */
+    int32_t device;             /* HIP device ordinal */
+} vf_config;
+
+typedef struct vf_handle vf_handle;
+
+int vf_abi_version(void);
+const char *vf_last_error(void);
+
+/* Number of float32 values vf_load_weights expects for `cfg` (the canonical tensor table of
+ * visual_foresight_amd/video_prediction/cdna_arch.py, concatenated in table order). */
+size_t vf_weight_count(const vf_config *cfg);
+
+/* Build one engine: allocates every device buffer (weights, recurrent state, activations,
+ * predictions for max_batch samples).  Replaces setup_predictor()'s graph/session build,
+ * visual_mpc/video_prediction/setup_predictor.py:61-128. */
+int vf_create(const vf_config *cfg, vf_handle **out);
+int vf_destroy(vf_handle *h);
+
+/* Upload network weights from a HOST blob in canonical layout and re-pack them for the MFMA
+ * kernels.  Replaces saver.restore / model.restore, setup_predictor.py:130-145, and
+ * predictor.restore(), pixel_cost_controller.py:34. */
+int vf_load_weights(vf_handle *h, const float *host_blob, size_t n_floats);
+
+/* Install the planning context (device pointers).  Replaces get_context(),
+ * visual_mpc/video_prediction/pred_util.py:4-13 (last n_context frames, uint8 -> float/255) and
+ * the batch-1 placeholders tiled per tower, setup_predictor.py:40-44: the context is kept once
+ * and broadcast to every sample by the kernels, never materialised per sample. */
+int vf_set_context(vf_handle *h, const uint8_t *d_frames, const float *d_states,
+                   const float *d_ctx_actions, const float *d_ctx_distrib, void *stream);
+
+/* Roll B (<= max_batch) action sequences through the predictor for T steps and reduce the
+ * predicted designated-pixel distributions to costs on the device.  Replaces
+ * predictor_func()/sess.run, setup_predictor.py:164-200, the call at
+ * pixel_cost_controller.py:83, and the host cost of pixel_cost_controller.py:135-197:
+ *   score_b = mean_p  sum_t w_t * E_{distrib[b,t,p]}[ || pix - goal_p || ] / sum_t w_t,
+ *   w = (1, ..., 1, finalweight).
+ * goal_pix: HOST int32 [ndesig][2] (row, col).  d_scores_per_task may be NULL.
+ * Predictions stay resident in the handle until the next vf_rollout (see vf_export). */
+int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *goal_pix,
+               float finalweight, float *d_scores, float *d_scores_per_task, void *stream);
+
+/* Copy the predictions of the last vf_rollout out in the reference's layout (normalised
+ * distributions).  Any destination may be NULL.  first/count select a sample range.
+ * Replaces the gen_images/gen_distrib/gen_states fetch of setup_predictor.py:155-200. */
+int vf_export(vf_handle *h, int32_t first, int32_t count, float *d_frames, float *d_distrib,
+              float *d_states, void *stream);
+
+/* Introspection for tests/benchmarks: algorithmic multiply-accumulates of one sample-step. */
+double vf_macs_per_sample_step(const vf_config *cfg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VF_HIP_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of libvf_hip.so (the C ABI declared in include/vf_hip.h).
+
+The library is built in-tree by ``build_library()`` (``hipcc --offload-arch=gfx950``; it
+cross-compiles without a GPU).  There is no CPU fallback: ``load_library()`` raises if the
+shared object is missing, and every wrapper raises ``VfError`` with ``vf_last_error()`` when
+a call fails.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, 'libvf_hip.so')
+SOURCES = [os.path.join(_HERE, 'csrc', f) for f in
+           ('vf_engine.hip', 'vf_conv_mfma.h', 'vf_small_kernels.h')] + \
+          [os.path.join(REPO, 'include', 'vf_hip.h')]
+
+EXPORTS = ('vf_abi_version', 'vf_last_error', 'vf_weight_count', 'vf_create', 'vf_destroy',
+           'vf_load_weights', 'vf_set_context', 'vf_rollout', 'vf_export',
+           'vf_macs_per_sample_step')
+
+
+class VfError(RuntimeError):
+    pass
+
+
+class VfConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ('height', 'width', 'adim', 'sdim', 'ndesig', 'n_context', 'sequence_length',
+                 'num_masks', 'max_batch', 'device')]
+
+
+def _hipcc():
+    for cand in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise VfError('hipcc not found; cannot build libvf_hip.so')
+
+
+def library_is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > built for s in SOURCES)
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP engine for gfx950 into visual_foresight_amd/libvf_hip.so."""
+    if not force and not library_is_stale():
+        return LIB_PATH
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+           '-o', LIB_PATH + '.tmp', SOURCES[0]]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or proc.returncode:
+        print(' '.join(cmd))
+        print(proc.stdout)
+    if proc.returncode:
+        raise VfError('hipcc failed building libvf_hip.so')
+    os.replace(LIB_PATH + '.tmp', LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libvf_hip.so and declare the prototypes.  Raises VfError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VfError('%s is missing - run `python -c "import __graft_entry__ as g; g.build()"` '
+                      '(there is no CPU fallback for the predictor)' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    P = ctypes.c_void_p
+    lib.vf_abi_version.restype = ctypes.c_int
+    lib.vf_last_error.restype = ctypes.c_char_p
+    lib.vf_weight_count.restype = ctypes.c_size_t
+    lib.vf_weight_count.argtypes = [ctypes.POINTER(VfConfig)]
+    lib.vf_macs_per_sample_step.restype = ctypes.c_double
+    lib.vf_macs_per_sample_step.argtypes = [ctypes.POINTER(VfConfig)]
+    lib.vf_create.argtypes = [ctypes.POINTER(VfConfig), ctypes.POINTER(P)]
+    lib.vf_destroy.argtypes = [P]
+    lib.vf_load_weights.argtypes = [P, P, ctypes.c_size_t]
+    lib.vf_set_context.argtypes = [P, P, P, P, P, P]
+    lib.vf_rollout.argtypes = [P, P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_float,
+                               P, P, P]
+    lib.vf_export.argtypes = [P, ctypes.c_int32, ctypes.c_int32, P, P, P, P]
+    for name in ('vf_create', 'vf_destroy', 'vf_load_weights', 'vf_set_context', 'vf_rollout',
+                 'vf_export'):
+        getattr(lib, name).restype = ctypes.c_int
+    if lib.vf_abi_version() != 1:
+        raise VfError('libvf_hip.so ABI version %d, expected 1' % lib.vf_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise VfError('libvf_hip error %d: %s' % (rc, load_library().vf_last_error().decode()))

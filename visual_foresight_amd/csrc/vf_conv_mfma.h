@@ -1,0 +1,326 @@
+// vf_conv_mfma.h - fp32 MFMA implicit-GEMM convolution for gfx950 (MI355X), one kernel
+// template for every dense layer of the CDNA predictor:
+//
+//   conv-LSTM gate conv 5x5 (+ fused cell update)         G = 4 (i, j, f, o)    EPI_LSTM
+//   strided encoder convs 5x5/2, 3x3/2, 1x1               G = 1                 EPI_BIAS_RELU / EPI_RAW_STATS
+//   transposed convs 3x3*2 as a 2x2 conv over the input   G = 4 (output parity) EPI_CONVT_*
+//   CDNA kernel FC [B,8192]x[8192,250], split over K      G = 1                 EPI_PARTIAL
+//
+// GEMM view: rows = output pixels (256 per workgroup: 4 waves x 2 MFMA row blocks of 32),
+// columns = one group of 32 output channels x G gates, K = taps x input channels.
+// A operand: the haloed input tile of one channel chunk staged in LDS ([pixel][KC+4] floats:
+// the +4 pad makes the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots); LayerNorm
+// (+relu) of the producing layer is applied while staging, so normalised tensors are never
+// materialised.  B operand: weights pre-packed [chunk][tap][k8][khalf][N][4] and read straight
+// from L2/L1 with one 16-B load per lane per gate (all four waves read the same lines).
+// One ds_read_b128 / global b128 feeds four v_mfma_f32_32x32x2_f32 (K order inside an 8-channel
+// step is permuted identically on both operands: lane half h supplies channels 4h..4h+3).
+//
+// Numerics: v_mfma_f32_32x32x2_f32 is an exact-fp32 fma chain (no reduced precision).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace vf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kConvThreads = 256;
+constexpr int kConvRows = 256;      // GEMM rows per workgroup
+constexpr float kLnEps = 1e-12f;
+
+enum Epilogue {
+    EPI_LSTM = 0,             // c,h update; h_out + LayerNorm partial sums
+    EPI_BIAS_RELU = 1,        // relu(acc + bias [+ per-sample bias])
+    EPI_RAW_STATS = 2,        // acc + bias, + LayerNorm partial sums
+    EPI_CONVT_RELU = 3,       // depth-to-space, relu(acc + bias)
+    EPI_CONVT_RAW_STATS = 4,  // depth-to-space, acc + bias, + LayerNorm partial sums
+    EPI_PARTIAL = 5           // raw accumulators of one K split
+};
+
+struct ConvSeg {
+    const float *ptr;       // NHWC activations of this input segment
+    long long bstride;      // floats between samples (0: one image broadcast to every sample)
+    int C;                  // channels (= pixel stride)
+    int nchunk;             // ceil(C / KC)
+    const double *ln_part;  // LayerNorm partial sums [B][ln_nparts][2] (sum, sumsq) or null
+    int ln_nparts;
+    float ln_inv_n;         // 1 / (elements normalised together)
+    const float *gamma;     // [gamma_mod]
+    const float *beta;
+    int gamma_mod;
+    int relu;               // relu after (optional) LayerNorm
+};
+
+struct ConvParams {
+    ConvSeg seg[2];
+    int nseg;
+    int B;
+    int Hin, Win;           // input spatial size
+    int Hout, Wout;         // GEMM row grid (transposed conv: == Hin, Win)
+    int KH, KW, stride, pad;
+    int KC;                 // channels per LDS chunk (8, 16 or 32)
+    int NI, TH, TW, RPI;    // images per workgroup, tile shape, GEMM rows reserved per image
+    int tilesY, tilesX;     // tiles per image
+    int ncg;                // groups of 32 output channels
+    int Cout;               // real output channels per gate
+    const float *Wp;        // packed weights
+    const float *bias;      // packed [ncg][G][32]
+    const float *sbias;     // optional per-sample bias [B][sbias_ld]
+    int sbias_ld;
+    float *out;
+    float *cstate;          // EPI_LSTM: cell state, updated in place
+    double *stats;          // LayerNorm partial sums of the output [B][stats_nparts][2]
+    int stats_nparts;
+    int chunks_per_split;   // K split (blockIdx.z)
+    int n_valid;            // EPI_PARTIAL: valid output columns
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    // tanh via exp; exact enough in fp32 (|err| ~ 1 ulp of the quotient), saturates cleanly
+    float e = __expf(-2.0f * fabsf(x));
+    float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int G, int EPI>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    const int KC = p.KC, KCpad = KC + 4, K8 = KC >> 3;
+    const int LH = (p.TH - 1) * p.stride + p.KH, LW = (p.TW - 1) * p.stride + p.KW;
+    const int tile_px = LH * LW;
+    const int tile_floats = p.NI * tile_px * KCpad;
+    float *lnTab = smem + tile_floats;                       // [2][NI][2]: mean, rstd
+    double *red = reinterpret_cast<double *>(lnTab + 4 * p.NI);   // [4 waves][2]
+    const int cg = blockIdx.y;
+    const int tiles_per_img = p.tilesY * p.tilesX;
+
+    int bimg0, ty0, tx0, tile_id;
+    if (p.NI == 1) {
+        bimg0 = blockIdx.x / tiles_per_img;
+        tile_id = blockIdx.x % tiles_per_img;
+        ty0 = (tile_id / p.tilesX) * p.TH;
+        tx0 = (tile_id % p.tilesX) * p.TW;
+    } else {
+        bimg0 = blockIdx.x * p.NI;
+        tile_id = 0; ty0 = 0; tx0 = 0;
+    }
+
+    // ---- LayerNorm statistics of the producing layers (this workgroup's samples only)
+    for (int i = tid; i < p.nseg * p.NI; i += kConvThreads) {
+        const int s = i / p.NI, img = i % p.NI;
+        const ConvSeg &sg = p.seg[s];
+        float mean = 0.f, rstd = 1.f;
+        const int b = bimg0 + img;
+        if (sg.ln_part && b < p.B) {
+            double su = 0.0, sq = 0.0;
+            const double *pp = sg.ln_part + (long long)b * sg.ln_nparts * 2;
+            for (int k = 0; k < sg.ln_nparts; ++k) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
+            const double m = su * (double)sg.ln_inv_n;
+            double var = sq * (double)sg.ln_inv_n - m * m;
+            var = var < 0.0 ? 0.0 : var;
+            mean = (float)m;
+            rstd = (float)(1.0 / sqrt(var + (double)kLnEps));
+        }
+        lnTab[2 * i] = mean;
+        lnTab[2 * i + 1] = rstd;
+    }
+
+    // ---- this lane's two A rows (GEMM rows wave*64 + m*32 + n)
+    const int px_per_img = p.TH * p.TW;
+    int abase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int row = wave * 64 + m * 32 + n;
+        const int img = row / p.RPI, rem = row % p.RPI;
+        const bool ok = img < p.NI && rem < px_per_img;
+        const int y = rem / p.TW, x = rem % p.TW;
+        abase[m] = (ok ? (img * tile_px + y * p.stride * LW + x * p.stride) * KCpad : 0) + kh * 4;
+    }
+
+    f32x16 acc[2][G];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][g][r] = 0.f;
+
+    const int ntaps = p.KH * p.KW;
+    const int Ntot = p.ncg * G * 32;
+    const int total_chunks = p.seg[0].nchunk + (p.nseg > 1 ? p.seg[1].nchunk : 0);
+    const int ch_begin = blockIdx.z * p.chunks_per_split;
+    const int ch_end = min(ch_begin + p.chunks_per_split, total_chunks);
+    const float *wlane = p.Wp + ((long long)kh * Ntot + (cg * G) * 32 + n) * 4;
+    const long long wstep = (long long)2 * Ntot * 4;        // floats per (chunk, tap, k8) block
+
+    const int q4 = KC >> 2;
+    const int items = p.NI * tile_px * q4;
+
+    for (int ci = ch_begin; ci < ch_end; ++ci) {
+        const int s = (ci < p.seg[0].nchunk) ? 0 : 1;
+        const ConvSeg &sg = p.seg[s];
+        const int c0 = (s == 0 ? ci : ci - p.seg[0].nchunk) * KC;
+        const bool vec_ok = (sg.C & 3) == 0;
+
+        __syncthreads();        // previous chunk fully consumed (and lnTab visible on entry)
+        for (int it = tid; it < items; it += kConvThreads) {
+            const int pix = it / q4, q = it - pix * q4;
+            const int img = pix / tile_px, r = pix - img * tile_px;
+            const int ly = r / LW, lx = r - ly * LW;
+            const int iy = ty0 * p.stride - p.pad + ly, ix = tx0 * p.stride - p.pad + lx;
+            const int b = bimg0 + img;
+            const int c = c0 + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && c < sg.C) {
+                const float *src = sg.ptr + (long long)b * sg.bstride +
+                                   ((long long)iy * p.Win + ix) * sg.C + c;
+                const int nvalid = min(4, sg.C - c);
+                if (vec_ok) {
+                    v = *reinterpret_cast<const f32x4 *>(src);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (j < nvalid) ? src[j] : 0.f;
+                }
+                if (sg.ln_part) {
+                    const float mean = lnTab[2 * (s * p.NI + img)];
+                    const float rstd = lnTab[2 * (s * p.NI + img) + 1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cc = (c + j) % sg.gamma_mod;
+                        v[j] = (v[j] - mean) * rstd * sg.gamma[cc] + sg.beta[cc];
+                    }
+                }
+                if (sg.relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (j < nvalid) ? v[j] : 0.f;
+            }
+            *reinterpret_cast<f32x4 *>(&smem[pix * KCpad + 4 * q]) = v;
+        }
+        __syncthreads();
+
+        const float *wchunk = wlane + (long long)ci * ntaps * K8 * wstep;
+        for (int ky = 0; ky < p.KH; ++ky) {
+            for (int kx = 0; kx < p.KW; ++kx) {
+                const int aoff = (ky * LW + kx) * KCpad;
+                const float *wtap = wchunk + (long long)(ky * p.KW + kx) * K8 * wstep;
+                for (int k8 = 0; k8 < K8; ++k8) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&smem[abase[0] + aoff + k8 * 8]);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&smem[abase[1] + aoff + k8 * 8]);
+                    f32x4 bw[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        bw[g] = *reinterpret_cast<const f32x4 *>(wtap + k8 * wstep + g * 128);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bw[g][j], acc[0][g], 0, 0, 0);
+                            acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bw[g][j], acc[1][g], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    const int ch = cg * 32 + n;             // output channel of this lane
+    float bias_g[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) bias_g[g] = (EPI == EPI_PARTIAL) ? 0.f : p.bias[(cg * G + g) * 32 + n];
+
+    float ssum = 0.f, ssq = 0.f;            // LayerNorm partials over this lane's outputs
+
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int img = row / p.RPI, rem = row % p.RPI;
+            const int y = ty0 + rem / p.TW, x = tx0 + rem % p.TW;
+            const int b = bimg0 + img;
+            const bool ok = img < p.NI && rem < px_per_img && b < p.B && y < p.Hout && x < p.Wout;
+            if (!ok) continue;
+            if constexpr (EPI == EPI_LSTM) {
+                const long long o = (((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch;
+                const float gi = acc[m][0][r] + bias_g[0];
+                const float gj = acc[m][1 % G][r] + bias_g[1 % G];
+                const float gf = acc[m][2 % G][r] + bias_g[2 % G];
+                const float go = acc[m][3 % G][r] + bias_g[3 % G];
+                const float c_old = p.cstate[o];
+                const float c_new = c_old * sigmoidf_(gf + 1.0f) + sigmoidf_(gi) * tanhf_(gj);
+                const float h_new = tanhf_(c_new) * sigmoidf_(go);
+                p.cstate[o] = c_new;
+                p.out[o] = h_new;
+                ssum += h_new; ssq += h_new * h_new;
+            } else if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_RAW_STATS) {
+                if (ch < p.Cout) {
+                    float v = acc[m][0][r] + bias_g[0];
+                    if (p.sbias) v += p.sbias[(long long)b * p.sbias_ld + ch];
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                    p.out[(((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch] = v;
+                    ssum += v; ssq += v * v;
+                }
+            } else if constexpr (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS) {
+                if (ch < p.Cout) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int oy = 2 * y + (g >> 1), ox = 2 * x + (g & 1);
+                        float v = acc[m][g][r] + bias_g[g];
+                        if (EPI == EPI_CONVT_RELU) v = fmaxf(v, 0.f);
+                        p.out[(((long long)b * (2 * p.Hout) + oy) * (2 * p.Wout) + ox) * p.Cout + ch] = v;
+                        ssum += v; ssq += v * v;
+                    }
+                }
+            } else {    // EPI_PARTIAL: [split][B][n_valid]
+                if (ch < p.n_valid)
+                    p.out[((long long)blockIdx.z * p.B + b) * p.n_valid + ch] = acc[m][0][r];
+            }
+        }
+    }
+
+    if constexpr (EPI == EPI_LSTM || EPI == EPI_RAW_STATS || EPI == EPI_CONVT_RAW_STATS) {
+        // deterministic reduction: lane -> wave (xor butterfly) -> fixed-order sum over waves
+        const double wsum = wave_sum((double)ssum), wsq = wave_sum((double)ssq);
+        __syncthreads();
+        if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
+        __syncthreads();
+        if (p.NI == 1) {
+            if (tid == 0 && bimg0 < p.B) {
+                double su = 0.0, sq = 0.0;
+                for (int w = 0; w < 4; ++w) { su += red[2 * w]; sq += red[2 * w + 1]; }
+                double *dst = p.stats + ((long long)bimg0 * p.stats_nparts + tile_id * p.ncg + cg) * 2;
+                dst[0] = su; dst[1] = sq;
+            }
+        } else {
+            // RPI is a multiple of 64 here: wave w owns image slot (w*64)/RPI entirely or shares
+            // it with its neighbours; sum the waves of each image in fixed order
+            const int waves_per_img = p.RPI / 64;
+            if (lane == 0 && (wave % waves_per_img) == 0) {
+                const int img = wave / waves_per_img;
+                const int b = bimg0 + img;
+                if (img < p.NI && b < p.B) {
+                    double su = 0.0, sq = 0.0;
+                    for (int w = 0; w < waves_per_img; ++w) { su += red[2 * (wave + w)]; sq += red[2 * (wave + w) + 1]; }
+                    double *dst = p.stats + ((long long)b * p.stats_nparts + cg) * 2;
+                    dst[0] = su; dst[1] = sq;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace vf

@@ -1,0 +1,258 @@
+"""MI355X-native predictor with the ``VPredEvaluation`` duck-type.
+
+Plugs into ``PixelCostController`` where the reference plugs
+``robonet.video_prediction.testing.VPredEvaluation`` (reference
+``visual_mpc/policy/cem_controllers/pixel_cost_controller.py:11-12,29-36,83-84,175``): ctor
+``(model_path, hparams_dict, n_gpus=, first_gpu=)``, ``restore()``, ``n_context``,
+``sequence_length``, ``__call__(context, {'actions'}) -> {'predicted_frames',
+'predicted_pixel_distributions'}``.  Like the legacy adapter it takes the *whole* history and
+slices the last ``n_context`` frames itself (reference ``video_prediction/pred_util.py:4-13``)
+and chunks the sample batch by ``run_batch_size`` (``pred_util.py:21-48``; the last chunk is
+simply run ragged instead of zero-padded - samples are independent).
+
+On top of that contract it offers the fused fast path ``score()``: rollouts are reduced to
+per-sample costs on the GPU, sharded over the ranks of ``torch.distributed`` when that is
+initialised (rank r evaluates samples ``[r*M/G, (r+1)*M/G)``; reference tower slicing
+``video_prediction/setup_predictor.py:34-39``), and only the ``M`` scores are all-gathered
+(RCCL) - the reference instead concatenates full predicted videos on the host
+(``setup_predictor.py:155-162``).
+
+PyTorch is the buffer carrier only: tensors own the device memory whose pointers cross the
+C ABI of ``include/vf_hip.h``; all arithmetic runs in ``libvf_hip.so``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from visual_foresight_amd import _lib
+from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights
+
+
+def _dist_info():
+    """(rank, world) of the sample-sharding group; (0, 1) when torch.distributed is not up."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
+def shard_bounds(M, rank, world):
+    """Contiguous sample range of one rank; the ranges partition [0, M) in rank order."""
+    base, extra = divmod(M, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class HipVPredEvaluation(object):
+    wants_agent_params = True       # PixelCostController passes adim/sdim/size/sequence_length
+    n_context_default = 2
+
+    def __init__(self, model_path, hparams, n_gpus=1, first_gpu=0):
+        import torch
+        self._torch = torch
+        hp = dict(hparams)
+        self.model_path = os.path.expanduser(model_path) if model_path else ''
+        self.n_context = int(hp.get('n_context', self.n_context_default))
+        self.sequence_length = int(hp.get('sequence_length', 15))
+        self.n_cam = int(hp.get('ncam', 1))
+        if self.n_cam != 1:
+            raise NotImplementedError('HipVPredEvaluation drives one view; multi-view is one predictor per view')
+        self.run_batch_size = int(hp.get('run_batch_size', 200))
+        self.seed = int(hp.get('seed', 0))
+        self.cfg = CdnaConfig(height=hp.get('image_height', 64), width=hp.get('image_width', 64),
+                              adim=hp.get('adim', 4), sdim=hp.get('sdim', 5),
+                              ndesig=hp.get('designated_pixel_count', 1), n_context=self.n_context,
+                              sequence_length=self.sequence_length)
+        if not torch.cuda.is_available():
+            raise _lib.VfError('HipVPredEvaluation needs a ROCm GPU (no CPU fallback)')
+        # one process drives one GPU; under torchrun LOCAL_RANK picks it
+        local_rank = int(os.environ.get('LOCAL_RANK', 0)) if _dist_info()[1] > 1 else 0
+        self.device_index = int(first_gpu) + local_rank
+        self.device = torch.device('cuda', self.device_index)
+        self._libh = _lib.load_library()
+        c = self.cfg
+        self._c_cfg = _lib.VfConfig(c.height, c.width, c.adim, c.sdim, c.ndesig, c.n_context,
+                                    c.sequence_length, c.num_masks, self.run_batch_size,
+                                    self.device_index)
+        self._handle = ctypes.c_void_p()
+        _lib.check(self._libh.vf_create(ctypes.byref(self._c_cfg), ctypes.byref(self._handle)))
+        self.weights = None
+        self._last_M = 0
+        self._last_lo = 0
+        self._scores_dev = None
+
+    def __del__(self):
+        try:
+            if getattr(self, '_handle', None) and self._handle.value:
+                self._libh.vf_destroy(self._handle)
+                self._handle = ctypes.c_void_p()
+        except Exception:   # interpreter shutdown
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def restore(self, weights=None):
+        """Load ``model_path`` (manifest.json + weights.bin) or, with no path, seeded random weights."""
+        if weights is None:
+            if self.model_path:
+                weights = CdnaWeights.load(self.model_path, self.cfg)
+            else:
+                weights = CdnaWeights.random(self.cfg, seed=self.seed)
+        self.weights = weights
+        blob = np.concatenate([v.ravel() for v in weights.tensors.values()]).astype(np.float32)
+        want = self._libh.vf_weight_count(ctypes.byref(self._c_cfg))
+        if blob.size != want:
+            raise _lib.VfError('weight blob has %d floats, library expects %d' % (blob.size, want))
+        _lib.check(self._libh.vf_load_weights(self._handle, blob.ctypes.data_as(ctypes.c_void_p),
+                                              blob.size))
+        return self
+
+    # ------------------------------------------------------------------ context
+    def _stream(self):
+        return ctypes.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _set_context(self, context):
+        torch, nc, c = self._torch, self.n_context, self.cfg
+        frames = np.ascontiguousarray(np.asarray(context['context_frames'])[-nc:, 0])
+        if frames.dtype != np.uint8 or frames.shape != (nc, c.height, c.width, 3):
+            raise ValueError('context_frames must be uint8 [>=%d, 1, %d, %d, 3], got %s %s'
+                             % (nc, c.height, c.width, frames.dtype, frames.shape))
+        distrib = np.ascontiguousarray(
+            np.asarray(context['context_pixel_distributions'], dtype=np.float32)[-nc:, 0])
+        states = np.ascontiguousarray(np.asarray(context['context_states'], dtype=np.float32)[-nc:])
+        if states.shape != (nc, c.sdim) or distrib.shape != (nc, c.height, c.width, c.ndesig):
+            raise ValueError('bad context shapes: states %s distrib %s' % (states.shape, distrib.shape))
+        if nc > 1:
+            acts = np.asarray(context['context_actions'], dtype=np.float32).reshape(-1, c.adim)[-(nc - 1):]
+            if acts.shape[0] != nc - 1:
+                raise ValueError('need at least %d executed actions as context' % (nc - 1))
+            acts = np.ascontiguousarray(acts)
+        else:
+            acts = np.zeros((1, c.adim), np.float32)
+        dev = self.device
+        self._ctx = [torch.from_numpy(a).to(dev) for a in (frames, states, acts, distrib)]
+        f, s, a, d = self._ctx
+        _lib.check(self._libh.vf_set_context(self._handle, f.data_ptr(), s.data_ptr(), a.data_ptr(),
+                                             d.data_ptr(), self._stream()))
+
+    # ------------------------------------------------------------------ rollouts
+    def _rollout_chunk(self, actions_dev, goal_pix, finalweight, scores_dev, per_task_dev):
+        B = actions_dev.shape[0]
+        goal = (ctypes.c_int32 * (2 * self.cfg.ndesig))(*[int(v) for v in np.asarray(goal_pix).reshape(-1)])
+        _lib.check(self._libh.vf_rollout(self._handle, actions_dev.data_ptr(), B, goal,
+                                         ctypes.c_float(finalweight), scores_dev.data_ptr(),
+                                         per_task_dev.data_ptr(), self._stream()))
+
+    def _check_actions(self, actions):
+        actions = np.asarray(actions)
+        T = self.sequence_length - self.n_context
+        if actions.ndim != 3 or actions.shape[1] != T or actions.shape[2] != self.cfg.adim:
+            raise ValueError('actions must be [M, %d, %d], got %s' % (T, self.cfg.adim, actions.shape))
+        return actions
+
+    def score(self, context, inputs, goal_pix, finalweight=10., only_take_first_view=False):
+        """Fused rollout + expected-pixel-distance cost.  Returns (scores[M], scores_per_task[M, nd]) float64.
+
+        Only the chunk evaluated last stays resident for ``fetch_pixel_distributions``; with
+        ``M <= run_batch_size`` (the reference default, ``pixel_cost_controller.py:31``) that is
+        the whole local shard.
+        """
+        torch = self._torch
+        actions = self._check_actions(inputs['actions'])
+        M = actions.shape[0]
+        nd = self.cfg.ndesig
+        goal = np.asarray(goal_pix).reshape(self.n_cam, nd, 2)[0]
+        rank, world = _dist_info()
+        lo, hi = shard_bounds(M, rank, world)
+        with torch.cuda.device(self.device):
+            self._set_context(context)
+            local = torch.from_numpy(np.ascontiguousarray(actions[lo:hi], dtype=np.float32)).to(self.device)
+            scores = torch.empty(hi - lo, dtype=torch.float32, device=self.device)
+            per_task = torch.empty((hi - lo, nd), dtype=torch.float32, device=self.device)
+            bs = self.run_batch_size
+            for c0 in range(0, hi - lo, bs):
+                c1 = min(c0 + bs, hi - lo)
+                self._rollout_chunk(local[c0:c1], goal, finalweight, scores[c0:c1], per_task[c0:c1])
+                self._last_lo, self._last_M = lo + c0, c1 - c0
+            if world > 1:
+                scores, per_task = self._all_gather(scores, per_task, M, world)
+            scores_np = scores.cpu().numpy().astype(np.float64)
+            per_task_np = per_task.cpu().numpy().astype(np.float64)
+        if only_take_first_view:
+            per_task_np = per_task_np[:, :1]
+            scores_np = per_task_np[:, 0].copy()
+        return scores_np, per_task_np
+
+    def _all_gather(self, scores, per_task, M, world):
+        """One collective: every rank's [scores | per-task scores] rows -> all M rows on every rank."""
+        torch = self._torch
+        import torch.distributed as dist
+        nd = per_task.shape[1]
+        packed = torch.cat([scores[:, None], per_task], dim=1).contiguous()
+        counts = [shard_bounds(M, r, world) for r in range(world)]
+        sizes = [b - a for a, b in counts]
+        if len(set(sizes)) == 1:
+            out = torch.empty((M, 1 + nd), dtype=packed.dtype, device=packed.device)
+            dist.all_gather_into_tensor(out, packed)
+        else:   # ragged shards: gather padded rows, then drop the padding
+            width = max(sizes)
+            padded = torch.zeros((width, 1 + nd), dtype=packed.dtype, device=packed.device)
+            padded[:packed.shape[0]] = packed
+            buf = torch.empty((world * width, 1 + nd), dtype=packed.dtype, device=packed.device)
+            dist.all_gather_into_tensor(buf, padded)
+            out = torch.cat([buf[r * width:r * width + sizes[r]] for r in range(world)], dim=0)
+        return out[:, 0].contiguous(), out[:, 1:].contiguous()
+
+    def fetch_pixel_distributions(self, sample_index):
+        """Normalised distributions ``[T, ncam, H, W, ndesig]`` of one sample of the last rollout."""
+        torch, c = self._torch, self.cfg
+        T = self.sequence_length - self.n_context
+        rank, world = _dist_info()
+        local = sample_index - self._last_lo
+        have = 0 <= local < self._last_M
+        out = torch.zeros((T, c.height, c.width, c.ndesig), dtype=torch.float32, device=self.device)
+        if have:
+            with torch.cuda.device(self.device):
+                _lib.check(self._libh.vf_export(self._handle, int(local), 1, None, out.data_ptr(), None,
+                                                self._stream()))
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(out)        # exactly one rank holds the sample, the others add zeros
+        elif not have:
+            raise IndexError('sample %d is not resident (last chunk holds [%d, %d))'
+                             % (sample_index, self._last_lo, self._last_lo + self._last_M))
+        return out.cpu().numpy()[:, None]
+
+    def __call__(self, context, inputs):
+        """Reference-compatible path: materialise all predicted frames and distributions on the host."""
+        torch, c = self._torch, self.cfg
+        actions = self._check_actions(inputs['actions'])
+        M, T = actions.shape[:2]
+        frames = np.empty((M, T, 1, c.height, c.width, 3), np.float32)
+        distrib = np.empty((M, T, 1, c.height, c.width, c.ndesig), np.float32)
+        states = np.empty((M, T, c.sdim), np.float32)
+        zero_goal = np.zeros((c.ndesig, 2), np.int32)
+        bs = self.run_batch_size
+        with torch.cuda.device(self.device):
+            self._set_context(context)
+            acts = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32)).to(self.device)
+            scores = torch.empty(bs, dtype=torch.float32, device=self.device)
+            per_task = torch.empty((bs, c.ndesig), dtype=torch.float32, device=self.device)
+            for c0 in range(0, M, bs):
+                c1 = min(c0 + bs, M)
+                n = c1 - c0
+                self._rollout_chunk(acts[c0:c1], zero_goal, 1.0, scores[:n], per_task[:n])
+                self._last_lo, self._last_M = c0, n
+                f = torch.empty((n, T, c.height, c.width, 3), dtype=torch.float32, device=self.device)
+                d = torch.empty((n, T, c.height, c.width, c.ndesig), dtype=torch.float32, device=self.device)
+                s = torch.empty((n, T, c.sdim), dtype=torch.float32, device=self.device)
+                _lib.check(self._libh.vf_export(self._handle, 0, n, f.data_ptr(), d.data_ptr(), s.data_ptr(),
+                                                self._stream()))
+                frames[c0:c1, :, 0] = f.cpu().numpy()
+                distrib[c0:c1, :, 0] = d.cpu().numpy()
+                states[c0:c1] = s.cpu().numpy()
+        return {'predicted_frames': frames, 'predicted_pixel_distributions': distrib,
+                'predicted_states': states}
