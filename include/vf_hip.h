@@ -102,6 +102,13 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
 int vf_export(vf_handle *h, int32_t first, int32_t count, float *d_frames, float *d_distrib,
               float *d_states, void *stream);
 
+/* Measurement hooks (no reference counterpart).  While enabled, every launch of the dominant
+ * kernel - the fused conv-LSTM gate GEMM - is bracketed by HIP events on the launch stream.
+ * vf_get_profile waits for them and returns the summed kernel time, the number of launches and
+ * their algorithmic FLOPs (2 * B*H*W * 25*(Cx+Ch) * 4C each), then resets the counters. */
+int vf_set_profiling(vf_handle *h, int32_t enable);
+int vf_get_profile(vf_handle *h, double *kernel_ms, int64_t *launches, double *flops);
+
 /* Introspection for tests/benchmarks: algorithmic multiply-accumulates of one sample-step. */
 double vf_macs_per_sample_step(const vf_config *cfg);
 

@@ -1,0 +1,75 @@
+"""CPU checks of the C-ABI library: it loads, exports what include/vf_hip.h declares, and its
+shape bookkeeping agrees with the Python architecture table (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from visual_foresight_amd import _lib
+from visual_foresight_amd.video_prediction import cdna_arch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    _lib.build_library()
+    return _lib.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    header = open(os.path.join(REPO, 'include', 'vf_hip.h')).read()
+    declared = set(re.findall(r'\b(vf_[a-z_]+)\s*\(', header))
+    assert declared, 'no prototypes found in the header'
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vf_abi_version() == 1
+
+
+@pytest.mark.parametrize('H,W,adim,sdim,nd', [(64, 64, 4, 5, 1), (48, 64, 3, 3, 2), (128, 128, 5, 5, 4)])
+def test_weight_count_and_macs_agree_with_arch_table(lib, H, W, adim, sdim, nd):
+    cfg = cdna_arch.CdnaConfig(height=H, width=W, adim=adim, sdim=sdim, ndesig=nd)
+    c = _lib.VfConfig(H, W, adim, sdim, nd, 2, 15, 10, 8, 0)
+    n = sum(int(np.prod(s)) for s in cdna_arch.tensor_shapes(cfg).values())
+    assert lib.vf_weight_count(ctypes.byref(c)) == n
+    macs = sum(cdna_arch.macs_per_sample_step(cfg).values())
+    assert lib.vf_macs_per_sample_step(ctypes.byref(c)) == pytest.approx(macs, rel=1e-12)
+
+
+def test_survey_mac_count():
+    macs = sum(cdna_arch.macs_per_sample_step(cdna_arch.CdnaConfig()).values())
+    assert macs == pytest.approx(1.63e9, rel=2e-3)      # 1.63 GMAC per sample-step
+
+
+def test_invalid_config_is_rejected(lib):
+    bad = _lib.VfConfig(60, 64, 4, 5, 1, 2, 15, 10, 8, 0)
+    assert lib.vf_weight_count(ctypes.byref(bad)) == 0
+    assert b'multiples of 8' in lib.vf_last_error()
+    with pytest.raises(_lib.VfError):
+        _lib.check(-1)
+
+
+def test_predictor_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+    with pytest.raises(_lib.VfError):
+        HipVPredEvaluation('', {'designated_pixel_count': 1, 'run_batch_size': 2})
+
+
+def test_weights_file_roundtrip(tmp_path):
+    cfg = cdna_arch.CdnaConfig(height=32, width=32)
+    w = cdna_arch.CdnaWeights.random(cfg, seed=5, bias_scale=0.1, ln_jitter=0.1)
+    w.save(str(tmp_path))
+    r = cdna_arch.CdnaWeights.load(str(tmp_path), cdna_arch.CdnaConfig(height=32, width=32, ndesig=2))
+    for k in w.tensors:
+        np.testing.assert_array_equal(w.tensors[k], r.tensors[k])
+    with pytest.raises(ValueError):
+        cdna_arch.CdnaWeights.load(str(tmp_path), cdna_arch.CdnaConfig(height=64, width=64))
+    again = cdna_arch.CdnaWeights.random(cfg, seed=5, bias_scale=0.1, ln_jitter=0.1)
+    for k in w.tensors:
+        np.testing.assert_array_equal(w.tensors[k], again.tensors[k])

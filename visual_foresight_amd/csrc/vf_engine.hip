@@ -250,6 +250,12 @@ struct vf_handle {
     long long sums_step_stride = 0;
 
     std::vector<void *> allocs;
+
+    // optional per-launch timing of the conv-LSTM kernel (HIP events on the launch stream)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double prof_flops = 0.0;        // algorithmic FLOPs of the launches bracketed so far
 };
 
 namespace vf {
@@ -463,6 +469,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
 int vf_destroy(vf_handle *h) {
     if (!h) return VF_OK;
     for (void *p : h->allocs) (void)hipFree(p);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
     return VF_OK;
 }
@@ -613,7 +620,19 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
             SegArg hs = plain(h->h_state[k][cur], (long long)lh[k] * lw[k] * L[k]);
             ConvParams q = make_params(h->lstm[k], B, x, &hs);
             q.out = h->h_state[k][nxt]; q.cstate = h->c_state[k]; q.stats = h->st_h[k];
-            return launch_conv_t<4, EPI_LSTM>(h->lstm[k], q, st);
+            if (!h->profiling) return launch_conv_t<4, EPI_LSTM>(h->lstm[k], q, st);
+            while (h->ev_pool.size() < h->ev_used + 2) {
+                hipEvent_t e;
+                VF_HIP_CHECK(hipEventCreate(&e));
+                h->ev_pool.push_back(e);
+            }
+            VF_HIP_CHECK(hipEventRecord(h->ev_pool[h->ev_used], st));
+            int r = launch_conv_t<4, EPI_LSTM>(h->lstm[k], q, st);
+            VF_HIP_CHECK(hipEventRecord(h->ev_pool[h->ev_used + 1], st));
+            h->ev_used += 2;
+            const ConvLayer &ll = h->lstm[k];
+            h->prof_flops += 2.0 * B * ll.Hout * ll.Wout * 25.0 * (ll.segC[0] + ll.segC[1]) * 4.0 * ll.Cout;
+            return r;
         };
         if ((rc = run_lstm(0, enc0_n))) return rc;
         if ((rc = run_lstm(1, h_normed(0, h->h_state[0][nxt])))) return rc;
@@ -723,6 +742,32 @@ int vf_export(vf_handle *h, int32_t first, int32_t count, float *d_frames, float
                            h->ntiles, d_distrib);
         VF_HIP_CHECK(hipGetLastError());
     }
+    return VF_OK;
+}
+
+int vf_set_profiling(vf_handle *h, int32_t enable) {
+    if (!h) return fail(VF_ERR_INVALID, "null handle");
+    h->profiling = enable != 0;
+    h->ev_used = 0;
+    h->prof_flops = 0.0;
+    return VF_OK;
+}
+
+int vf_get_profile(vf_handle *h, double *kernel_ms, int64_t *launches, double *flops) {
+    if (!h || !kernel_ms || !launches || !flops) return fail(VF_ERR_INVALID, "null argument");
+    VF_HIP_CHECK(hipSetDevice(h->cfg.device));
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        VF_HIP_CHECK(hipEventSynchronize(h->ev_pool[i + 1]));
+        float dt = 0.f;
+        VF_HIP_CHECK(hipEventElapsedTime(&dt, h->ev_pool[i], h->ev_pool[i + 1]));
+        ms += dt;
+    }
+    *kernel_ms = ms;
+    *launches = (int64_t)(h->ev_used / 2);
+    *flops = h->prof_flops;
+    h->ev_used = 0;
+    h->prof_flops = 0.0;
     return VF_OK;
 }
 

@@ -27,24 +27,7 @@ import numpy as np
 
 from visual_foresight_amd import _lib
 from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights
-
-
-def _dist_info():
-    """(rank, world) of the sample-sharding group; (0, 1) when torch.distributed is not up."""
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_rank(), dist.get_world_size()
-    except ImportError:
-        pass
-    return 0, 1
-
-
-def shard_bounds(M, rank, world):
-    """Contiguous sample range of one rank; the ranges partition [0, M) in rank order."""
-    base, extra = divmod(M, world)
-    lo = rank * base + min(rank, extra)
-    return lo, lo + base + (1 if rank < extra else 0)
+from visual_foresight_amd.video_prediction.sharding import dist_info as _dist_info, shard_bounds, all_gather_rows
 
 
 class HipVPredEvaluation(object):
@@ -92,6 +75,17 @@ class HipVPredEvaluation(object):
                 self._handle = ctypes.c_void_p()
         except Exception:   # interpreter shutdown
             pass
+
+    # ------------------------------------------------------------------ measurement hooks
+    def set_profiling(self, enable):
+        _lib.check(self._libh.vf_set_profiling(self._handle, int(bool(enable))))
+
+    def get_profile(self):
+        """-> (kernel_ms, launches, flops) of the conv-LSTM kernel since the last call."""
+        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(self._libh.vf_get_profile(self._handle, ctypes.byref(ms), ctypes.byref(n),
+                                             ctypes.byref(fl)))
+        return ms.value, n.value, fl.value
 
     # ------------------------------------------------------------------ weights
     def restore(self, weights=None):
@@ -187,23 +181,9 @@ class HipVPredEvaluation(object):
         return scores_np, per_task_np
 
     def _all_gather(self, scores, per_task, M, world):
-        """One collective: every rank's [scores | per-task scores] rows -> all M rows on every rank."""
-        torch = self._torch
-        import torch.distributed as dist
-        nd = per_task.shape[1]
-        packed = torch.cat([scores[:, None], per_task], dim=1).contiguous()
-        counts = [shard_bounds(M, r, world) for r in range(world)]
-        sizes = [b - a for a, b in counts]
-        if len(set(sizes)) == 1:
-            out = torch.empty((M, 1 + nd), dtype=packed.dtype, device=packed.device)
-            dist.all_gather_into_tensor(out, packed)
-        else:   # ragged shards: gather padded rows, then drop the padding
-            width = max(sizes)
-            padded = torch.zeros((width, 1 + nd), dtype=packed.dtype, device=packed.device)
-            padded[:packed.shape[0]] = packed
-            buf = torch.empty((world * width, 1 + nd), dtype=packed.dtype, device=packed.device)
-            dist.all_gather_into_tensor(buf, padded)
-            out = torch.cat([buf[r * width:r * width + sizes[r]] for r in range(world)], dim=0)
+        """One collective: every rank's [score | per-task scores] rows -> all M rows on every rank."""
+        packed = self._torch.cat([scores[:, None], per_task], dim=1).contiguous()
+        out = all_gather_rows(packed, M)
         return out[:, 0].contiguous(), out[:, 1:].contiguous()
 
     def fetch_pixel_distributions(self, sample_index):
