@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--iterations', type=int, default=3)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-samples', type=int, default=4)
+    ap.add_argument('--cpu-samples', type=int, default=128)
     return ap.parse_args()
 
 
