@@ -139,7 +139,7 @@ def main():
             out = plan()
         sync()
         elapsed = time.perf_counter() - t0
-        kernel_ms, launches, flops = ctrl.predictor.get_profile()
+        kernel_ms, launches, flops, busy_ms = ctrl.predictor.get_profile()
         ctrl.predictor.set_profiling(False)
 
     if world > 1:
@@ -165,7 +165,9 @@ def main():
                      'frac': (flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if kernel_ms > 0 else None,
                      'traffic': None, 'launches': launches,
                      'avg_launch_us': 1e3 * kernel_ms / max(launches, 1),
-                     'kernel_time_share': kernel_ms * 1e-3 / elapsed},
+                     'busy_ms': busy_ms, 'achieved_while_busy': flops / (busy_ms * 1e-3) / 1e12 if busy_ms > 0 else None,
+                     'substreams': ctrl.predictor.substreams,
+                     'kernel_time_share': busy_ms * 1e-3 / elapsed},
         'best_score_last_plan': float(np.min(out['plan_stat']['scores_itr%d' % (iters - 1)])),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -102,12 +102,29 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
 int vf_export(vf_handle *h, int32_t first, int32_t count, float *d_frames, float *d_distrib,
               float *d_states, void *stream);
 
+/* Sub-batch concurrency (no reference counterpart).  Samples never interact before their
+ * scores are compared, so vf_rollout may cut the batch into n contiguous sub-batches that
+ * advance on internal streams forked from / joined back to the caller's stream; idle CUs in
+ * the tail of one sub-batch's launch are filled by the other's.  Results are bit-identical
+ * for every n.  Default 1. */
+int vf_set_substreams(vf_handle *h, int32_t n);
+
+/* Context de-duplication (default on).  While a step's inputs are context, part of the network
+ * sees identical inputs for every sample (step < n_context-1: everything; step < n_context: the
+ * encoder up to enc2); those launches then run once with batch 1 and are broadcast.  The
+ * per-sample arithmetic is unchanged, results are bit-identical either way; the switch exists
+ * for A/B measurements. */
+int vf_set_dedup(vf_handle *h, int32_t enable);
+
 /* Measurement hooks (no reference counterpart).  While enabled, every launch of the dominant
- * kernel - the fused conv-LSTM gate GEMM - is bracketed by HIP events on the launch stream.
- * vf_get_profile waits for them and returns the summed kernel time, the number of launches and
- * their algorithmic FLOPs (2 * B*H*W * 25*(Cx+Ch) * 4C each), then resets the counters. */
+ * kernel - the fused conv-LSTM gate GEMM - is bracketed by HIP events on its launch stream.
+ * vf_get_profile waits for them and returns: kernel_ms = sum of the per-launch durations,
+ * busy_ms = time during which at least one such launch was in flight (== kernel_ms when
+ * launches do not overlap), the number of launches and their algorithmic FLOPs
+ * (2 * B*H*W * 25*(Cx+Ch) * 4C each); then it resets the counters. */
 int vf_set_profiling(vf_handle *h, int32_t enable);
-int vf_get_profile(vf_handle *h, double *kernel_ms, int64_t *launches, double *flops);
+int vf_get_profile(vf_handle *h, double *kernel_ms, int64_t *launches, double *flops,
+                   double *busy_ms);
 
 /* Introspection for tests/benchmarks: algorithmic multiply-accumulates of one sample-step. */
 double vf_macs_per_sample_step(const vf_config *cfg);

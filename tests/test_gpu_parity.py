@@ -186,3 +186,24 @@ def test_errors_are_loud():
     pred, _ = _predictor(32, 32, 2, 1, bs=2)
     with pytest.raises(ValueError):
         pred.score(_context(32, 32, 1, np.random.RandomState(0)), {'actions': np.zeros((2, 5, 4))}, [[[0, 0]]])
+
+
+def test_dedup_and_substreams_are_bit_identical():
+    """Context de-duplication and sub-batch streams only reorganise launches: same bits out."""
+    H = W = 32
+    T, M = 3, 37
+    pred, _ = _predictor(H, W, T, 2, bs=M)
+    rs = np.random.RandomState(31)
+    ctx = _context(H, W, 2, rs)
+    actions = rs.normal(0, 0.1, (M, T, 4))
+    goal = np.array([[[3, 20], [30, 1]]])
+    outs = []
+    for dedup, nsub in ((1, 1), (0, 1), (1, 2), (0, 3)):
+        pred.set_dedup(dedup)
+        pred.set_substreams(nsub)
+        s, pt = pred.score(ctx, {'actions': actions}, goal)
+        got = pred(ctx, {'actions': actions})
+        outs.append((s, pt, got['predicted_frames'], got['predicted_pixel_distributions'], got['predicted_states']))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)

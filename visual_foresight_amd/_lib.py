@@ -19,7 +19,7 @@ SOURCES = [os.path.join(_HERE, 'csrc', f) for f in
 
 EXPORTS = ('vf_abi_version', 'vf_last_error', 'vf_weight_count', 'vf_create', 'vf_destroy',
            'vf_load_weights', 'vf_set_context', 'vf_rollout', 'vf_export',
-           'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile')
+           'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile', 'vf_set_substreams', 'vf_set_dedup')
 
 
 class VfError(RuntimeError):
@@ -90,8 +90,11 @@ def load_library():
     lib.vf_export.argtypes = [P, ctypes.c_int32, ctypes.c_int32, P, P, P, P]
     lib.vf_set_profiling.argtypes = [P, ctypes.c_int32]
     lib.vf_get_profile.argtypes = [P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
-                                   ctypes.POINTER(ctypes.c_double)]
-    lib.vf_set_profiling.restype = lib.vf_get_profile.restype = ctypes.c_int
+                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    lib.vf_set_substreams.argtypes = [P, ctypes.c_int32]
+    lib.vf_set_dedup.argtypes = [P, ctypes.c_int32]
+    lib.vf_set_dedup.restype = ctypes.c_int
+    lib.vf_set_profiling.restype = lib.vf_get_profile.restype = lib.vf_set_substreams.restype = ctypes.c_int
     for name in ('vf_create', 'vf_destroy', 'vf_load_weights', 'vf_set_context', 'vf_rollout',
                  'vf_export'):
         getattr(lib, name).restype = ctypes.c_int

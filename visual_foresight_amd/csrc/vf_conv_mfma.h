@@ -44,6 +44,7 @@ struct ConvSeg {
     int C;                  // channels (= pixel stride)
     int nchunk;             // ceil(C / KC)
     const double *ln_part;  // LayerNorm partial sums [B][ln_nparts][2] (sum, sumsq) or null
+    long long ln_bstride;   // doubles between samples (0: shared statistics)
     int ln_nparts;
     float ln_inv_n;         // 1 / (elements normalised together)
     const float *gamma;     // [gamma_mod]
@@ -69,7 +70,9 @@ struct ConvParams {
     const float *sbias;     // optional per-sample bias [B][sbias_ld]
     int sbias_ld;
     float *out;
-    float *cstate;          // EPI_LSTM: cell state, updated in place
+    float *cstate;          // EPI_LSTM: new cell state [B][H][W][C]
+    const float *cstate_in; // EPI_LSTM: previous cell state (may alias cstate)
+    long long cin_bstride;  // floats between samples of cstate_in (0: shared)
     double *stats;          // LayerNorm partial sums of the output [B][stats_nparts][2]
     int stats_nparts;
     int chunks_per_split;   // K split (blockIdx.z)
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
         const int b = bimg0 + img;
         if (sg.ln_part && b < p.B) {
             double su = 0.0, sq = 0.0;
-            const double *pp = sg.ln_part + (long long)b * sg.ln_nparts * 2;
+            const double *pp = sg.ln_part + (long long)b * sg.ln_bstride;
             for (int k = 0; k < sg.ln_nparts; ++k) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
             const double m = su * (double)sg.ln_inv_n;
             double var = sq * (double)sg.ln_inv_n - m * m;
@@ -211,29 +214,44 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
         }
         __syncthreads();
 
+        // ---- K loop over (tap, k8), software pipelined: operands of step it+1 are fetched
+        // (A: LDS b128, B: L1/L2 b128 per gate) before the 8*G MFMAs of step it are issued.
         const float *wchunk = wlane + (long long)ci * ntaps * K8 * wstep;
-        for (int ky = 0; ky < p.KH; ++ky) {
-            for (int kx = 0; kx < p.KW; ++kx) {
-                const int aoff = (ky * LW + kx) * KCpad;
-                const float *wtap = wchunk + (long long)(ky * p.KW + kx) * K8 * wstep;
-                for (int k8 = 0; k8 < K8; ++k8) {
-                    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&smem[abase[0] + aoff + k8 * 8]);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&smem[abase[1] + aoff + k8 * 8]);
-                    f32x4 bw[G];
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        bw[g] = *reinterpret_cast<const f32x4 *>(wtap + k8 * wstep + g * 128);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                        for (int g = 0; g < G; ++g) {
-                            acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bw[g][j], acc[0][g], 0, 0, 0);
-                            acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bw[g][j], acc[1][g], 0, 0, 0);
-                        }
-                    }
-                }
-            }
+        const int nit = ntaps * K8;
+        const f32x4 *smem4 = reinterpret_cast<const f32x4 *>(smem);
+        const int a0base = abase[0] >> 2, a1base = abase[1] >> 2;   // in float4 units
+        const int kcp4 = KCpad >> 2;
+        int ky = 0, kx = 0, k8 = 0;
+
+        f32x4 aP[2], aQ[2], bP[G], bQ[G];
+#define VF_FETCH(A_, B_, IT_)                                                                   \
+        {                                                                                       \
+            const int ao_ = (ky * LW + kx) * kcp4 + k8 * 2;                                     \
+            A_[0] = smem4[a0base + ao_];                                                        \
+            A_[1] = smem4[a1base + ao_];                                                        \
+            const float *wp_ = wchunk + (long long)(IT_) * wstep;                               \
+            _Pragma("unroll") for (int g = 0; g < G; ++g)                                       \
+                B_[g] = *reinterpret_cast<const f32x4 *>(wp_ + g * 128);                        \
+            if (++k8 == K8) { k8 = 0; if (++kx == p.KW) { kx = 0; ++ky; } }                     \
         }
+#define VF_MFMA(A_, B_)                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                     \
+                acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[0][j], B_[g][j], acc[0][g], 0, 0, 0); \
+                acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[1][j], B_[g][j], acc[1][g], 0, 0, 0); \
+            }                                                                                   \
+        }
+        VF_FETCH(aP, bP, 0)
+        int it = 0;
+        for (; it + 2 <= nit; it += 2) {
+            VF_FETCH(aQ, bQ, it + 1)
+            VF_MFMA(aP, bP)
+            if (it + 2 < nit) VF_FETCH(aP, bP, it + 2)
+            VF_MFMA(aQ, bQ)
+        }
+        if (it < nit) VF_MFMA(aP, bP)
+#undef VF_FETCH
+#undef VF_MFMA
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -260,7 +278,8 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
                 const float gj = acc[m][1 % G][r] + bias_g[1 % G];
                 const float gf = acc[m][2 % G][r] + bias_g[2 % G];
                 const float go = acc[m][3 % G][r] + bias_g[3 % G];
-                const float c_old = p.cstate[o];
+                const float c_old = p.cstate_in[(long long)b * p.cin_bstride +
+                                                ((long long)y * p.Wout + x) * p.Cout + ch];
                 const float c_new = c_old * sigmoidf_(gf + 1.0f) + sigmoidf_(gi) * tanhf_(gj);
                 const float h_new = tanhf_(c_new) * sigmoidf_(go);
                 p.cstate[o] = c_new;

@@ -35,6 +35,7 @@ static int fail(int code, const std::string &msg) {
     } while (0)
 
 static const int kLstmSizes[7] = {32, 32, 64, 64, 128, 64, 32};
+static const int kMaxSubBatches = 8;
 
 // ------------------------------------------------------------------ canonical tensor table
 struct TensorDesc {
@@ -216,6 +217,19 @@ static std::vector<float> pack_bias(const ConvLayer &l, const float *b) {
 
 using namespace vf;
 
+// Views of the engine's working buffers: one per sub-batch (offset to its first sample) and
+// one "shared" set of batch-1 buffers per sub-batch for tensors that are identical for every
+// sample (see run_steps).
+struct BatchView {
+    float *enc0_o, *enc1_o, *enc2_o, *enc3_o, *enc4_o, *enc5_o, *enc6_o;
+    float *c_state[7], *h_state[7][2];
+    double *st_enc0, *st_h[7], *st_enc6;
+    float *sbias, *fc_part, *kern;
+    float *frames_all, *distrib_all, *states_all;
+    double *sums;
+    const float *actions;
+};
+
 // ------------------------------------------------------------------ the engine
 struct vf_handle {
     vf_config cfg;
@@ -250,6 +264,16 @@ struct vf_handle {
     long long sums_step_stride = 0;
 
     std::vector<void *> allocs;
+
+    // batch-1 buffers for tensors shared by all samples of a sub-batch (context de-duplication)
+    bool dedup = true;
+    std::vector<BatchView> shared_views;
+
+    // sub-batch streams (forked from / joined to the caller's stream inside vf_rollout)
+    int n_sub = 1;
+    std::vector<hipStream_t> sub_streams;
+    std::vector<hipEvent_t> ev_join;
+    hipEvent_t ev_fork = nullptr;
 
     // optional per-launch timing of the conv-LSTM kernel (HIP events on the launch stream)
     bool profiling = false;
@@ -320,7 +344,7 @@ static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st
 }
 
 struct SegArg {
-    const float *ptr; long long bstride; const double *ln_part; int ln_nparts; float ln_inv_n;
+    const float *ptr; long long bstride; const double *ln_part; long long ln_bstride; int ln_nparts; float ln_inv_n;
     const float *gamma, *beta; int gamma_mod; int relu;
 };
 
@@ -332,6 +356,7 @@ static ConvParams make_params(const ConvLayer &l, int B, const SegArg &s0, const
         p.seg[s].ptr = sa[s]->ptr; p.seg[s].bstride = sa[s]->bstride; p.seg[s].C = l.segC[s];
         p.seg[s].nchunk = l.nchunk[s];
         p.seg[s].ln_part = sa[s]->ln_part; p.seg[s].ln_nparts = sa[s]->ln_nparts;
+        p.seg[s].ln_bstride = sa[s]->ln_bstride;
         p.seg[s].ln_inv_n = sa[s]->ln_inv_n;
         p.seg[s].gamma = sa[s]->gamma; p.seg[s].beta = sa[s]->beta;
         p.seg[s].gamma_mod = sa[s]->gamma_mod > 0 ? sa[s]->gamma_mod : 1;
@@ -461,6 +486,26 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     VF_ALLOC(h->states_all, (size_t)Bc * h->T * cfg->sdim);
     h->sums_step_stride = (long long)Bc * ND * h->ntiles * 2;
     VF_ALLOC(h->sums, (size_t)h->T * h->sums_step_stride);
+    for (int i = 0; i < kMaxSubBatches; ++i) {
+        BatchView sv;
+        memset(&sv, 0, sizeof(sv));
+        VF_ALLOC(sv.enc0_o, (size_t)H2 * W2 * 32);
+        VF_ALLOC(sv.enc1_o, (size_t)H4 * W4 * L[1]);
+        VF_ALLOC(sv.enc2_o, (size_t)H8 * W8 * L[3]);
+        VF_ALLOC(sv.enc3_o, (size_t)H8 * W8 * L[3]);
+        VF_ALLOC(sv.enc4_o, (size_t)H4 * W4 * L[4]);
+        VF_ALLOC(sv.enc5_o, (size_t)H2 * W2 * L[5]);
+        for (int k = 0; k < 7; ++k) {
+            const size_t per = (size_t)lh[k] * lw[k] * L[k];
+            VF_ALLOC(sv.c_state[k], per);
+            VF_ALLOC(sv.h_state[k][0], per);
+            VF_ALLOC(sv.h_state[k][1], per);
+            VF_ALLOC(sv.st_h[k], (size_t)h->lstm[k].stats_nparts * 2);
+        }
+        VF_ALLOC(sv.st_enc0, (size_t)h->enc0.stats_nparts * 2);
+        VF_ALLOC(sv.sbias, (size_t)L[3]);
+        h->shared_views.push_back(sv);
+    }
 #undef VF_ALLOC
     *out = h;
     return VF_OK;
@@ -470,6 +515,9 @@ int vf_destroy(vf_handle *h) {
     if (!h) return VF_OK;
     for (void *p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_join) (void)hipEventDestroy(e);
+    for (hipStream_t s : h->sub_streams) (void)hipStreamDestroy(s);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     delete h;
     return VF_OK;
 }
@@ -550,15 +598,57 @@ int vf_set_context(vf_handle *h, const uint8_t *d_frames, const float *d_states,
     return VF_OK;
 }
 
-int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *goal_pix, float finalweight,
-               float *d_scores, float *d_scores_per_task, void *stream) {
-    if (!h || !d_actions || !goal_pix || !d_scores) return fail(VF_ERR_INVALID, "null argument");
-    if (!h->have_weights) return fail(VF_ERR_NOWEIGHTS, "vf_load_weights has not been called");
-    if (!h->have_context) return fail(VF_ERR_NOCONTEXT, "vf_set_context has not been called");
-    if (B < 1 || B > h->cfg.max_batch)
-        return fail(VF_ERR_INVALID, "batch " + std::to_string(B) + " outside 1.." + std::to_string(h->cfg.max_batch));
-    VF_HIP_CHECK(hipSetDevice(h->cfg.device));
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+static BatchView make_view(vf_handle *h, const float *d_actions, int b0) {
+    const vf_config &c = h->cfg;
+    const int H = h->H, W = h->W, T = h->T, ND = h->ND;
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+    const int *L = kLstmSizes;
+    const int lh[7] = {H2, H2, H4, H4, H8, H4, H2}, lw[7] = {W2, W2, W4, W4, W8, W4, W2};
+    const size_t b = (size_t)b0;
+    BatchView v;
+    v.enc0_o = h->enc0_o + b * H2 * W2 * 32;
+    v.enc1_o = h->enc1_o + b * H4 * W4 * L[1];
+    v.enc2_o = h->enc2_o + b * H8 * W8 * L[3];
+    v.enc3_o = h->enc3_o + b * H8 * W8 * L[3];
+    v.enc4_o = h->enc4_o + b * H4 * W4 * L[4];
+    v.enc5_o = h->enc5_o + b * H2 * W2 * L[5];
+    v.enc6_o = h->enc6_o + b * H * W * 32;
+    for (int k = 0; k < 7; ++k) {
+        const size_t per = (size_t)lh[k] * lw[k] * L[k];
+        v.c_state[k] = h->c_state[k] + b * per;
+        v.h_state[k][0] = h->h_state[k][0] + b * per;
+        v.h_state[k][1] = h->h_state[k][1] + b * per;
+        v.st_h[k] = h->st_h[k] + b * h->lstm[k].stats_nparts * 2;
+    }
+    v.st_enc0 = h->st_enc0 + b * h->enc0.stats_nparts * 2;
+    v.st_enc6 = h->st_enc6 + b * h->convt3.stats_nparts * 2;
+    v.sbias = h->sbias + b * L[3];
+    v.fc_part = h->fc_part + b * h->fc.nsplit * kTaps * h->K;
+    v.kern = h->kern + b * kTaps * h->K;
+    v.frames_all = h->frames_all + b * T * H * W * 3;
+    v.distrib_all = h->distrib_all + b * T * H * W * ND;
+    v.states_all = h->states_all + b * T * c.sdim;
+    v.sums = h->sums + b * ND * h->ntiles * 2;
+    v.actions = d_actions + b * T * c.adim;
+    return v;
+}
+
+// A tensor of one step: where it lives and whether it is one image shared by every sample.
+struct Loc {
+    bool shared;
+    int B;                  // samples the producing launch covers (1 when shared)
+};
+
+// All S steps of the predictor for the B samples of one view, enqueued on one stream.
+//
+// Context de-duplication: while a step's inputs are the context, part of the network sees the
+// same input for every sample - at steps s < n_context-1 everything (frame, action and state
+// all come from the context), and at steps s < n_context the encoder up to enc2 (enc0, lstm1-4,
+// enc1, enc2: the per-sample action only enters at enc3).  Those launches run once with batch 1
+// into the sub-batch's "shared" buffers and their consumers read them with batch stride 0; the
+// arithmetic per sample is unchanged, so results are bit-identical to the redundant evaluation.
+static int run_steps(vf_handle *h, const BatchView &v, const BatchView &sh, int B, const int32_t *goal_pix,
+                     hipStream_t st) {
     const vf_config &c = h->cfg;
     const int H = h->H, W = h->W, T = h->T, ND = h->ND, nc = c.n_context;
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
@@ -566,60 +656,80 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
     const int lh[7] = {H2, H2, H4, H4, H8, H4, H2}, lw[7] = {W2, W2, W4, W4, W8, W4, W2};
     int rc;
 
+    // the zero initial state is one shared image per layer
     for (int k = 0; k < 7; ++k) {
-        const size_t bytes = (size_t)B * lh[k] * lw[k] * L[k] * sizeof(float);
-        VF_HIP_CHECK(hipMemsetAsync(h->c_state[k], 0, bytes, st));
-        VF_HIP_CHECK(hipMemsetAsync(h->h_state[k][0], 0, bytes, st));
+        const size_t bytes = (size_t)lh[k] * lw[k] * L[k] * sizeof(float);
+        VF_HIP_CHECK(hipMemsetAsync(sh.c_state[k], 0, bytes, st));
+        VF_HIP_CHECK(hipMemsetAsync(sh.h_state[k][0], 0, bytes, st));
     }
+
+    auto all_shared = [&](int s) { return h->dedup && s < nc - 1; };
+    auto enc_shared = [&](int s) { return h->dedup && s < nc; };
+    // is the output of lstm k at step s one shared image?
+    auto lstm_shared = [&](int k, int s) { return s < 0 || all_shared(s) || (k < 4 && enc_shared(s)); };
 
     auto plain = [](const float *ptr, long long bs) {
         SegArg s; memset(&s, 0, sizeof(s)); s.ptr = ptr; s.bstride = bs; s.gamma_mod = 1; return s;
     };
-    auto normed = [](const float *ptr, long long bs, const double *part, int nparts, long long count,
-                     const float *g, const float *b, int gmod, int relu) {
+    auto normed = [](const float *ptr, long long bs, const double *part, int nparts, bool shared,
+                     long long count, const float *g, const float *b, int gmod, int relu) {
         SegArg s; s.ptr = ptr; s.bstride = bs; s.ln_part = part; s.ln_nparts = nparts;
+        s.ln_bstride = shared ? 0 : (long long)nparts * 2;
         s.ln_inv_n = (float)(1.0 / (double)count); s.gamma = g; s.beta = b; s.gamma_mod = gmod; s.relu = relu;
         return s;
-    };
-    // LayerNorm index: ln1 = enc0, ln2..ln8 = lstm1..7, ln9 = convt3
-    auto h_normed = [&](int k, const float *hptr) {
-        return normed(hptr, (long long)lh[k] * lw[k] * L[k], h->st_h[k], h->lstm[k].stats_nparts,
-                      (long long)lh[k] * lw[k] * L[k], h->d_ln_g[k + 1], h->d_ln_b[k + 1], L[k], 0);
     };
 
     for (int s = 0; s < h->S; ++s) {
         const int cur = s & 1, nxt = cur ^ 1;
         const bool produce = s >= nc - 1;
         const int t_out = s - (nc - 1);
+        const bool enc_sh = enc_shared(s), all_sh = all_shared(s);
+        const BatchView &E = enc_sh ? sh : v;       // encoder tensors of this step
+        const BatchView &D = all_sh ? sh : v;       // tensors from enc3 on
+        const int BE = enc_sh ? 1 : B, BD = all_sh ? 1 : B;
+        auto bs = [](bool shared, long long per) { return shared ? 0LL : per; };
 
         // ---- state FC + action/state bias of enc3
         SaParams sp; memset(&sp, 0, sizeof(sp));
         if (s < nc - 1) { sp.action = h->ctx_actions + (size_t)s * c.adim; sp.action_bstride = 0; }
-        else { sp.action = d_actions + (size_t)(s - (nc - 1)) * c.adim; sp.action_bstride = (long long)T * c.adim; }
+        else { sp.action = v.actions + (size_t)(s - (nc - 1)) * c.adim; sp.action_bstride = (long long)T * c.adim; }
         if (s < nc) { sp.state = h->ctx_states + (size_t)s * c.sdim; sp.state_bstride = 0; }
-        else { sp.state = h->states_all + (size_t)(s - nc) * c.sdim; sp.state_bstride = (long long)T * c.sdim; }
-        sp.adim = c.adim; sp.sdim = c.sdim; sp.B = B;
+        else { sp.state = v.states_all + (size_t)(s - nc) * c.sdim; sp.state_bstride = (long long)T * c.sdim; }
+        sp.adim = c.adim; sp.sdim = c.sdim; sp.B = BD;
         sp.w_state = h->d_w_state; sp.b_state = h->d_b_state; sp.w_sa = h->d_w_sa; sp.n_out = L[3];
-        sp.state_out = produce ? h->states_all + (size_t)t_out * c.sdim : nullptr;
+        sp.state_out = produce ? v.states_all + (size_t)t_out * c.sdim : nullptr;
         sp.state_out_bstride = (long long)T * c.sdim;
-        sp.sbias = h->sbias;
-        hipLaunchKernelGGL(sa_kernel, dim3(B), dim3(64), 0, st, sp);
+        sp.sbias = D.sbias;
+        hipLaunchKernelGGL(sa_kernel, dim3(BD), dim3(64), 0, st, sp);
 
         // ---- encoder
         const float *frame_in; long long frame_bs;
         if (s < nc) { frame_in = h->ctx_frames + (size_t)s * H * W * 3; frame_bs = 0; }
-        else { frame_in = h->frames_all + (size_t)(s - nc) * H * W * 3; frame_bs = (long long)T * H * W * 3; }
+        else { frame_in = v.frames_all + (size_t)(s - nc) * H * W * 3; frame_bs = (long long)T * H * W * 3; }
 
-        ConvParams p = make_params(h->enc0, B, plain(frame_in, frame_bs), nullptr);
-        p.out = h->enc0_o; p.stats = h->st_enc0;
+        ConvParams p = make_params(h->enc0, BE, plain(frame_in, frame_bs), nullptr);
+        p.out = E.enc0_o; p.stats = E.st_enc0;
         if ((rc = launch_conv_t<1, EPI_RAW_STATS>(h->enc0, p, st))) return rc;
 
-        SegArg enc0_n = normed(h->enc0_o, (long long)H2 * W2 * 32, h->st_enc0, h->enc0.stats_nparts,
-                               (long long)H2 * W2 * 32, h->d_ln_g[0], h->d_ln_b[0], 32, 1);
+        SegArg enc0_n = normed(E.enc0_o, bs(enc_sh, (long long)H2 * W2 * 32), E.st_enc0, h->enc0.stats_nparts,
+                               enc_sh, (long long)H2 * W2 * 32, h->d_ln_g[0], h->d_ln_b[0], 32, 1);
+        // LayerNorm index: ln1 = enc0, ln2..ln8 = lstm1..7, ln9 = convt3
+        auto h_normed = [&](int k) {        // normalised new hidden state of lstm k at this step
+            const bool shd = lstm_shared(k, s);
+            const BatchView &O = shd ? sh : v;
+            const long long per = (long long)lh[k] * lw[k] * L[k];
+            return normed(O.h_state[k][nxt], bs(shd, per), O.st_h[k], h->lstm[k].stats_nparts, shd, per,
+                          h->d_ln_g[k + 1], h->d_ln_b[k + 1], L[k], 0);
+        };
         auto run_lstm = [&](int k, const SegArg &x) -> int {
-            SegArg hs = plain(h->h_state[k][cur], (long long)lh[k] * lw[k] * L[k]);
-            ConvParams q = make_params(h->lstm[k], B, x, &hs);
-            q.out = h->h_state[k][nxt]; q.cstate = h->c_state[k]; q.stats = h->st_h[k];
+            const bool out_sh = lstm_shared(k, s), in_sh = lstm_shared(k, s - 1);
+            const BatchView &O = out_sh ? sh : v, &I = in_sh ? sh : v;
+            const long long per = (long long)lh[k] * lw[k] * L[k];
+            const int Bk = out_sh ? 1 : B;
+            SegArg hs = plain(I.h_state[k][cur], bs(in_sh, per));
+            ConvParams q = make_params(h->lstm[k], Bk, x, &hs);
+            q.out = O.h_state[k][nxt]; q.cstate = O.c_state[k]; q.stats = O.st_h[k];
+            q.cstate_in = I.c_state[k]; q.cin_bstride = bs(in_sh, per);
             if (!h->profiling) return launch_conv_t<4, EPI_LSTM>(h->lstm[k], q, st);
             while (h->ev_pool.size() < h->ev_used + 2) {
                 hipEvent_t e;
@@ -631,77 +741,77 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
             VF_HIP_CHECK(hipEventRecord(h->ev_pool[h->ev_used + 1], st));
             h->ev_used += 2;
             const ConvLayer &ll = h->lstm[k];
-            h->prof_flops += 2.0 * B * ll.Hout * ll.Wout * 25.0 * (ll.segC[0] + ll.segC[1]) * 4.0 * ll.Cout;
+            h->prof_flops += 2.0 * Bk * ll.Hout * ll.Wout * 25.0 * (ll.segC[0] + ll.segC[1]) * 4.0 * ll.Cout;
             return r;
         };
         if ((rc = run_lstm(0, enc0_n))) return rc;
-        if ((rc = run_lstm(1, h_normed(0, h->h_state[0][nxt])))) return rc;
+        if ((rc = run_lstm(1, h_normed(0)))) return rc;
 
-        p = make_params(h->enc1, B, h_normed(1, h->h_state[1][nxt]), nullptr);
-        p.out = h->enc1_o;
+        p = make_params(h->enc1, BE, h_normed(1), nullptr);
+        p.out = E.enc1_o;
         if ((rc = launch_conv_t<1, EPI_BIAS_RELU>(h->enc1, p, st))) return rc;
 
-        if ((rc = run_lstm(2, plain(h->enc1_o, (long long)H4 * W4 * L[1])))) return rc;
-        if ((rc = run_lstm(3, h_normed(2, h->h_state[2][nxt])))) return rc;
+        if ((rc = run_lstm(2, plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]))))) return rc;
+        if ((rc = run_lstm(3, h_normed(2)))) return rc;
 
-        p = make_params(h->enc2, B, h_normed(3, h->h_state[3][nxt]), nullptr);
-        p.out = h->enc2_o;
+        p = make_params(h->enc2, BE, h_normed(3), nullptr);
+        p.out = E.enc2_o;
         if ((rc = launch_conv_t<1, EPI_BIAS_RELU>(h->enc2, p, st))) return rc;
 
-        p = make_params(h->enc3, B, plain(h->enc2_o, (long long)H8 * W8 * L[3]), nullptr);
-        p.out = h->enc3_o; p.sbias = h->sbias; p.sbias_ld = L[3];
+        p = make_params(h->enc3, BD, plain(E.enc2_o, bs(enc_sh, (long long)H8 * W8 * L[3])), nullptr);
+        p.out = D.enc3_o; p.sbias = D.sbias; p.sbias_ld = L[3];
         if ((rc = launch_conv_t<1, EPI_BIAS_RELU>(h->enc3, p, st))) return rc;
 
-        if ((rc = run_lstm(4, plain(h->enc3_o, (long long)H8 * W8 * L[3])))) return rc;
-        SegArg h5n = h_normed(4, h->h_state[4][nxt]);
+        if ((rc = run_lstm(4, plain(D.enc3_o, bs(all_sh, (long long)H8 * W8 * L[3]))))) return rc;
+        SegArg h5n = h_normed(4);
 
         // ---- CDNA kernels (only needed when this step's prediction is used)
         if (produce) {
             SegArg flat = h5n;      // same LayerNorm, viewed as [B][1][1][H8*W8*128]
             p = make_params(h->fc, B, flat, nullptr);
-            p.out = h->fc_part;
+            p.out = v.fc_part;
             if ((rc = launch_conv_t<1, EPI_PARTIAL>(h->fc, p, st))) return rc;
-            hipLaunchKernelGGL(cdna_finalize_kernel, dim3(B), dim3(256), 0, st, h->fc_part, h->fc.nsplit, B,
-                               h->K, h->d_b_fc, h->kern);
+            hipLaunchKernelGGL(cdna_finalize_kernel, dim3(B), dim3(256), 0, st, v.fc_part, h->fc.nsplit, B,
+                               h->K, h->d_b_fc, v.kern);
         }
 
         // ---- decoder
-        p = make_params(h->convt1, B, h5n, nullptr);
-        p.out = h->enc4_o;
+        p = make_params(h->convt1, BD, h5n, nullptr);
+        p.out = D.enc4_o;
         if ((rc = launch_conv_t<4, EPI_CONVT_RELU>(h->convt1, p, st))) return rc;
-        if ((rc = run_lstm(5, plain(h->enc4_o, (long long)H4 * W4 * L[4])))) return rc;
+        if ((rc = run_lstm(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))))) return rc;
 
-        SegArg enc1_s = plain(h->enc1_o, (long long)H4 * W4 * L[1]);
-        p = make_params(h->convt2, B, h_normed(5, h->h_state[5][nxt]), &enc1_s);
-        p.out = h->enc5_o;
+        SegArg enc1_s = plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]));
+        p = make_params(h->convt2, BD, h_normed(5), &enc1_s);
+        p.out = D.enc5_o;
         if ((rc = launch_conv_t<4, EPI_CONVT_RELU>(h->convt2, p, st))) return rc;
-        if ((rc = run_lstm(6, plain(h->enc5_o, (long long)H2 * W2 * L[5])))) return rc;
+        if ((rc = run_lstm(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))))) return rc;
 
-        if (produce) {
-            p = make_params(h->convt3, B, h_normed(6, h->h_state[6][nxt]), &enc0_n);
-            p.out = h->enc6_o; p.stats = h->st_enc6;
+        if (produce) {      // never an all-shared step
+            p = make_params(h->convt3, B, h_normed(6), &enc0_n);
+            p.out = v.enc6_o; p.stats = v.st_enc6;
             if ((rc = launch_conv_t<4, EPI_CONVT_RAW_STATS>(h->convt3, p, st))) return rc;
 
             CompositeParams cp; memset(&cp, 0, sizeof(cp));
             cp.B = B; cp.H = H; cp.W = W; cp.ND = ND; cp.K = h->K;
-            cp.enc6 = h->enc6_o; cp.ln_part = h->st_enc6; cp.ln_nparts = h->convt3.stats_nparts;
+            cp.enc6 = v.enc6_o; cp.ln_part = v.st_enc6; cp.ln_nparts = h->convt3.stats_nparts;
             cp.ln_inv_n = (float)(1.0 / ((double)H * W * 32));
             cp.gamma = h->d_ln_g[8]; cp.beta = h->d_ln_b[8];
             cp.w_rgb = h->d_w_rgb; cp.b_rgb = h->d_b_rgb; cp.w_mask = h->d_w_mask; cp.b_mask = h->d_b_mask;
-            cp.kern = h->kern;
+            cp.kern = v.kern;
             cp.prev_frame = frame_in; cp.prev_frame_bstride = frame_bs;
             if (s < nc) {
                 cp.prev_distrib = h->ctx_distrib + (size_t)s * H * W * ND; cp.prev_distrib_bstride = 0;
                 cp.prev_sums = nullptr;
             } else {
-                cp.prev_distrib = h->distrib_all + (size_t)(s - nc) * H * W * ND;
+                cp.prev_distrib = v.distrib_all + (size_t)(s - nc) * H * W * ND;
                 cp.prev_distrib_bstride = (long long)T * H * W * ND;
-                cp.prev_sums = h->sums + (long long)(s - nc) * h->sums_step_stride;
+                cp.prev_sums = v.sums + (long long)(s - nc) * h->sums_step_stride;
             }
-            cp.out_frame = h->frames_all + (size_t)t_out * H * W * 3; cp.out_frame_bstride = (long long)T * H * W * 3;
-            cp.out_distrib = h->distrib_all + (size_t)t_out * H * W * ND;
+            cp.out_frame = v.frames_all + (size_t)t_out * H * W * 3; cp.out_frame_bstride = (long long)T * H * W * 3;
+            cp.out_distrib = v.distrib_all + (size_t)t_out * H * W * ND;
             cp.out_distrib_bstride = (long long)T * H * W * ND;
-            cp.out_sums = h->sums + (long long)t_out * h->sums_step_stride;
+            cp.out_sums = v.sums + (long long)t_out * h->sums_step_stride;
             for (int d = 0; d < ND; ++d) { cp.goal[d][0] = goal_pix[2 * d]; cp.goal[d][1] = goal_pix[2 * d + 1]; }
             dim3 grid(h->ntiles, B);
             switch (ND) {
@@ -713,10 +823,65 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
         }
         VF_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(scores_kernel, dim3((B + 63) / 64), dim3(64), 0, st, h->sums, h->sums_step_stride, B, T,
-                       ND, h->ntiles, finalweight, d_scores, d_scores_per_task);
+    return VF_OK;
+}
+
+int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *goal_pix, float finalweight,
+               float *d_scores, float *d_scores_per_task, void *stream) {
+    if (!h || !d_actions || !goal_pix || !d_scores) return fail(VF_ERR_INVALID, "null argument");
+    if (!h->have_weights) return fail(VF_ERR_NOWEIGHTS, "vf_load_weights has not been called");
+    if (!h->have_context) return fail(VF_ERR_NOCONTEXT, "vf_set_context has not been called");
+    if (B < 1 || B > h->cfg.max_batch)
+        return fail(VF_ERR_INVALID, "batch " + std::to_string(B) + " outside 1.." + std::to_string(h->cfg.max_batch));
+    VF_HIP_CHECK(hipSetDevice(h->cfg.device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+
+    // Samples never interact before the scores are compared, so the batch is cut into
+    // sub-batches that advance on forked streams: while one sub-batch drains the tail of a
+    // layer, the other's workgroups fill the idle CUs.  Results are bit-identical for any split.
+    const int nsub = std::max(1, std::min({h->n_sub, B / 16, (int)h->sub_streams.size() + 1}));
+    if (nsub == 1) {
+        if ((rc = run_steps(h, make_view(h, d_actions, 0), h->shared_views[0], B, goal_pix, st))) return rc;
+    } else {
+        VF_HIP_CHECK(hipEventRecord(h->ev_fork, st));
+        for (int i = 0; i < nsub; ++i) {
+            const int b0 = (int)((long long)B * i / nsub), b1 = (int)((long long)B * (i + 1) / nsub);
+            hipStream_t ss = i == 0 ? st : h->sub_streams[i - 1];
+            if (i > 0) VF_HIP_CHECK(hipStreamWaitEvent(ss, h->ev_fork, 0));
+            if ((rc = run_steps(h, make_view(h, d_actions, b0), h->shared_views[i], b1 - b0, goal_pix, ss))) return rc;
+            if (i > 0) {
+                VF_HIP_CHECK(hipEventRecord(h->ev_join[i - 1], ss));
+                VF_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join[i - 1], 0));
+            }
+        }
+    }
+    hipLaunchKernelGGL(scores_kernel, dim3((B + 63) / 64), dim3(64), 0, st, h->sums, h->sums_step_stride, B,
+                       h->T, h->ND, h->ntiles, finalweight, d_scores, d_scores_per_task);
     VF_HIP_CHECK(hipGetLastError());
     h->last_B = B;
+    return VF_OK;
+}
+
+int vf_set_dedup(vf_handle *h, int32_t enable) {
+    if (!h) return fail(VF_ERR_INVALID, "null handle");
+    h->dedup = enable != 0;
+    return VF_OK;
+}
+
+int vf_set_substreams(vf_handle *h, int32_t n) {
+    if (!h || n < 1 || n > kMaxSubBatches) return fail(VF_ERR_INVALID, "sub-stream count must be 1..8");
+    VF_HIP_CHECK(hipSetDevice(h->cfg.device));
+    while ((int)h->sub_streams.size() < n - 1) {
+        hipStream_t s;
+        hipEvent_t e;
+        VF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        VF_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->sub_streams.push_back(s);
+        h->ev_join.push_back(e);
+    }
+    if (!h->ev_fork) VF_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    h->n_sub = n;
     return VF_OK;
 }
 
@@ -753,17 +918,33 @@ int vf_set_profiling(vf_handle *h, int32_t enable) {
     return VF_OK;
 }
 
-int vf_get_profile(vf_handle *h, double *kernel_ms, int64_t *launches, double *flops) {
-    if (!h || !kernel_ms || !launches || !flops) return fail(VF_ERR_INVALID, "null argument");
+int vf_get_profile(vf_handle *h, double *kernel_ms, int64_t *launches, double *flops, double *busy_ms) {
+    if (!h || !kernel_ms || !launches || !flops || !busy_ms) return fail(VF_ERR_INVALID, "null argument");
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
     double ms = 0.0;
+    std::vector<std::pair<float, float>> spans;
     for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
         VF_HIP_CHECK(hipEventSynchronize(h->ev_pool[i + 1]));
-        float dt = 0.f;
+        float dt = 0.f, t0 = 0.f;
         VF_HIP_CHECK(hipEventElapsedTime(&dt, h->ev_pool[i], h->ev_pool[i + 1]));
+        if (i > 0) VF_HIP_CHECK(hipEventElapsedTime(&t0, h->ev_pool[0], h->ev_pool[i]));
         ms += dt;
+        spans.emplace_back(t0, t0 + dt);
     }
+    // time during which at least one bracketed launch was in flight (== kernel_ms on one stream)
+    std::sort(spans.begin(), spans.end());
+    double busy = 0.0, lo = 0.0, hi = -1.0;
+    for (const auto &sp : spans) {
+        if (hi < 0.0 || sp.first > hi) {
+            if (hi >= 0.0) busy += hi - lo;
+            lo = sp.first; hi = sp.second;
+        } else if (sp.second > hi) {
+            hi = sp.second;
+        }
+    }
+    if (hi >= 0.0) busy += hi - lo;
     *kernel_ms = ms;
+    *busy_ms = busy;
     *launches = (int64_t)(h->ev_used / 2);
     *flops = h->prof_flops;
     h->ev_used = 0;

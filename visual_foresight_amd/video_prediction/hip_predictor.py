@@ -63,6 +63,8 @@ class HipVPredEvaluation(object):
                                     self.device_index)
         self._handle = ctypes.c_void_p()
         _lib.check(self._libh.vf_create(ctypes.byref(self._c_cfg), ctypes.byref(self._handle)))
+        self.set_substreams(int(hp.get('substreams', os.environ.get('VF_SUBSTREAMS', 1))))
+        self.set_dedup(int(hp.get('dedup', os.environ.get('VF_DEDUP', 1))))
         self.weights = None
         self._last_M = 0
         self._last_lo = 0
@@ -81,11 +83,20 @@ class HipVPredEvaluation(object):
         _lib.check(self._libh.vf_set_profiling(self._handle, int(bool(enable))))
 
     def get_profile(self):
-        """-> (kernel_ms, launches, flops) of the conv-LSTM kernel since the last call."""
-        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        """-> (kernel_ms, launches, flops, busy_ms) of the conv-LSTM kernel since the last call."""
+        ms, n, fl, busy = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
         _lib.check(self._libh.vf_get_profile(self._handle, ctypes.byref(ms), ctypes.byref(n),
-                                             ctypes.byref(fl)))
-        return ms.value, n.value, fl.value
+                                             ctypes.byref(fl), ctypes.byref(busy)))
+        return ms.value, n.value, fl.value, busy.value
+
+    def set_dedup(self, enable):
+        """Switch context de-duplication (bit-identical results either way; for A/B timing)."""
+        _lib.check(self._libh.vf_set_dedup(self._handle, int(bool(enable))))
+
+    def set_substreams(self, n):
+        """Cut each rollout into n concurrent sub-batches (bit-identical results for any n)."""
+        _lib.check(self._libh.vf_set_substreams(self._handle, int(n)))
+        self.substreams = int(n)
 
     # ------------------------------------------------------------------ weights
     def restore(self, weights=None):
