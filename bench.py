@@ -128,10 +128,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    with contextlib.redirect_stdout(io.StringIO()):
+    # The sampler's 52x52 SVD / covariance refits are tiny: BLAS worker threads only add wake-up
+    # latency there (several ms per CEM iteration on a 256-core host), so host math runs on 1 thread.
+    try:
+        from threadpoolctl import threadpool_limits
+        blas_guard = threadpool_limits(limits=1, user_api='blas')
+    except ImportError:
+        blas_guard = contextlib.nullcontext()
+
+    score_time = [0.0]
+    inner_score = ctrl.predictor.score
+
+    def timed_score(*a, **k):
+        t = time.perf_counter()
+        out = inner_score(*a, **k)
+        score_time[0] += time.perf_counter() - t
+        return out
+    ctrl.predictor.score = timed_score
+
+    with contextlib.redirect_stdout(io.StringIO()), blas_guard:
         ctrl.act(t=0, i_tr=0, desig_pix=desig, goal_pix=goal, images=frames[:1], state=states[:1])
         for _ in range(args.warmup):
             plan()
+        score_time[0] = 0.0
         ctrl.predictor.set_profiling(True)
         sync()
         t0 = time.perf_counter()
@@ -168,6 +187,7 @@ def main():
                      'busy_ms': busy_ms, 'achieved_while_busy': flops / (busy_ms * 1e-3) / 1e12 if busy_ms > 0 else None,
                      'substreams': ctrl.predictor.substreams,
                      'kernel_time_share': busy_ms * 1e-3 / elapsed},
+        'host_ms_per_step_outside_predictor': 1e3 * (elapsed - score_time[0]) / args.steps,
         'best_score_last_plan': float(np.min(out['plan_stat']['scores_itr%d' % (iters - 1)])),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -109,6 +109,15 @@ int vf_export(vf_handle *h, int32_t first, int32_t count, float *d_frames, float
  * for every n.  Default 1. */
 int vf_set_substreams(vf_handle *h, int32_t n);
 
+/* Persistent rollout (no reference counterpart).  When enabled vf_rollout runs ALL steps, layers
+ * and samples as one persistent launch whose workgroups draw tiles from a ticket queue and
+ * honour per-sample dependencies, so the tail of one layer overlaps the head of the next
+ * (visual_foresight_amd/csrc/vf_persistent.h).  Results are bit-identical to the per-layer
+ * launches.  vf_device_status synchronises and returns 0 unless a tile of the last persistent
+ * rollout gave up waiting for its producers. */
+int vf_set_persistent(vf_handle *h, int32_t enable);
+int vf_device_status(vf_handle *h, int32_t *status);
+
 /* Context de-duplication (default on).  While a step's inputs are context, part of the network
  * sees identical inputs for every sample (step < n_context-1: everything; step < n_context: the
  * encoder up to enc2); those launches then run once with batch 1 and are broadcast.  The

@@ -188,8 +188,9 @@ def test_errors_are_loud():
         pred.score(_context(32, 32, 1, np.random.RandomState(0)), {'actions': np.zeros((2, 5, 4))}, [[[0, 0]]])
 
 
-def test_dedup_and_substreams_are_bit_identical():
-    """Context de-duplication and sub-batch streams only reorganise launches: same bits out."""
+def test_launch_strategies_are_bit_identical():
+    """Context de-duplication, sub-batch streams and the persistent single-launch rollout only
+    reorganise the same per-sample arithmetic: same bits out."""
     H = W = 32
     T, M = 3, 37
     pred, _ = _predictor(H, W, T, 2, bs=M)
@@ -198,10 +199,12 @@ def test_dedup_and_substreams_are_bit_identical():
     actions = rs.normal(0, 0.1, (M, T, 4))
     goal = np.array([[[3, 20], [30, 1]]])
     outs = []
-    for dedup, nsub in ((1, 1), (0, 1), (1, 2), (0, 3)):
+    for dedup, nsub, persistent in ((1, 1, 0), (0, 1, 0), (1, 2, 0), (0, 3, 0), (1, 1, 1), (0, 1, 1)):
         pred.set_dedup(dedup)
         pred.set_substreams(nsub)
+        pred.set_persistent(persistent)
         s, pt = pred.score(ctx, {'actions': actions}, goal)
+        assert pred.device_status() == 0
         got = pred(ctx, {'actions': actions})
         outs.append((s, pt, got['predicted_frames'], got['predicted_pixel_distributions'], got['predicted_states']))
     for other in outs[1:]:

@@ -14,12 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, 'libvf_hip.so')
 SOURCES = [os.path.join(_HERE, 'csrc', f) for f in
-           ('vf_engine.hip', 'vf_conv_mfma.h', 'vf_small_kernels.h')] + \
+           ('vf_engine.hip', 'vf_conv_mfma.h', 'vf_small_kernels.h', 'vf_persistent.h')] + \
           [os.path.join(REPO, 'include', 'vf_hip.h')]
 
 EXPORTS = ('vf_abi_version', 'vf_last_error', 'vf_weight_count', 'vf_create', 'vf_destroy',
            'vf_load_weights', 'vf_set_context', 'vf_rollout', 'vf_export',
-           'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile', 'vf_set_substreams', 'vf_set_dedup')
+           'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile', 'vf_set_substreams', 'vf_set_dedup', 'vf_set_persistent',
+           'vf_device_status')
 
 
 class VfError(RuntimeError):
@@ -50,7 +51,7 @@ def build_library(force=False, verbose=False):
     """Compile the HIP engine for gfx950 into visual_foresight_amd/libvf_hip.so."""
     if not force and not library_is_stale():
         return LIB_PATH
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-shared', '-fPIC',
            '-o', LIB_PATH + '.tmp', SOURCES[0]]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or proc.returncode:
@@ -94,6 +95,9 @@ def load_library():
     lib.vf_set_substreams.argtypes = [P, ctypes.c_int32]
     lib.vf_set_dedup.argtypes = [P, ctypes.c_int32]
     lib.vf_set_dedup.restype = ctypes.c_int
+    lib.vf_set_persistent.argtypes = [P, ctypes.c_int32]
+    lib.vf_device_status.argtypes = [P, ctypes.POINTER(ctypes.c_int32)]
+    lib.vf_set_persistent.restype = lib.vf_device_status.restype = ctypes.c_int
     lib.vf_set_profiling.restype = lib.vf_get_profile.restype = lib.vf_set_substreams.restype = ctypes.c_int
     for name in ('vf_create', 'vf_destroy', 'vf_load_weights', 'vf_set_context', 'vf_rollout',
                  'vf_export'):

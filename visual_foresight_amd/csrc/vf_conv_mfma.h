@@ -16,7 +16,10 @@
 // One ds_read_b128 / global b128 feeds four v_mfma_f32_32x32x2_f32 (K order inside an 8-channel
 // step is permuted identically on both operands: lane half h supplies channels 4h..4h+3).
 //
-// Numerics: v_mfma_f32_32x32x2_f32 is an exact-fp32 fma chain (no reduced precision).
+// Numerics: v_mfma_f32_32x32x2_f32 is an exact-fp32 fma chain (no reduced precision).  The library
+// is built with -ffp-contract=off and every fused multiply-add is written as fmaf(), so the same
+// tile body gives the same bits whether it is compiled into a per-layer kernel or into the
+// persistent rollout kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kConvThreads = 256;
-constexpr int kConvRows = 256;      // GEMM rows per workgroup
+constexpr int kConvRows = 256;      // GEMM rows per workgroup at MREP = 2 (128 at MREP = 1)
 constexpr float kLnEps = 1e-12f;
 
 enum Epilogue {
@@ -93,9 +96,14 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-template <int G, int EPI>
-__global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// One workgroup tile.  (bx, by, bz) = (row tile, channel group, K split); smem = the workgroup's
+// dynamic LDS (conv_lds_bytes).  Called by the per-layer kernel below and, item by item, by the
+// persistent rollout kernel (vf_persistent.h).
+// MREP = MFMA row blocks (of 32 GEMM rows) per wave: the workgroup covers 4 * MREP * 32 rows.
+template <int G, int EPI, int MREP>
+__device__ __forceinline__ void conv_tile(const ConvParams &p, const int bx, const int by, const int bz,
+                                          float *smem) {
+    constexpr int WROWS = MREP * 32;    // GEMM rows per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     const int KC = p.KC, KCpad = KC + 4, K8 = KC >> 3;
@@ -104,17 +112,17 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
     const int tile_floats = p.NI * tile_px * KCpad;
     float *lnTab = smem + tile_floats;                       // [2][NI][2]: mean, rstd
     double *red = reinterpret_cast<double *>(lnTab + 4 * p.NI);   // [4 waves][2]
-    const int cg = blockIdx.y;
+    const int cg = by;
     const int tiles_per_img = p.tilesY * p.tilesX;
 
     int bimg0, ty0, tx0, tile_id;
     if (p.NI == 1) {
-        bimg0 = blockIdx.x / tiles_per_img;
-        tile_id = blockIdx.x % tiles_per_img;
+        bimg0 = bx / tiles_per_img;
+        tile_id = bx % tiles_per_img;
         ty0 = (tile_id / p.tilesX) * p.TH;
         tx0 = (tile_id % p.tilesX) * p.TW;
     } else {
-        bimg0 = blockIdx.x * p.NI;
+        bimg0 = bx * p.NI;
         tile_id = 0; ty0 = 0; tx0 = 0;
     }
 
@@ -138,21 +146,21 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
         lnTab[2 * i + 1] = rstd;
     }
 
-    // ---- this lane's two A rows (GEMM rows wave*64 + m*32 + n)
+    // ---- this lane's A rows (GEMM rows wave*WROWS + m*32 + n)
     const int px_per_img = p.TH * p.TW;
-    int abase[2];
+    int abase[MREP];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int row = wave * 64 + m * 32 + n;
+    for (int m = 0; m < MREP; ++m) {
+        const int row = wave * WROWS + m * 32 + n;
         const int img = row / p.RPI, rem = row % p.RPI;
         const bool ok = img < p.NI && rem < px_per_img;
         const int y = rem / p.TW, x = rem % p.TW;
         abase[m] = (ok ? (img * tile_px + y * p.stride * LW + x * p.stride) * KCpad : 0) + kh * 4;
     }
 
-    f32x16 acc[2][G];
+    f32x16 acc[MREP][G];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MREP; ++m)
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
     const int ntaps = p.KH * p.KW;
     const int Ntot = p.ncg * G * 32;
     const int total_chunks = p.seg[0].nchunk + (p.nseg > 1 ? p.seg[1].nchunk : 0);
-    const int ch_begin = blockIdx.z * p.chunks_per_split;
+    const int ch_begin = bz * p.chunks_per_split;
     const int ch_end = min(ch_begin + p.chunks_per_split, total_chunks);
     const float *wlane = p.Wp + ((long long)kh * Ntot + (cg * G) * 32 + n) * 4;
     const long long wstep = (long long)2 * Ntot * 4;        // floats per (chunk, tap, k8) block
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int cc = (c + j) % sg.gamma_mod;
-                        v[j] = (v[j] - mean) * rstd * sg.gamma[cc] + sg.beta[cc];
+                        v[j] = fmaf((v[j] - mean) * rstd, sg.gamma[cc], sg.beta[cc]);
                     }
                 }
                 if (sg.relu) {
@@ -219,16 +227,17 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
         const float *wchunk = wlane + (long long)ci * ntaps * K8 * wstep;
         const int nit = ntaps * K8;
         const f32x4 *smem4 = reinterpret_cast<const f32x4 *>(smem);
-        const int a0base = abase[0] >> 2, a1base = abase[1] >> 2;   // in float4 units
+        int ab4[MREP];                                              // in float4 units
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) ab4[m] = abase[m] >> 2;
         const int kcp4 = KCpad >> 2;
         int ky = 0, kx = 0, k8 = 0;
 
-        f32x4 aP[2], aQ[2], bP[G], bQ[G];
+        f32x4 aP[MREP], aQ[MREP], bP[G], bQ[G];
 #define VF_FETCH(A_, B_, IT_)                                                                   \
         {                                                                                       \
             const int ao_ = (ky * LW + kx) * kcp4 + k8 * 2;                                     \
-            A_[0] = smem4[a0base + ao_];                                                        \
-            A_[1] = smem4[a1base + ao_];                                                        \
+            _Pragma("unroll") for (int m = 0; m < MREP; ++m) A_[m] = smem4[ab4[m] + ao_];      \
             const float *wp_ = wchunk + (long long)(IT_) * wstep;                               \
             _Pragma("unroll") for (int g = 0; g < G; ++g)                                       \
                 B_[g] = *reinterpret_cast<const f32x4 *>(wp_ + g * 128);                        \
@@ -237,8 +246,8 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
 #define VF_MFMA(A_, B_)                                                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
             _Pragma("unroll") for (int g = 0; g < G; ++g) {                                     \
-                acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[0][j], B_[g][j], acc[0][g], 0, 0, 0); \
-                acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[1][j], B_[g][j], acc[1][g], 0, 0, 0); \
+                _Pragma("unroll") for (int m = 0; m < MREP; ++m)                                \
+                    acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m][j], B_[g][j], acc[m][g], 0, 0, 0); \
             }                                                                                   \
         }
         VF_FETCH(aP, bP, 0)
@@ -263,10 +272,10 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
     float ssum = 0.f, ssq = 0.f;            // LayerNorm partials over this lane's outputs
 
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MREP; ++m) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = wave * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int row = wave * WROWS + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             const int img = row / p.RPI, rem = row % p.RPI;
             const int y = ty0 + rem / p.TW, x = tx0 + rem % p.TW;
             const int b = bimg0 + img;
@@ -280,18 +289,18 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
                 const float go = acc[m][3 % G][r] + bias_g[3 % G];
                 const float c_old = p.cstate_in[(long long)b * p.cin_bstride +
                                                 ((long long)y * p.Wout + x) * p.Cout + ch];
-                const float c_new = c_old * sigmoidf_(gf + 1.0f) + sigmoidf_(gi) * tanhf_(gj);
+                const float c_new = fmaf(c_old, sigmoidf_(gf + 1.0f), sigmoidf_(gi) * tanhf_(gj));
                 const float h_new = tanhf_(c_new) * sigmoidf_(go);
                 p.cstate[o] = c_new;
                 p.out[o] = h_new;
-                ssum += h_new; ssq += h_new * h_new;
+                ssum += h_new; ssq = fmaf(h_new, h_new, ssq);
             } else if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_RAW_STATS) {
                 if (ch < p.Cout) {
                     float v = acc[m][0][r] + bias_g[0];
                     if (p.sbias) v += p.sbias[(long long)b * p.sbias_ld + ch];
                     if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
                     p.out[(((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch] = v;
-                    ssum += v; ssq += v * v;
+                    ssum += v; ssq = fmaf(v, v, ssq);
                 }
             } else if constexpr (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS) {
                 if (ch < p.Cout) {
@@ -301,12 +310,12 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
                         float v = acc[m][g][r] + bias_g[g];
                         if (EPI == EPI_CONVT_RELU) v = fmaxf(v, 0.f);
                         p.out[(((long long)b * (2 * p.Hout) + oy) * (2 * p.Wout) + ox) * p.Cout + ch] = v;
-                        ssum += v; ssq += v * v;
+                        ssum += v; ssq = fmaf(v, v, ssq);
                     }
                 }
             } else {    // EPI_PARTIAL: [split][B][n_valid]
                 if (ch < p.n_valid)
-                    p.out[((long long)blockIdx.z * p.B + b) * p.n_valid + ch] = acc[m][0][r];
+                    p.out[((long long)bz * p.B + b) * p.n_valid + ch] = acc[m][0][r];
             }
         }
     }
@@ -325,9 +334,9 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
                 dst[0] = su; dst[1] = sq;
             }
         } else {
-            // RPI is a multiple of 64 here: wave w owns image slot (w*64)/RPI entirely or shares
-            // it with its neighbours; sum the waves of each image in fixed order
-            const int waves_per_img = p.RPI / 64;
+            // RPI is a multiple of WROWS here: wave w owns image slot (w*WROWS)/RPI entirely or
+            // shares it with its neighbours; sum the waves of each image in fixed order
+            const int waves_per_img = p.RPI / WROWS;
             if (lane == 0 && (wave % waves_per_img) == 0) {
                 const int img = wave / waves_per_img;
                 const int b = bimg0 + img;
@@ -340,6 +349,12 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvPa
             }
         }
     }
+}
+
+template <int G, int EPI, int MREP>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_tile<G, EPI, MREP>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 }  // namespace vf

@@ -11,12 +11,14 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "../../include/vf_hip.h"
 #include "vf_conv_mfma.h"
 #include "vf_small_kernels.h"
+#include "vf_persistent.h"
 
 namespace vf {
 
@@ -113,6 +115,7 @@ struct ConvLayer {
     int KH, KW, stride, pad;        // kernel geometry as the GEMM sees it
     int segC[2], nseg;
     int KC, nchunk[2];
+    int mrep;                       // MFMA row blocks per wave: the workgroup covers 128 * mrep rows
     int NI, TH, TW, RPI, tilesY, tilesX;
     int ncg, Cout;
     int nsplit, chunks_per_split, n_valid;
@@ -130,19 +133,21 @@ static size_t conv_lds_bytes(const ConvLayer &l, int KC) {
 
 // choose tile shape and chunk size for a layer whose GEMM row grid is Hout x Wout
 static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images) {
+    const int rows = 128 * l.mrep, wrows = 32 * l.mrep;
     if (one_pixel_images) {         // FC: every sample is a 1x1 image with many channels
-        l.TH = l.TW = 1; l.tilesY = l.tilesX = 1; l.RPI = 1; l.NI = kConvRows;
+        l.TH = l.TW = 1; l.tilesY = l.tilesX = 1; l.RPI = 1; l.NI = rows;
     } else {
         l.TW = std::min(l.Wout, 32);
-        l.TH = std::min(l.Hout, kConvRows / l.TW);
+        l.TH = std::min(l.Hout, rows / l.TW);
         l.tilesX = (l.Wout + l.TW - 1) / l.TW;
         l.tilesY = (l.Hout + l.TH - 1) / l.TH;
         const int px = l.TH * l.TW;
-        if (l.tilesX * l.tilesY == 1 && px <= kConvRows / 2) {
-            l.RPI = needs_stats ? round_up(px, 64) : px;
-            l.NI = kConvRows / l.RPI;
+        if (l.tilesX * l.tilesY == 1 && px <= rows / 2) {
+            // several whole images per workgroup; with statistics every wave must sit inside one image
+            l.RPI = needs_stats ? round_up(px, wrows) : px;
+            l.NI = rows / l.RPI;
         } else {
-            l.RPI = kConvRows; l.NI = 1;
+            l.RPI = rows; l.NI = 1;
         }
     }
     const int maxC = std::max(l.segC[0], l.nseg > 1 ? l.segC[1] : 0);
@@ -269,6 +274,23 @@ struct vf_handle {
     bool dedup = true;
     std::vector<BatchView> shared_views;
 
+    // persistent single-launch rollout (vf_persistent.h)
+    bool persistent = false;
+    int n_cu = 256;
+    float *actions_buf = nullptr;
+    PhaseDesc *d_phases = nullptr;
+    size_t sched_capacity = 0, counter_capacity = 0;
+    int *d_sync = nullptr;              // [ticket, status, counters...]
+    unsigned long long *d_stats = nullptr;  // debugging aid (VF_PERSIST_STATS): per-phase wait/run ticks
+    std::vector<int> sched_types, sched_nitems;
+    int sched_B = -1, sched_items = 0, sched_counters = 0, sched_phases = 0;
+    int n_groups = 1, group_offset = 9, sched_groups = 0, sched_offset = 0;
+    int persist_wgs_per_cu = 2;
+    bool sched_dedup = true;
+    int32_t sched_goal[2 * kMaxDesig] = {0};
+    double sched_flops = 0.0;
+    size_t sched_lds = 0;
+
     // sub-batch streams (forked from / joined to the caller's stream inside vf_rollout)
     int n_sub = 1;
     std::vector<hipStream_t> sub_streams;
@@ -310,8 +332,8 @@ static int validate(const vf_config *c) {
 
 static void init_layer(ConvLayer &l, const char *name, PackMode mode, int Hin, int Win, int Hout, int Wout,
                        int KH, int KW, int stride, int pad, int c0, int c1, int Cout, bool stats,
-                       bool fc = false) {
-    l.name = name; l.mode = mode; l.G = (mode == PACK_PLAIN) ? 1 : 4;
+                       bool fc = false, int mrep = 1) {
+    l.name = name; l.mode = mode; l.G = (mode == PACK_PLAIN) ? 1 : 4; l.mrep = mrep;
     l.Hin = Hin; l.Win = Win; l.Hout = Hout; l.Wout = Wout;
     l.KH = KH; l.KW = KW; l.stride = stride; l.pad = pad;
     l.segC[0] = c0; l.segC[1] = c1; l.nseg = c1 > 0 ? 2 : 1;
@@ -328,19 +350,32 @@ static int upload(vf_handle *h, float **dst, const float *src, size_t n) {
     return VF_OK;
 }
 
-template <int G, int EPI>
-static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
+template <int G, int EPI, int MREP>
+static int launch_conv_m(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     static size_t configured = 0;
     if (l.lds_bytes > configured) {
-        VF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<G, EPI>),
+        VF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<G, EPI, MREP>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes));
         configured = l.lds_bytes;
     }
     const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
     dim3 grid(tiles, l.ncg, l.nsplit);
-    hipLaunchKernelGGL((conv_mfma_kernel<G, EPI>), grid, dim3(kConvThreads), l.lds_bytes, st, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<G, EPI, MREP>), grid, dim3(kConvThreads), l.lds_bytes, st, p);
     VF_HIP_CHECK(hipGetLastError());
     return VF_OK;
+}
+
+// which (G, EPI, MREP) instances exist: LSTM in both tile heights, the FC with 256 rows (it has
+// few rows and a long K), every other layer with 128-row tiles
+template <int G, int EPI>
+static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
+    if constexpr (EPI == EPI_LSTM) {
+        return l.mrep == 1 ? launch_conv_m<G, EPI, 1>(l, p, st) : launch_conv_m<G, EPI, 2>(l, p, st);
+    } else if constexpr (EPI == EPI_PARTIAL) {
+        return launch_conv_m<G, EPI, 2>(l, p, st);
+    } else {
+        return launch_conv_m<G, EPI, 1>(l, p, st);
+    }
 }
 
 struct SegArg {
@@ -424,22 +459,27 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     const int *L = kLstmSizes;
     h->ntiles = ((H + kCompTile - 1) / kCompTile) * ((W + kCompTile - 1) / kCompTile);
 
+    // rows per LSTM workgroup: 128 (mrep 1) keeps items short - the per-sample dependency chain,
+    // not the MFMA rate, bounds a 200-sample rollout; VF_LSTM_MREP=2222222 selects 256-row tiles
+    int lstm_mrep[7] = {1, 1, 1, 1, 1, 1, 1};
+    if (const char *e = getenv("VF_LSTM_MREP"))
+        for (int k = 0; k < 7 && e[k]; ++k) lstm_mrep[k] = e[k] == '2' ? 2 : 1;
     init_layer(h->enc0, "enc0", PACK_PLAIN, H, W, H2, W2, 5, 5, 2, 1, 3, 0, 32, true);
-    init_layer(h->lstm[0], "lstm1", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, 32, L[0], L[0], true);
-    init_layer(h->lstm[1], "lstm2", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[0], L[1], L[1], true);
+    init_layer(h->lstm[0], "lstm1", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, 32, L[0], L[0], true, false, lstm_mrep[0]);
+    init_layer(h->lstm[1], "lstm2", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[0], L[1], L[1], true, false, lstm_mrep[1]);
     init_layer(h->enc1, "enc1", PACK_PLAIN, H2, W2, H4, W4, 3, 3, 2, 0, L[1], 0, L[1], false);
-    init_layer(h->lstm[2], "lstm3", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[1], L[2], L[2], true);
-    init_layer(h->lstm[3], "lstm4", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[2], L[3], L[3], true);
+    init_layer(h->lstm[2], "lstm3", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[1], L[2], L[2], true, false, lstm_mrep[2]);
+    init_layer(h->lstm[3], "lstm4", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[2], L[3], L[3], true, false, lstm_mrep[3]);
     init_layer(h->enc2, "enc2", PACK_PLAIN, H4, W4, H8, W8, 3, 3, 2, 0, L[3], 0, L[3], false);
     init_layer(h->enc3, "enc3", PACK_PLAIN, H8, W8, H8, W8, 1, 1, 1, 0, L[3], 0, L[3], false);
-    init_layer(h->lstm[4], "lstm5", PACK_LSTM, H8, W8, H8, W8, 5, 5, 1, 2, L[3], L[4], L[4], true);
+    init_layer(h->lstm[4], "lstm5", PACK_LSTM, H8, W8, H8, W8, 5, 5, 1, 2, L[3], L[4], L[4], true, false, lstm_mrep[4]);
     init_layer(h->convt1, "convt1", PACK_CONVT, H8, W8, H8, W8, 2, 2, 1, 1, L[4], 0, L[4], false);
-    init_layer(h->lstm[5], "lstm6", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[4], L[5], L[5], true);
+    init_layer(h->lstm[5], "lstm6", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[4], L[5], L[5], true, false, lstm_mrep[5]);
     init_layer(h->convt2, "convt2", PACK_CONVT, H4, W4, H4, W4, 2, 2, 1, 1, L[5], L[1], L[5], false);
-    init_layer(h->lstm[6], "lstm7", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[5], L[6], L[6], true);
+    init_layer(h->lstm[6], "lstm7", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[5], L[6], L[6], true, false, lstm_mrep[6]);
     init_layer(h->convt3, "convt3", PACK_CONVT, H2, W2, H2, W2, 2, 2, 1, 1, L[6], 32, 32, true);
     // CDNA FC as a K-split GEMM over 1x1 "images"
-    init_layer(h->fc, "cdna", PACK_PLAIN, 1, 1, 1, 1, 1, 1, 1, 0, H8 * W8 * L[4], 0, kTaps * h->K, false, true);
+    init_layer(h->fc, "cdna", PACK_PLAIN, 1, 1, 1, 1, 1, 1, 1, 0, H8 * W8 * L[4], 0, kTaps * h->K, false, true, 2);
     {
         ConvLayer &f = h->fc;
         const int total = f.nchunk[0];
@@ -486,6 +526,20 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     VF_ALLOC(h->states_all, (size_t)Bc * h->T * cfg->sdim);
     h->sums_step_stride = (long long)Bc * ND * h->ntiles * 2;
     VF_ALLOC(h->sums, (size_t)h->T * h->sums_step_stride);
+    VF_ALLOC(h->actions_buf, (size_t)Bc * h->T * cfg->adim);
+    h->sched_capacity = ((size_t)h->S * 20 + 8) * kMaxSubBatches;
+    h->counter_capacity = ((size_t)h->S * 20 + 8) * ((size_t)Bc + kMaxSubBatches);
+    VF_ALLOC(h->d_phases, h->sched_capacity);
+    VF_ALLOC(h->d_sync, 2 + h->counter_capacity);
+    if (hipMemset(h->d_sync, 0, 2 * sizeof(int)) != hipSuccess) {
+        vf_destroy(h);
+        return fail(VF_ERR_HIP, "hipMemset of the scheduler words failed");
+    }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+            h->n_cu = prop.multiProcessorCount;
+    }
     for (int i = 0; i < kMaxSubBatches; ++i) {
         BatchView sv;
         memset(&sv, 0, sizeof(sv));
@@ -598,6 +652,8 @@ int vf_set_context(vf_handle *h, const uint8_t *d_frames, const float *d_states,
     return VF_OK;
 }
 
+}  // extern "C"
+
 static BatchView make_view(vf_handle *h, const float *d_actions, int b0) {
     const vf_config &c = h->cfg;
     const int H = h->H, W = h->W, T = h->T, ND = h->ND;
@@ -633,39 +689,144 @@ static BatchView make_view(vf_handle *h, const float *d_actions, int b0) {
     return v;
 }
 
-// A tensor of one step: where it lives and whether it is one image shared by every sample.
-struct Loc {
-    bool shared;
-    int B;                  // samples the producing launch covers (1 when shared)
+// ------------------------------------------------------------------ rollout emission
+// emit_rollout() walks the S steps of the predictor once and hands every unit of device work
+// to a sink, together with the units it depends on.  LaunchSink enqueues one kernel per unit
+// (stream order makes the dependencies implicit); ScheduleSink records the units as phases of
+// the persistent launch (vf_persistent.h) with explicit per-sample dependencies.
+struct LaunchSink {
+    vf_handle *h;
+    hipStream_t st;
+
+    int conv(int type, const ConvLayer &l, const ConvParams &p, std::initializer_list<int>) {
+        switch (type) {
+            case PH_LSTM: {
+                if (!h->profiling) return launch_conv_t<4, EPI_LSTM>(l, p, st);
+                while (h->ev_pool.size() < h->ev_used + 2) {
+                    hipEvent_t e;
+                    VF_HIP_CHECK(hipEventCreate(&e));
+                    h->ev_pool.push_back(e);
+                }
+                VF_HIP_CHECK(hipEventRecord(h->ev_pool[h->ev_used], st));
+                int r = launch_conv_t<4, EPI_LSTM>(l, p, st);
+                VF_HIP_CHECK(hipEventRecord(h->ev_pool[h->ev_used + 1], st));
+                h->ev_used += 2;
+                h->prof_flops += 2.0 * p.B * l.Hout * l.Wout * 25.0 * (l.segC[0] + l.segC[1]) * 4.0 * l.Cout;
+                return r;
+            }
+            case PH_CONV_RELU: return launch_conv_t<1, EPI_BIAS_RELU>(l, p, st);
+            case PH_CONV_RAW: return launch_conv_t<1, EPI_RAW_STATS>(l, p, st);
+            case PH_CONVT_RELU: return launch_conv_t<4, EPI_CONVT_RELU>(l, p, st);
+            case PH_CONVT_RAW: return launch_conv_t<4, EPI_CONVT_RAW_STATS>(l, p, st);
+            default: return launch_conv_t<1, EPI_PARTIAL>(l, p, st);
+        }
+    }
+    int sa(const SaParams &p, std::initializer_list<int>) {
+        hipLaunchKernelGGL(sa_kernel, dim3(p.B), dim3(64), 0, st, p);
+        return VF_OK;
+    }
+    int fin(const FinParams &p, std::initializer_list<int>) {
+        hipLaunchKernelGGL(cdna_finalize_kernel, dim3(p.B), dim3(256), 0, st, p);
+        return VF_OK;
+    }
+    int composite(const CompositeParams &p, int ntiles, std::initializer_list<int>) {
+        dim3 grid(ntiles, p.B);
+        switch (p.ND) {
+            case 1: hipLaunchKernelGGL((composite_kernel<1, 10>), grid, dim3(256), 0, st, p); break;
+            case 2: hipLaunchKernelGGL((composite_kernel<2, 10>), grid, dim3(256), 0, st, p); break;
+            case 3: hipLaunchKernelGGL((composite_kernel<3, 10>), grid, dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL((composite_kernel<4, 10>), grid, dim3(256), 0, st, p); break;
+        }
+        VF_HIP_CHECK(hipGetLastError());
+        return VF_OK;
+    }
+    static bool failed(int rc) { return rc != VF_OK; }
 };
 
-// All S steps of the predictor for the B samples of one view, enqueued on one stream.
-//
+struct ScheduleSink {
+    std::vector<PhaseDesc> phases;
+    int next_ticket = 0, next_counter = 0;      // tickets are re-assigned when groups are merged
+    double flops = 0.0;         // algorithmic FLOPs of all MFMA (conv / FC) phases
+    size_t max_lds = 0;
+
+    int add(PhaseDesc &P, int n_items, int counters, std::initializer_list<int> deps) {
+        P.first_ticket = next_ticket; P.n_items = n_items;
+        P.cnt_base = next_counter;
+        next_ticket += n_items; next_counter += counters;
+        P.ndep = 0;
+        for (int d : deps) {
+            if (d < 0) continue;
+            const PhaseDesc &Q = phases[d];
+            PhaseDep &dp = P.dep[P.ndep++];
+            dp.cnt_base = Q.cnt_base;
+            if (Q.whole) { dp.mode = 1; dp.expect = Q.n_items; }
+            else {
+                dp.mode = (Q.B == 1) ? 1 : 0;       // a batch-1 producer is shared by every sample
+                switch (Q.type) {
+                    case PH_SA: case PH_CDNA_FIN: dp.expect = 1; break;
+                    case PH_COMPOSITE: dp.expect = Q.gx; break;
+                    default: dp.expect = (Q.NI == 1 ? Q.tiles_per_img : 1) * Q.gy;
+                }
+            }
+        }
+        phases.push_back(P);
+        return (int)phases.size() - 1;
+    }
+    int conv(int type, const ConvLayer &l, const ConvParams &p, std::initializer_list<int> deps) {
+        PhaseDesc P;
+        memset(&P, 0, sizeof(P));
+        P.type = type; P.conv = p; P.B = p.B;
+        P.NI = l.NI; P.tiles_per_img = l.tilesY * l.tilesX;
+        P.gx = l.NI == 1 ? p.B * P.tiles_per_img : (p.B + l.NI - 1) / l.NI;
+        P.gy = l.ncg;
+        P.whole = type == PH_FC_PARTIAL;
+        P.mrep = l.mrep;
+        max_lds = std::max(max_lds, l.lds_bytes);
+        const double rows = (double)p.B * l.Hout * l.Wout;
+        const double taps = l.mode == PACK_CONVT ? 9.0 / 4.0 * 4.0 : (double)l.KH * l.KW;   // real taps
+        flops += 2.0 * rows * taps * (l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0)) *
+                 (l.mode == PACK_LSTM ? 4.0 : 1.0) * l.Cout;
+        return add(P, P.gx * P.gy * l.nsplit, P.whole ? 1 : p.B, deps);
+    }
+    int sa(const SaParams &p, std::initializer_list<int> deps) {
+        PhaseDesc P;
+        memset(&P, 0, sizeof(P));
+        P.type = PH_SA; P.sa = p; P.B = p.B;
+        return add(P, (p.B + kSaPerItem - 1) / kSaPerItem, p.B, deps);
+    }
+    int fin(const FinParams &p, std::initializer_list<int> deps) {
+        PhaseDesc P;
+        memset(&P, 0, sizeof(P));
+        P.type = PH_CDNA_FIN; P.fin = p; P.B = p.B;
+        return add(P, p.B, p.B, deps);
+    }
+    int composite(const CompositeParams &p, int ntiles, std::initializer_list<int> deps) {
+        PhaseDesc P;
+        memset(&P, 0, sizeof(P));
+        P.type = PH_COMPOSITE; P.comp = p; P.B = p.B; P.gx = ntiles;
+        return add(P, ntiles * p.B, p.B, deps);
+    }
+    static bool failed(int rc) { return rc < 0; }
+};
+
 // Context de-duplication: while a step's inputs are the context, part of the network sees the
 // same input for every sample - at steps s < n_context-1 everything (frame, action and state
 // all come from the context), and at steps s < n_context the encoder up to enc2 (enc0, lstm1-4,
-// enc1, enc2: the per-sample action only enters at enc3).  Those launches run once with batch 1
-// into the sub-batch's "shared" buffers and their consumers read them with batch stride 0; the
-// arithmetic per sample is unchanged, so results are bit-identical to the redundant evaluation.
-static int run_steps(vf_handle *h, const BatchView &v, const BatchView &sh, int B, const int32_t *goal_pix,
-                     hipStream_t st) {
+// enc1, enc2: the per-sample action only enters at enc3).  Those units run once with batch 1
+// into the "shared" buffers and their consumers read them with batch stride 0; the arithmetic
+// per sample is unchanged, so results are bit-identical to the redundant evaluation.
+template <class Sink>
+static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, int B, const int32_t *goal_pix,
+                        Sink &sink) {
     const vf_config &c = h->cfg;
     const int H = h->H, W = h->W, T = h->T, ND = h->ND, nc = c.n_context;
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
     const int *L = kLstmSizes;
     const int lh[7] = {H2, H2, H4, H4, H8, H4, H2}, lw[7] = {W2, W2, W4, W4, W8, W4, W2};
-    int rc;
-
-    // the zero initial state is one shared image per layer
-    for (int k = 0; k < 7; ++k) {
-        const size_t bytes = (size_t)lh[k] * lw[k] * L[k] * sizeof(float);
-        VF_HIP_CHECK(hipMemsetAsync(sh.c_state[k], 0, bytes, st));
-        VF_HIP_CHECK(hipMemsetAsync(sh.h_state[k][0], 0, bytes, st));
-    }
 
     auto all_shared = [&](int s) { return h->dedup && s < nc - 1; };
     auto enc_shared = [&](int s) { return h->dedup && s < nc; };
-    // is the output of lstm k at step s one shared image?
+    // is the output of lstm k at step s one shared image?  (s < 0: the shared zero state)
     auto lstm_shared = [&](int k, int s) { return s < 0 || all_shared(s) || (k < 4 && enc_shared(s)); };
 
     auto plain = [](const float *ptr, long long bs) {
@@ -678,7 +839,11 @@ static int run_steps(vf_handle *h, const BatchView &v, const BatchView &sh, int 
         s.ln_inv_n = (float)(1.0 / (double)count); s.gamma = g; s.beta = b; s.gamma_mod = gmod; s.relu = relu;
         return s;
     };
+#define VF_EMIT(var, expr)                 \
+    const int var = (expr);                \
+    if (Sink::failed(var)) return var;
 
+    int last = -1;      // terminal unit of the previous step
     for (int s = 0; s < h->S; ++s) {
         const int cur = s & 1, nxt = cur ^ 1;
         const bool produce = s >= nc - 1;
@@ -700,7 +865,7 @@ static int run_steps(vf_handle *h, const BatchView &v, const BatchView &sh, int 
         sp.state_out = produce ? v.states_all + (size_t)t_out * c.sdim : nullptr;
         sp.state_out_bstride = (long long)T * c.sdim;
         sp.sbias = D.sbias;
-        hipLaunchKernelGGL(sa_kernel, dim3(BD), dim3(64), 0, st, sp);
+        VF_EMIT(u_sa, sink.sa(sp, {last}))
 
         // ---- encoder
         const float *frame_in; long long frame_bs;
@@ -709,7 +874,7 @@ static int run_steps(vf_handle *h, const BatchView &v, const BatchView &sh, int 
 
         ConvParams p = make_params(h->enc0, BE, plain(frame_in, frame_bs), nullptr);
         p.out = E.enc0_o; p.stats = E.st_enc0;
-        if ((rc = launch_conv_t<1, EPI_RAW_STATS>(h->enc0, p, st))) return rc;
+        VF_EMIT(u_enc0, sink.conv(PH_CONV_RAW, h->enc0, p, {last}))
 
         SegArg enc0_n = normed(E.enc0_o, bs(enc_sh, (long long)H2 * W2 * 32), E.st_enc0, h->enc0.stats_nparts,
                                enc_sh, (long long)H2 * W2 * 32, h->d_ln_g[0], h->d_ln_b[0], 32, 1);
@@ -721,76 +886,73 @@ static int run_steps(vf_handle *h, const BatchView &v, const BatchView &sh, int 
             return normed(O.h_state[k][nxt], bs(shd, per), O.st_h[k], h->lstm[k].stats_nparts, shd, per,
                           h->d_ln_g[k + 1], h->d_ln_b[k + 1], L[k], 0);
         };
-        auto run_lstm = [&](int k, const SegArg &x) -> int {
+        auto lstm_params = [&](int k, const SegArg &x) {
             const bool out_sh = lstm_shared(k, s), in_sh = lstm_shared(k, s - 1);
             const BatchView &O = out_sh ? sh : v, &I = in_sh ? sh : v;
             const long long per = (long long)lh[k] * lw[k] * L[k];
-            const int Bk = out_sh ? 1 : B;
             SegArg hs = plain(I.h_state[k][cur], bs(in_sh, per));
-            ConvParams q = make_params(h->lstm[k], Bk, x, &hs);
+            ConvParams q = make_params(h->lstm[k], out_sh ? 1 : B, x, &hs);
             q.out = O.h_state[k][nxt]; q.cstate = O.c_state[k]; q.stats = O.st_h[k];
             q.cstate_in = I.c_state[k]; q.cin_bstride = bs(in_sh, per);
-            if (!h->profiling) return launch_conv_t<4, EPI_LSTM>(h->lstm[k], q, st);
-            while (h->ev_pool.size() < h->ev_used + 2) {
-                hipEvent_t e;
-                VF_HIP_CHECK(hipEventCreate(&e));
-                h->ev_pool.push_back(e);
-            }
-            VF_HIP_CHECK(hipEventRecord(h->ev_pool[h->ev_used], st));
-            int r = launch_conv_t<4, EPI_LSTM>(h->lstm[k], q, st);
-            VF_HIP_CHECK(hipEventRecord(h->ev_pool[h->ev_used + 1], st));
-            h->ev_used += 2;
-            const ConvLayer &ll = h->lstm[k];
-            h->prof_flops += 2.0 * Bk * ll.Hout * ll.Wout * 25.0 * (ll.segC[0] + ll.segC[1]) * 4.0 * ll.Cout;
-            return r;
+            return q;
         };
-        if ((rc = run_lstm(0, enc0_n))) return rc;
-        if ((rc = run_lstm(1, h_normed(0)))) return rc;
+        VF_EMIT(u_l1, sink.conv(PH_LSTM, h->lstm[0], lstm_params(0, enc0_n), {u_enc0}))
+        VF_EMIT(u_l2, sink.conv(PH_LSTM, h->lstm[1], lstm_params(1, h_normed(0)), {u_l1}))
 
         p = make_params(h->enc1, BE, h_normed(1), nullptr);
         p.out = E.enc1_o;
-        if ((rc = launch_conv_t<1, EPI_BIAS_RELU>(h->enc1, p, st))) return rc;
+        VF_EMIT(u_enc1, sink.conv(PH_CONV_RELU, h->enc1, p, {u_l2}))
 
-        if ((rc = run_lstm(2, plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]))))) return rc;
-        if ((rc = run_lstm(3, h_normed(2)))) return rc;
+        VF_EMIT(u_l3, sink.conv(PH_LSTM, h->lstm[2],
+                                lstm_params(2, plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]))), {u_enc1}))
+        VF_EMIT(u_l4, sink.conv(PH_LSTM, h->lstm[3], lstm_params(3, h_normed(2)), {u_l3}))
 
         p = make_params(h->enc2, BE, h_normed(3), nullptr);
         p.out = E.enc2_o;
-        if ((rc = launch_conv_t<1, EPI_BIAS_RELU>(h->enc2, p, st))) return rc;
+        VF_EMIT(u_enc2, sink.conv(PH_CONV_RELU, h->enc2, p, {u_l4}))
 
         p = make_params(h->enc3, BD, plain(E.enc2_o, bs(enc_sh, (long long)H8 * W8 * L[3])), nullptr);
         p.out = D.enc3_o; p.sbias = D.sbias; p.sbias_ld = L[3];
-        if ((rc = launch_conv_t<1, EPI_BIAS_RELU>(h->enc3, p, st))) return rc;
+        VF_EMIT(u_enc3, sink.conv(PH_CONV_RELU, h->enc3, p, {u_enc2, u_sa}))
 
-        if ((rc = run_lstm(4, plain(D.enc3_o, bs(all_sh, (long long)H8 * W8 * L[3]))))) return rc;
+        VF_EMIT(u_l5, sink.conv(PH_LSTM, h->lstm[4],
+                                lstm_params(4, plain(D.enc3_o, bs(all_sh, (long long)H8 * W8 * L[3]))), {u_enc3}))
         SegArg h5n = h_normed(4);
-
-        // ---- CDNA kernels (only needed when this step's prediction is used)
-        if (produce) {
-            SegArg flat = h5n;      // same LayerNorm, viewed as [B][1][1][H8*W8*128]
-            p = make_params(h->fc, B, flat, nullptr);
-            p.out = v.fc_part;
-            if ((rc = launch_conv_t<1, EPI_PARTIAL>(h->fc, p, st))) return rc;
-            hipLaunchKernelGGL(cdna_finalize_kernel, dim3(B), dim3(256), 0, st, v.fc_part, h->fc.nsplit, B,
-                               h->K, h->d_b_fc, v.kern);
-        }
 
         // ---- decoder
         p = make_params(h->convt1, BD, h5n, nullptr);
         p.out = D.enc4_o;
-        if ((rc = launch_conv_t<4, EPI_CONVT_RELU>(h->convt1, p, st))) return rc;
-        if ((rc = run_lstm(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))))) return rc;
+        VF_EMIT(u_t1, sink.conv(PH_CONVT_RELU, h->convt1, p, {u_l5}))
+        VF_EMIT(u_l6, sink.conv(PH_LSTM, h->lstm[5],
+                                lstm_params(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))), {u_t1}))
 
         SegArg enc1_s = plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]));
         p = make_params(h->convt2, BD, h_normed(5), &enc1_s);
         p.out = D.enc5_o;
-        if ((rc = launch_conv_t<4, EPI_CONVT_RELU>(h->convt2, p, st))) return rc;
-        if ((rc = run_lstm(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))))) return rc;
+        VF_EMIT(u_t2, sink.conv(PH_CONVT_RELU, h->convt2, p, {u_l6}))
+        VF_EMIT(u_l7, sink.conv(PH_LSTM, h->lstm[6],
+                                lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))), {u_t2}))
+        last = u_l7;
+
+        // ---- CDNA kernels (only needed when this step's prediction is used).  Emitted late: the FC
+        // needs lstm5 of EVERY sample, and its only consumer is the compositing at the end of the step.
+        int u_fin = -1;
+        if (produce) {
+            SegArg flat = h5n;      // same LayerNorm, viewed as [B][1][1][H8*W8*128]
+            p = make_params(h->fc, B, flat, nullptr);
+            p.out = v.fc_part;
+            VF_EMIT(u_fc, sink.conv(PH_FC_PARTIAL, h->fc, p, {u_l5}))
+            FinParams fp;
+            fp.partial = v.fc_part; fp.nsplit = h->fc.nsplit; fp.B = B; fp.K = h->K;
+            fp.bias = h->d_b_fc; fp.kern = v.kern;
+            u_fin = sink.fin(fp, {u_fc});
+            if (Sink::failed(u_fin)) return u_fin;
+        }
 
         if (produce) {      // never an all-shared step
             p = make_params(h->convt3, B, h_normed(6), &enc0_n);
             p.out = v.enc6_o; p.stats = v.st_enc6;
-            if ((rc = launch_conv_t<4, EPI_CONVT_RAW_STATS>(h->convt3, p, st))) return rc;
+            VF_EMIT(u_t3, sink.conv(PH_CONVT_RAW, h->convt3, p, {u_l7}))
 
             CompositeParams cp; memset(&cp, 0, sizeof(cp));
             cp.B = B; cp.H = H; cp.W = W; cp.ND = ND; cp.K = h->K;
@@ -813,18 +975,151 @@ static int run_steps(vf_handle *h, const BatchView &v, const BatchView &sh, int 
             cp.out_distrib_bstride = (long long)T * H * W * ND;
             cp.out_sums = v.sums + (long long)t_out * h->sums_step_stride;
             for (int d = 0; d < ND; ++d) { cp.goal[d][0] = goal_pix[2 * d]; cp.goal[d][1] = goal_pix[2 * d + 1]; }
-            dim3 grid(h->ntiles, B);
-            switch (ND) {
-                case 1: hipLaunchKernelGGL((composite_kernel<1, 10>), grid, dim3(256), 0, st, cp); break;
-                case 2: hipLaunchKernelGGL((composite_kernel<2, 10>), grid, dim3(256), 0, st, cp); break;
-                case 3: hipLaunchKernelGGL((composite_kernel<3, 10>), grid, dim3(256), 0, st, cp); break;
-                default: hipLaunchKernelGGL((composite_kernel<4, 10>), grid, dim3(256), 0, st, cp); break;
-            }
+            VF_EMIT(u_comp, sink.composite(cp, h->ntiles, {u_t3, u_fin}))
+            last = u_comp;
         }
-        VF_HIP_CHECK(hipGetLastError());
+    }
+#undef VF_EMIT
+    return VF_OK;
+}
+
+// the zero initial LSTM state is one shared image per layer
+static int zero_shared_state(vf_handle *h, const BatchView &sh, hipStream_t st) {
+    const int H = h->H, W = h->W;
+    const int *L = kLstmSizes;
+    const int lh[7] = {H / 2, H / 2, H / 4, H / 4, H / 8, H / 4, H / 2};
+    const int lw[7] = {W / 2, W / 2, W / 4, W / 4, W / 8, W / 4, W / 2};
+    for (int k = 0; k < 7; ++k) {
+        const size_t bytes = (size_t)lh[k] * lw[k] * L[k] * sizeof(float);
+        VF_HIP_CHECK(hipMemsetAsync(sh.c_state[k], 0, bytes, st));
+        VF_HIP_CHECK(hipMemsetAsync(sh.h_state[k][0], 0, bytes, st));
     }
     return VF_OK;
 }
+
+static int run_steps(vf_handle *h, const BatchView &v, const BatchView &sh, int B, const int32_t *goal_pix,
+                     hipStream_t st) {
+    int rc = zero_shared_state(h, sh, st);
+    if (rc) return rc;
+    LaunchSink sink{h, st};
+    return emit_rollout(h, v, sh, B, goal_pix, sink);
+}
+
+template <int ND>
+static int launch_persistent_t(vf_handle *h, const Schedule &sc, int grid, size_t lds, hipStream_t st) {
+    static size_t configured = 0;
+    if (lds > configured) {
+        VF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_persistent_kernel<ND>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL((rollout_persistent_kernel<ND>), dim3(grid), dim3(kConvThreads), lds, st, sc.phases, sc);
+    VF_HIP_CHECK(hipGetLastError());
+    return VF_OK;
+}
+
+// the whole rollout as one persistent launch (vf_persistent.h)
+static int run_persistent(vf_handle *h, const float *d_actions, int B, const int32_t *goal_pix, hipStream_t st) {
+    int rc;
+    // the schedule holds pointers into the handle's own action buffer, so it only depends on
+    // (B, goal pixels) and is rebuilt when those change
+    const size_t act_bytes = (size_t)B * h->T * h->cfg.adim * sizeof(float);
+    VF_HIP_CHECK(hipMemcpyAsync(h->actions_buf, d_actions, act_bytes, hipMemcpyDeviceToDevice, st));
+    const int ngroups = std::max(1, std::min({h->n_groups, kMaxSubBatches, B / 8}));
+    bool rebuild = h->sched_B != B || h->sched_dedup != h->dedup || h->sched_groups != ngroups ||
+                   h->sched_offset != h->group_offset;
+    for (int d = 0; d < 2 * h->ND; ++d) rebuild = rebuild || h->sched_goal[d] != goal_pix[d];
+    if (rebuild) {
+        // Sample groups: each group of samples gets its own phase list (own shared buffers, own
+        // counters); the lists are merged with a phase offset so that while one group is in the
+        // narrow 8x8 / 16x16 middle of the network another one is in the wide 32x32 layers.
+        std::vector<ScheduleSink> sinks(ngroups);
+        int counters = 0;
+        double flops = 0.0;
+        size_t max_lds = 0;
+        for (int g = 0; g < ngroups; ++g) {
+            const int b0 = (int)((long long)B * g / ngroups), b1 = (int)((long long)B * (g + 1) / ngroups);
+            sinks[g].next_counter = counters;
+            if ((rc = emit_rollout(h, make_view(h, h->actions_buf, b0), h->shared_views[g], b1 - b0, goal_pix,
+                                   sinks[g])) < 0)
+                return rc;
+            counters = sinks[g].next_counter;
+            flops += sinks[g].flops;
+            max_lds = std::max(max_lds, sinks[g].max_lds);
+        }
+        std::vector<PhaseDesc> merged;
+        std::vector<size_t> pos(ngroups, 0);
+        for (long long vt = 0;; ++vt) {     // virtual time: group g runs its phase i at vt = i + g * offset
+            bool any_left = false;
+            for (int g = 0; g < ngroups; ++g) {
+                const long long i = vt - (long long)g * h->group_offset;
+                if (pos[g] < sinks[g].phases.size()) any_left = true;
+                if (i >= 0 && (size_t)i == pos[g] && pos[g] < sinks[g].phases.size())
+                    merged.push_back(sinks[g].phases[pos[g]++]);
+            }
+            if (!any_left) break;
+        }
+        int ticket = 0;
+        for (PhaseDesc &P : merged) { P.first_ticket = ticket; ticket += P.n_items; }
+        if (merged.size() > h->sched_capacity || (size_t)counters > h->counter_capacity)
+            return fail(VF_ERR_INVALID, "persistent schedule exceeds its preallocated capacity");
+        // an earlier rollout may still be reading the device copy
+        VF_HIP_CHECK(hipStreamSynchronize(st));
+        VF_HIP_CHECK(hipMemcpy(h->d_phases, merged.data(), merged.size() * sizeof(PhaseDesc),
+                               hipMemcpyHostToDevice));
+        h->sched_B = B; h->sched_dedup = h->dedup; h->sched_groups = ngroups; h->sched_offset = h->group_offset;
+        for (int d = 0; d < 2 * h->ND; ++d) h->sched_goal[d] = goal_pix[d];
+        h->sched_items = ticket; h->sched_counters = counters;
+        h->sched_phases = (int)merged.size();
+        h->sched_types.clear(); h->sched_nitems.clear();
+        for (const PhaseDesc &P : merged) { h->sched_types.push_back(P.type); h->sched_nitems.push_back(P.n_items); }
+        h->sched_flops = flops;
+        h->sched_lds = std::max(max_lds, (size_t)composite_lds_floats<kMaxDesig, 10>() * 4) + 16;
+    }
+    for (int g = 0; g < ngroups; ++g)
+        if ((rc = zero_shared_state(h, h->shared_views[g], st))) return rc;
+    VF_HIP_CHECK(hipMemsetAsync(h->d_sync, 0, (2 + (size_t)h->sched_counters) * sizeof(int), st));
+    Schedule sc;
+    sc.phases = h->d_phases; sc.n_phases = h->sched_phases; sc.total_items = h->sched_items;
+    sc.ticket = h->d_sync; sc.status = h->d_sync + 1; sc.counters = h->d_sync + 2;
+    sc.stats = nullptr;
+    if (getenv("VF_PERSIST_STATS")) {
+        if (!h->d_stats) {
+            void *q = nullptr;
+            VF_HIP_CHECK(hipMalloc(&q, h->sched_capacity * 2 * sizeof(unsigned long long)));
+            h->allocs.push_back(q);
+            h->d_stats = reinterpret_cast<unsigned long long *>(q);
+        }
+        VF_HIP_CHECK(hipMemsetAsync(h->d_stats, 0, h->sched_capacity * 2 * sizeof(unsigned long long), st));
+        sc.stats = h->d_stats;
+    }
+    const int grid = std::min(h->sched_items, h->n_cu * h->persist_wgs_per_cu);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling) {
+        while (h->ev_pool.size() < h->ev_used + 2) {
+            hipEvent_t e;
+            VF_HIP_CHECK(hipEventCreate(&e));
+            h->ev_pool.push_back(e);
+        }
+        e0 = h->ev_pool[h->ev_used]; e1 = h->ev_pool[h->ev_used + 1];
+        VF_HIP_CHECK(hipEventRecord(e0, st));
+    }
+    switch (h->ND) {
+        case 1: rc = launch_persistent_t<1>(h, sc, grid, h->sched_lds, st); break;
+        case 2: rc = launch_persistent_t<2>(h, sc, grid, h->sched_lds, st); break;
+        case 3: rc = launch_persistent_t<3>(h, sc, grid, h->sched_lds, st); break;
+        default: rc = launch_persistent_t<4>(h, sc, grid, h->sched_lds, st); break;
+    }
+    if (rc) return rc;
+    if (h->profiling) {
+        VF_HIP_CHECK(hipEventRecord(e1, st));
+        h->ev_used += 2;
+        h->prof_flops += h->sched_flops;
+    }
+    return VF_OK;
+}
+
+extern "C" {
 
 int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *goal_pix, float finalweight,
                float *d_scores, float *d_scores_per_task, void *stream) {
@@ -841,7 +1136,9 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
     // sub-batches that advance on forked streams: while one sub-batch drains the tail of a
     // layer, the other's workgroups fill the idle CUs.  Results are bit-identical for any split.
     const int nsub = std::max(1, std::min({h->n_sub, B / 16, (int)h->sub_streams.size() + 1}));
-    if (nsub == 1) {
+    if (h->persistent) {
+        if ((rc = run_persistent(h, d_actions, B, goal_pix, st))) return rc;
+    } else if (nsub == 1) {
         if ((rc = run_steps(h, make_view(h, d_actions, 0), h->shared_views[0], B, goal_pix, st))) return rc;
     } else {
         VF_HIP_CHECK(hipEventRecord(h->ev_fork, st));
@@ -861,6 +1158,35 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
     VF_HIP_CHECK(hipGetLastError());
     h->last_B = B;
     return VF_OK;
+}
+
+int vf_set_persistent(vf_handle *h, int32_t enable) {
+    if (!h) return fail(VF_ERR_INVALID, "null handle");
+    h->persistent = enable != 0;
+    // tuning knobs of the persistent schedule (sample groups, their phase offset, resident
+    // workgroups per CU); read once per switch so A/B runs need no rebuild
+    if (const char *e = getenv("VF_GROUPS")) h->n_groups = std::max(1, atoi(e));
+    if (const char *e = getenv("VF_GROUP_OFFSET")) h->group_offset = std::max(0, atoi(e));
+    if (const char *e = getenv("VF_PERSIST_WGS_PER_CU")) h->persist_wgs_per_cu = std::max(1, std::min(4, atoi(e)));
+    return VF_OK;
+}
+
+int vf_device_status(vf_handle *h, int32_t *status) {
+    if (!h || !status) return fail(VF_ERR_INVALID, "null argument");
+    VF_HIP_CHECK(hipSetDevice(h->cfg.device));
+    VF_HIP_CHECK(hipMemcpy(status, h->d_sync + 1, sizeof(int), hipMemcpyDeviceToHost));
+    return VF_OK;
+}
+
+// debugging aid: per-phase (type, items, wait ticks, run ticks) of the last persistent rollout
+int vf_debug_phase_stats(vf_handle *h, int32_t max_phases, int32_t *types, int32_t *items, uint64_t *wait_run) {
+    if (!h || !h->d_stats) return fail(VF_ERR_INVALID, "no phase statistics (set VF_PERSIST_STATS)");
+    VF_HIP_CHECK(hipSetDevice(h->cfg.device));
+    VF_HIP_CHECK(hipDeviceSynchronize());
+    const int n = std::min<int>(max_phases, h->sched_phases);
+    for (int i = 0; i < n; ++i) { types[i] = h->sched_types[i]; items[i] = h->sched_nitems[i]; }
+    VF_HIP_CHECK(hipMemcpy(wait_run, h->d_stats, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return n;
 }
 
 int vf_set_dedup(vf_handle *h, int32_t enable) {

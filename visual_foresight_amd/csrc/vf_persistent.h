@@ -1,0 +1,216 @@
+// vf_persistent.h - the whole rollout (all steps, all layers, all samples) as ONE persistent launch.
+//
+// Why: every layer launch of the per-layer path ends in a tail (at B=200 the 800/400/200
+// workgroups of a layer fill 512 workgroup slots 1.56 / 0.78 / 0.39 times), and the next layer
+// cannot start before the last workgroup of the previous one retires - although a sample's next
+// layer only needs THAT sample's previous layer.  Here the launch is a list of phases (one per
+// former kernel launch) cut into items (one per former workgroup).  Resident workgroups draw
+// items from one ticket counter in phase order; before running an item they wait until the
+// producer phases have finished the tiles of the samples the item covers (per-phase per-sample
+// completion counters).  So the head of layer k+1 overlaps the tail of layer k, and step s+1
+// overlaps step s.  Deadlock-free by construction: an item only waits for items with smaller
+// tickets, and tickets are only drawn by running workgroups.
+//
+// Visibility between workgroups follows the agent-scope release/acquire recipe of the CDNA guide
+// (section 6, guideline 16): producer = every wave drains its stores, barrier, one lane issues
+// fence(release, agent) and then the relaxed agent-scope counter increments; consumer = one wave
+// polls the counters relaxed, one lane issues fence(acquire, agent), barrier, plain loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vf_conv_mfma.h"
+#include "vf_small_kernels.h"
+
+namespace vf {
+
+enum PhaseType {
+    PH_LSTM = 0, PH_CONV_RELU, PH_CONV_RAW, PH_CONVT_RELU, PH_CONVT_RAW, PH_FC_PARTIAL,
+    PH_SA, PH_CDNA_FIN, PH_COMPOSITE
+};
+
+constexpr int kMaxDeps = 3;
+constexpr int kSaPerItem = 4;               // samples per PH_SA item (one per wave)
+constexpr unsigned kSpinLimit = 1u << 26;   // polls before a waiting item gives up (~ seconds)
+
+struct PhaseDep {
+    int cnt_base;       // first completion counter of the producer phase
+    int expect;         // value of a counter once the producer is done with that sample
+    int mode;           // 0: counter of the same sample, 1: counter 0 (shared / whole-phase producer)
+};
+
+struct PhaseDesc {
+    int type;
+    int first_ticket, n_items;
+    int gx, gy;             // conv phases: items = gx * gy * gz, channel group (gy) fastest
+    int B;                  // samples this phase covers
+    int NI, tiles_per_img;  // conv phases: how an item maps to samples
+    int whole;              // 1: completion is counted once per item on counter 0
+    int mrep;               // MFMA row blocks per wave of this conv phase (1 or 2)
+    int cnt_base;
+    int ndep;
+    PhaseDep dep[kMaxDeps];
+    ConvParams conv;
+    SaParams sa;
+    FinParams fin;
+    CompositeParams comp;
+};
+
+struct Schedule {
+    const PhaseDesc *phases;
+    int n_phases;
+    int total_items;
+    int *ticket;            // [1]
+    int *counters;          // completion counters
+    int *status;            // [1] set non-zero when an item gave up waiting
+    unsigned long long *stats;  // optional [n_phases][2]: summed wait / run time per phase (wall clock ticks)
+};
+
+__device__ __forceinline__ int ld_relaxed(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// samples [b0, b1) covered by item `local` of phase P
+__device__ __forceinline__ void item_samples(const PhaseDesc &P, int local, int &b0, int &b1) {
+    switch (P.type) {
+        case PH_SA: b0 = local * kSaPerItem; b1 = min(b0 + kSaPerItem, P.B); break;
+        case PH_CDNA_FIN: b0 = local; b1 = local + 1; break;
+        case PH_COMPOSITE: b0 = local / P.gx; b1 = b0 + 1; break;      // gx = tiles per image
+        case PH_FC_PARTIAL: b0 = 0; b1 = P.B; break;
+        default: {
+            const int bx = local / P.gy;    // channel group fastest: a sample's items are adjacent
+            if (P.NI == 1) { b0 = bx / P.tiles_per_img; b1 = b0 + 1; }
+            else { b0 = bx * P.NI; b1 = min(b0 + P.NI, P.B); }
+        }
+    }
+}
+
+// Out-of-line tile bodies: each keeps its own register allocation instead of being merged into
+// one giant function (inlining all of them costs ~60 VGPRs of pressure and spills).
+template <int G, int EPI, int MREP>
+__device__ __noinline__ void conv_tile_call(const ConvParams *p, int bx, int by, int bz, float *smem) {
+    conv_tile<G, EPI, MREP>(*p, bx, by, bz, smem);
+}
+template <int ND>
+__device__ __noinline__ void composite_tile_call(const CompositeParams *p, int tile, int b, float *smem) {
+    composite_tile<ND, 10>(*p, tile, b, smem);
+}
+__device__ __noinline__ void small_item_call(const PhaseDesc *P, int b0, int b1, float *smem) {
+    if (P->type == PH_SA) {
+        const int wave = threadIdx.x >> 6, b = b0 + wave;
+        if (b < b1) sa_sample(P->sa, b, threadIdx.x & 63, smem + 32 * wave);
+    } else {
+        cdna_finalize_sample(P->fin, b0, smem);
+    }
+}
+
+template <int ND>
+__global__ __launch_bounds__(kConvThreads, 2) void rollout_persistent_kernel(
+    const PhaseDesc *__restrict__ phases, const Schedule sched) {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    // all LDS in one dynamic array: 4 control words first, the tile workspace after them
+    int *s_ctl = reinterpret_cast<int *>(smem_all);
+    float *smem = smem_all + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int ph = 0;
+
+    for (;;) {
+        __syncthreads();                    // previous item fully retired (LDS reusable)
+        if (tid == 0) s_ctl[0] = atomicAdd(sched.ticket, 1);
+        __syncthreads();
+        const int t = s_ctl[0];
+        if (t >= sched.total_items) break;
+        while (t >= phases[ph].first_ticket + phases[ph].n_items) ++ph;
+        const PhaseDesc &P = phases[ph];
+        const int local = t - P.first_ticket;
+
+        int b0, b1;
+        item_samples(P, local, b0, b1);
+        const unsigned long long t_start = sched.stats ? wall_clock64() : 0ull;
+
+        // ---- wait for the producers (wave 0 polls: lane i watches sample b0 + i, strided)
+        if (wave == 0 && P.ndep > 0) {
+            unsigned spins = 0;
+            bool ok;
+            do {
+                ok = true;
+                for (int d = 0; d < P.ndep; ++d) {
+                    const PhaseDep &dp = P.dep[d];
+                    if (dp.mode == 1) {
+                        if (lane == 0) ok = ok && (ld_relaxed(sched.counters + dp.cnt_base) >= dp.expect);
+                    } else {
+                        for (int b = b0 + lane; b < b1; b += 64)
+                            ok = ok && (ld_relaxed(sched.counters + dp.cnt_base + b) >= dp.expect);
+                    }
+                }
+                ok = __all(ok);
+                if (!ok) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > kSpinLimit || ld_relaxed(sched.status) != 0) {
+                        if (lane == 0) atomicExch(sched.status, 1);
+                        break;
+                    }
+                }
+            } while (!ok);
+            if (lane == 0) {
+                s_ctl[1] = ok ? 1 : 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        } else if (tid == 0) {
+            s_ctl[1] = 1;
+        }
+        __syncthreads();
+        if (s_ctl[1] == 0) break;           // a producer never arrived: abandon the rollout
+        const unsigned long long t_run = sched.stats ? wall_clock64() : 0ull;
+
+        // ---- run the item
+        {
+            // conv items: channel group fastest, then row tile (so all items of one sample are
+            // neighbours in ticket order); FC: (cg, split) fastest over its single row tile
+            const int by = local % P.gy, bx = local / P.gy;
+            switch (P.type) {
+                case PH_LSTM:
+                    if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0, smem);
+                    else conv_tile_call<4, EPI_LSTM, 2>(&P.conv, bx, by, 0, smem);
+                    break;
+                case PH_CONV_RELU: conv_tile_call<1, EPI_BIAS_RELU, 1>(&P.conv, bx, by, 0, smem); break;
+                case PH_CONV_RAW: conv_tile_call<1, EPI_RAW_STATS, 1>(&P.conv, bx, by, 0, smem); break;
+                case PH_CONVT_RELU: conv_tile_call<4, EPI_CONVT_RELU, 1>(&P.conv, bx, by, 0, smem); break;
+                case PH_CONVT_RAW: conv_tile_call<4, EPI_CONVT_RAW_STATS, 1>(&P.conv, bx, by, 0, smem); break;
+                case PH_FC_PARTIAL:
+                    conv_tile_call<1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx, smem);
+                    break;
+                case PH_COMPOSITE: composite_tile_call<ND>(&P.comp, local % P.gx, b0, smem); break;
+                default: small_item_call(&P, b0, b1, smem); break;
+            }
+        }
+
+        // ---- publish: drain this wave's stores, barrier, one release, then the counters
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (sched.stats && tid == 0) {
+            const unsigned long long t_end = wall_clock64();
+            atomicAdd(sched.stats + 2 * ph, t_run - t_start);
+            atomicAdd(sched.stats + 2 * ph + 1, t_end - t_run);
+        }
+        if (wave == 0) {
+            if (lane == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (P.whole) {
+                if (lane == 0)
+                    __hip_atomic_fetch_add(sched.counters + P.cnt_base, 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                // lane 0 performed the release; its counter increments must not be overtaken, so
+                // the same lane publishes every covered sample
+                if (lane == 0)
+                    for (int b = b0; b < b1; ++b)
+                        __hip_atomic_fetch_add(sched.counters + P.cnt_base + b, 1, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+}  // namespace vf

@@ -42,48 +42,60 @@ struct SaParams {
     float *sbias;                       // [B][n_out]
 };
 
-__global__ void sa_kernel(const SaParams p) {
-    const int b = blockIdx.x;
-    const int t = threadIdx.x;
-    __shared__ float sa[32];
+// one sample, executed by the 64 lanes of one wave; sa = 32 floats of LDS scratch for this wave
+__device__ __forceinline__ void sa_sample(const SaParams &p, const int b, const int t, float *sa) {
     const int nsa = p.adim + p.sdim;
     if (t < p.adim) sa[t] = p.action[(long long)b * p.action_bstride + t];
     else if (t < nsa) sa[t] = p.state[(long long)b * p.state_bstride + (t - p.adim)];
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
     if (t < p.n_out) {
         float acc = 0.f;
-        for (int k = 0; k < nsa; ++k) acc += sa[k] * p.w_sa[k * p.n_out + t];
+        for (int k = 0; k < nsa; ++k) acc = fmaf(sa[k], p.w_sa[k * p.n_out + t], acc);
         p.sbias[(long long)b * p.n_out + t] = acc;
     }
     if (p.state_out && t < p.sdim) {
         float acc = 0.f;
-        for (int k = 0; k < nsa; ++k) acc += sa[k] * p.w_state[k * p.sdim + t];
+        for (int k = 0; k < nsa; ++k) acc = fmaf(sa[k], p.w_state[k * p.sdim + t], acc);
         p.state_out[(long long)b * p.state_out_bstride + t] = acc + p.b_state[t];
     }
 }
 
+__global__ void sa_kernel(const SaParams p) {
+    __shared__ float sa[32];
+    sa_sample(p, blockIdx.x, threadIdx.x, sa);
+}
+
 // ------------------------------------------------------------------------------------------
 // kern[b][tap][k] = v / sum_tap v,  v = relu(fc - shift) + shift,  fc = bias + sum_split partial
-__global__ void cdna_finalize_kernel(const float *partial, int nsplit, int B, int K,
-                                     const float *bias, float *kern) {
-    const int b = blockIdx.x;
+struct FinParams {
+    const float *partial; int nsplit; int B; int K;
+    const float *bias; float *kern;
+};
+
+// one sample per workgroup call; scratch: kTaps*16 + 16 floats of LDS
+__device__ __forceinline__ void cdna_finalize_sample(const FinParams &p, const int b, float *scratch) {
     const int t = threadIdx.x;
-    const int n = kTaps * K;
-    __shared__ float v[kTaps * 16];
-    __shared__ float norm[16];
+    const int n = kTaps * p.K;
+    float *v = scratch, *norm = scratch + kTaps * 16;
     if (t < n) {
-        float acc = bias[t];
-        for (int z = 0; z < nsplit; ++z) acc += partial[((long long)z * B + b) * n + t];
+        float acc = p.bias[t];
+        for (int z = 0; z < p.nsplit; ++z) acc += p.partial[((long long)z * p.B + b) * n + t];
         v[t] = fmaxf(acc - kReluShift, 0.f) + kReluShift;
     }
     __syncthreads();
-    if (t < K) {
+    if (t < p.K) {
         float s = 0.f;
-        for (int tap = 0; tap < kTaps; ++tap) s += v[tap * K + t];
+        for (int tap = 0; tap < kTaps; ++tap) s += v[tap * p.K + t];
         norm[t] = s;
     }
     __syncthreads();
-    if (t < n) kern[(long long)b * n + t] = v[t] / norm[t % K];
+    if (t < n) p.kern[(long long)b * n + t] = v[t] / norm[t % p.K];
+}
+
+__global__ void cdna_finalize_kernel(const FinParams p) {
+    __shared__ float scratch[kTaps * 16 + 16];
+    cdna_finalize_sample(p, blockIdx.x, scratch);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -104,22 +116,31 @@ struct CompositeParams {
     int goal[kMaxDesig][2];             // (row, col)
 };
 
+// LDS floats needed by composite_tile<ND, K>
 template <int ND, int K>
-__global__ __launch_bounds__(256) void composite_kernel(const CompositeParams p) {
+__host__ __device__ constexpr int composite_lds_floats() {
+    return (kCompTile + 4) * (kCompTile + 4) * (3 + ND) + kTaps * K + 2 + ND + 2 /*pad*/ + 2 * 4 * 2 * ND;
+}
+
+// one 16x16 pixel tile of one sample
+template <int ND, int K>
+__device__ __forceinline__ void composite_tile(const CompositeParams &p, const int tile, const int b,
+                                               float *smem) {
     constexpr int TS = kCompTile, HS = TS + 4;
     constexpr int NM = K + 1;
-    __shared__ float s_frame[HS * HS * 3];
-    __shared__ float s_dist[HS * HS * ND];
-    __shared__ float s_kern[kTaps * K];
-    __shared__ float s_ln[2];
-    __shared__ float s_dscale[ND];
-    __shared__ double s_red[4][2 * ND];
+    float *s_frame = smem;                              // [HS*HS*3]
+    float *s_dist = s_frame + HS * HS * 3;              // [HS*HS*ND]
+    float *s_kern = s_dist + HS * HS * ND;              // [kTaps*K]
+    float *s_ln = s_kern + kTaps * K;                   // [2]
+    float *s_dscale = s_ln + 2;                         // [ND]
+    // doubles: keep 8-byte alignment (all counts above are even except possibly ND)
+    double (*s_red)[2 * ND] = reinterpret_cast<double (*)[2 * ND]>(
+        smem + ((HS * HS * (3 + ND) + kTaps * K + 2 + ND + 1) & ~1));
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.y;
     const int tilesX = (p.W + TS - 1) / TS;
     const int ntiles = tilesX * ((p.H + TS - 1) / TS);
-    const int ty0 = (blockIdx.x / tilesX) * TS, tx0 = (blockIdx.x % tilesX) * TS;
+    const int ty0 = (tile / tilesX) * TS, tx0 = (tile % tilesX) * TS;
 
     if (tid == 0) {
         double su = 0.0, sq = 0.0;
@@ -181,11 +202,11 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompositeParams p)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = q * 4 + e;
-                const float f = fmaxf((raw[e] - mean) * rstd * p.gamma[c] + p.beta[c], 0.f);
+                const float f = fmaxf(fmaf((raw[e] - mean) * rstd, p.gamma[c], p.beta[c]), 0.f);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) o_rgb[j] += f * p.w_rgb[c * 3 + j];
+                for (int j = 0; j < 3; ++j) o_rgb[j] = fmaf(f, p.w_rgb[c * 3 + j], o_rgb[j]);
 #pragma unroll
-                for (int j = 0; j < NM; ++j) o_m[j] += f * p.w_mask[c * NM + j];
+                for (int j = 0; j < NM; ++j) o_m[j] = fmaf(f, p.w_mask[c * NM + j], o_m[j]);
             }
         }
         float mx = o_m[0];
@@ -203,7 +224,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompositeParams p)
         const int ctr = (ly + 2) * HS + (lx + 2);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            of[c] = o_m[0] * s_frame[ctr * 3 + c] + o_m[1] * sigmoidf_(o_rgb[c]);
+            of[c] = fmaf(o_m[0], s_frame[ctr * 3 + c], o_m[1] * sigmoidf_(o_rgb[c]));
 #pragma unroll
         for (int d = 0; d < ND; ++d) od[d] = o_m[0] * s_dist[ctr * ND + d];
 #pragma unroll
@@ -213,12 +234,12 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompositeParams p)
                 const int tap = dy * kDnaKern + dx;
                 float ke = 0.f;
 #pragma unroll
-                for (int k = 0; k < K - 1; ++k) ke += o_m[k + 2] * s_kern[tap * K + k];
+                for (int k = 0; k < K - 1; ++k) ke = fmaf(o_m[k + 2], s_kern[tap * K + k], ke);
                 const int sp = (ly + dy) * HS + (lx + dx);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) of[c] += ke * s_frame[sp * 3 + c];
+                for (int c = 0; c < 3; ++c) of[c] = fmaf(ke, s_frame[sp * 3 + c], of[c]);
 #pragma unroll
-                for (int d = 0; d < ND; ++d) od[d] += ke * s_dist[sp * ND + d];
+                for (int d = 0; d < ND; ++d) od[d] = fmaf(ke, s_dist[sp * ND + d], od[d]);
             }
         }
         const long long o = (long long)y * p.W + x;
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompositeParams p)
         for (int d = 0; d < ND; ++d) {
             dout[d] = od[d];
             const float ry = (float)(y - p.goal[d][0]), rx = (float)(x - p.goal[d][1]);
-            const float dist = sqrtf(ry * ry + rx * rx);
+            const float dist = sqrtf(fmaf(ry, ry, rx * rx));
             cost[2 * d] = (double)od[d];
             cost[2 * d + 1] = (double)od[d] * (double)dist;
         }
@@ -247,8 +268,14 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompositeParams p)
     if (tid < 2 * ND) {
         const double s = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
         const int d = tid >> 1;
-        p.out_sums[(((long long)b * ND + d) * ntiles + blockIdx.x) * 2 + (tid & 1)] = s;
+        p.out_sums[(((long long)b * ND + d) * ntiles + tile) * 2 + (tid & 1)] = s;
     }
+}
+
+template <int ND, int K>
+__global__ __launch_bounds__(256) void composite_kernel(const CompositeParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[composite_lds_floats<ND, K>()];
+    composite_tile<ND, K>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 // ------------------------------------------------------------------------------------------

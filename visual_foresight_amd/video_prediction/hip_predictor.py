@@ -65,6 +65,7 @@ class HipVPredEvaluation(object):
         _lib.check(self._libh.vf_create(ctypes.byref(self._c_cfg), ctypes.byref(self._handle)))
         self.set_substreams(int(hp.get('substreams', os.environ.get('VF_SUBSTREAMS', 1))))
         self.set_dedup(int(hp.get('dedup', os.environ.get('VF_DEDUP', 1))))
+        self.set_persistent(int(hp.get('persistent', os.environ.get('VF_PERSISTENT', 0))))
         self.weights = None
         self._last_M = 0
         self._last_lo = 0
@@ -88,6 +89,16 @@ class HipVPredEvaluation(object):
         _lib.check(self._libh.vf_get_profile(self._handle, ctypes.byref(ms), ctypes.byref(n),
                                              ctypes.byref(fl), ctypes.byref(busy)))
         return ms.value, n.value, fl.value, busy.value
+
+    def set_persistent(self, enable):
+        """Run each rollout as one persistent launch (bit-identical results; see vf_persistent.h)."""
+        _lib.check(self._libh.vf_set_persistent(self._handle, int(bool(enable))))
+        self.persistent = bool(enable)
+
+    def device_status(self):
+        st = ctypes.c_int32()
+        _lib.check(self._libh.vf_device_status(self._handle, ctypes.byref(st)))
+        return st.value
 
     def set_dedup(self, enable):
         """Switch context de-duplication (bit-identical results either way; for A/B timing)."""
