@@ -178,7 +178,11 @@ def main():
                                '%d CEM iters, pixel-distance cost, random-init weights' %
                                (args.samples_per_gpu, T, H, W, iters),
                    'num_samples': M, 'horizon': T, 'iterations': iters, 'sharding': 'samples over %d rank(s)' % world},
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel<4,EPI_LSTM> (fused conv-LSTM gate GEMM)',
+        'roofline': {'bound': 'mfma',
+                     'kernel': ('rollout_persistent_kernel (one launch per rollout: every conv-LSTM / conv / '
+                                'transposed-conv / FC tile of all steps; FLOPs = algorithmic MFMA work of the launch)'
+                                if getattr(ctrl.predictor, 'persistent', False) else
+                                'conv_mfma_kernel<4,EPI_LSTM> (fused conv-LSTM gate GEMM, one launch per layer per step)'),
                      'achieved': flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else None,
                      'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': (flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if kernel_ms > 0 else None,

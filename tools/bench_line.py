@@ -6,5 +6,5 @@ r = json.loads(sys.stdin.read().strip().splitlines()[-1])
 rf = r['roofline']
 print('%s M=%d: %.0f frames/s  %.2f iters/s  %.1f ms/step | %s: %.1f TF/s frac %.3f  launches %d avg %.1f us  share %.3f host %.1f ms' % (
     sys.argv[1] if len(sys.argv) > 1 else '', r['config']['num_samples'], r['value'], r['cem_iters_per_sec'],
-    r['ms_per_step'], rf['kernel'].split(' ')[0], rf['achieved'], rf['frac'], rf['launches'], rf['avg_launch_us'],
+    r['ms_per_step'], rf['kernel'].split(' ')[0][:26], rf['achieved'], rf['frac'], rf['launches'], rf['avg_launch_us'],
     rf['kernel_time_share'], r.get('host_ms_per_step_outside_predictor', -1)))

@@ -100,8 +100,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // dynamic LDS (conv_lds_bytes).  Called by the per-layer kernel below and, item by item, by the
 // persistent rollout kernel (vf_persistent.h).
 // MREP = MFMA row blocks (of 32 GEMM rows) per wave: the workgroup covers 4 * MREP * 32 rows.
-template <int G, int EPI, int MREP>
-__device__ __forceinline__ void conv_tile(const ConvParams &p, const int bx, const int by, const int bz,
+// PT = ConvParams (kernel argument) or ConvParams in the constant address space (persistent kernel).
+template <int G, int EPI, int MREP, class PT>
+__device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int by, const int bz,
                                           float *smem) {
     constexpr int WROWS = MREP * 32;    // GEMM rows per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -129,7 +130,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const int bx, con
     // ---- LayerNorm statistics of the producing layers (this workgroup's samples only)
     for (int i = tid; i < p.nseg * p.NI; i += kConvThreads) {
         const int s = i / p.NI, img = i % p.NI;
-        const ConvSeg &sg = p.seg[s];
+        const auto &sg = p.seg[s];
         float mean = 0.f, rstd = 1.f;
         const int b = bimg0 + img;
         if (sg.ln_part && b < p.B) {
@@ -179,7 +180,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const int bx, con
 
     for (int ci = ch_begin; ci < ch_end; ++ci) {
         const int s = (ci < p.seg[0].nchunk) ? 0 : 1;
-        const ConvSeg &sg = p.seg[s];
+        const auto &sg = p.seg[s];
         const int c0 = (s == 0 ? ci : ci - p.seg[0].nchunk) * KC;
         const bool vec_ok = (sg.C & 3) == 0;
 

@@ -1005,17 +1005,27 @@ static int run_steps(vf_handle *h, const BatchView &v, const BatchView &sh, int 
     return emit_rollout(h, v, sh, B, goal_pix, sink);
 }
 
-template <int ND>
-static int launch_persistent_t(vf_handle *h, const Schedule &sc, int grid, size_t lds, hipStream_t st) {
+template <int ND, int WPS>
+static int launch_persistent_w(vf_handle *h, const Schedule &sc, int grid, size_t lds, hipStream_t st) {
     static size_t configured = 0;
     if (lds > configured) {
-        VF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_persistent_kernel<ND>),
+        VF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_persistent_kernel<ND, WPS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
-    hipLaunchKernelGGL((rollout_persistent_kernel<ND>), dim3(grid), dim3(kConvThreads), lds, st, sc.phases, sc);
+    hipLaunchKernelGGL((rollout_persistent_kernel<ND, WPS>), dim3(grid), dim3(kConvThreads), lds, st, sc.phases,
+                       sc);
     VF_HIP_CHECK(hipGetLastError());
     return VF_OK;
+}
+
+template <int ND>
+static int launch_persistent_t(vf_handle *h, const Schedule &sc, int grid, size_t lds, hipStream_t st) {
+    // 3 resident workgroups per CU need the 168-VGPR build, which has no 256-row LSTM tile
+    bool any_mrep2 = false;
+    for (int k = 0; k < 7; ++k) any_mrep2 = any_mrep2 || h->lstm[k].mrep == 2;
+    if (h->persist_wgs_per_cu >= 3 && !any_mrep2) return launch_persistent_w<ND, 3>(h, sc, grid, lds, st);
+    return launch_persistent_w<ND, 2>(h, sc, grid, lds, st);
 }
 
 // the whole rollout as one persistent launch (vf_persistent.h)
@@ -1083,6 +1093,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     sc.phases = h->d_phases; sc.n_phases = h->sched_phases; sc.total_items = h->sched_items;
     sc.ticket = h->d_sync; sc.status = h->d_sync + 1; sc.counters = h->d_sync + 2;
     sc.stats = nullptr;
+    sc.debug_no_fence = getenv("VF_DEBUG_NO_FENCE") ? 1 : 0;
     if (getenv("VF_PERSIST_STATS")) {
         if (!h->d_stats) {
             void *q = nullptr;
@@ -1093,7 +1104,9 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         VF_HIP_CHECK(hipMemsetAsync(h->d_stats, 0, h->sched_capacity * 2 * sizeof(unsigned long long), st));
         sc.stats = h->d_stats;
     }
-    const int grid = std::min(h->sched_items, h->n_cu * h->persist_wgs_per_cu);
+    // resident workgroups per CU: bounded by the LDS a workgroup needs (160 KiB per CU)
+    const int by_lds = (int)std::max<size_t>(1, (160 * 1024) / h->sched_lds);
+    const int grid = std::min(h->sched_items, h->n_cu * std::min(h->persist_wgs_per_cu, by_lds));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) {
         while (h->ev_pool.size() < h->ev_used + 2) {

@@ -61,6 +61,7 @@ struct Schedule {
     int *ticket;            // [1]
     int *counters;          // completion counters
     int *status;            // [1] set non-zero when an item gave up waiting
+    int debug_no_fence;     // timing experiments only: skip the agent-scope fences (results invalid)
     unsigned long long *stats;  // optional [n_phases][2]: summed wait / run time per phase (wall clock ticks)
 };
 
@@ -84,31 +85,55 @@ __device__ __forceinline__ void item_samples(const PhaseDesc &P, int local, int 
 }
 
 // Out-of-line tile bodies: each keeps its own register allocation instead of being merged into
-// one giant function (inlining all of them costs ~60 VGPRs of pressure and spills).
+// one giant function (inlining all of them costs ~60 VGPRs of pressure and spills).  Two things
+// keep them as fast as the stand-alone kernels: the LDS workspace is re-derived from the
+// `extern __shared__` symbol (a pointer argument would be generic and turn every LDS access
+// into a FLAT instruction), and the parameter block is copied out of the CONSTANT address space
+// (scalar loads into SGPRs; pointers loaded from constant memory are known to be global).
+#define VF_CONST_AS __attribute__((address_space(4)))
+
+// Function arguments travel in VGPRs, so the compiler cannot know the pointer is wave-uniform;
+// readfirstlane makes it scalar, and the constant address space makes every field access an
+// s_load and every pointer field a known-global pointer.
+template <class T>
+__device__ __forceinline__ const VF_CONST_AS T &const_params(const T *generic_ptr) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(generic_ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return *(const VF_CONST_AS T *)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ float *tile_lds() {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    return smem_all + 4;    // 4 control words of the scheduler come first
+}
+
 template <int G, int EPI, int MREP>
-__device__ __noinline__ void conv_tile_call(const ConvParams *p, int bx, int by, int bz, float *smem) {
-    conv_tile<G, EPI, MREP>(*p, bx, by, bz, smem);
+__device__ __noinline__ void conv_tile_call(const ConvParams *p, int bx, int by, int bz) {
+    conv_tile<G, EPI, MREP>(const_params(p), bx, by, bz, tile_lds());
 }
 template <int ND>
-__device__ __noinline__ void composite_tile_call(const CompositeParams *p, int tile, int b, float *smem) {
-    composite_tile<ND, 10>(*p, tile, b, smem);
+__device__ __noinline__ void composite_tile_call(const CompositeParams *p, int tile, int b) {
+    composite_tile<ND, 10>(const_params(p), tile, b, tile_lds());
 }
-__device__ __noinline__ void small_item_call(const PhaseDesc *P, int b0, int b1, float *smem) {
-    if (P->type == PH_SA) {
+__device__ __noinline__ void small_item_call(const PhaseDesc *P, int type, int b0, int b1) {
+    float *smem = tile_lds();
+    if (type == PH_SA) {
         const int wave = threadIdx.x >> 6, b = b0 + wave;
-        if (b < b1) sa_sample(P->sa, b, threadIdx.x & 63, smem + 32 * wave);
+        if (b < b1) sa_sample(const_params(&P->sa), b, threadIdx.x & 63, smem + 32 * wave);
     } else {
-        cdna_finalize_sample(P->fin, b0, smem);
+        cdna_finalize_sample(const_params(&P->fin), b0, smem);
     }
 }
 
-template <int ND>
-__global__ __launch_bounds__(kConvThreads, 2) void rollout_persistent_kernel(
+// WPS = waves per SIMD the kernel is compiled for (= resident workgroups per CU).  WPS 3 leaves
+// 168 VGPRs per lane, which fits every tile body except the 256-row conv-LSTM tile (MREP 2).
+template <int ND, int WPS>
+__global__ __launch_bounds__(kConvThreads, WPS) void rollout_persistent_kernel(
     const PhaseDesc *__restrict__ phases, const Schedule sched) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     // all LDS in one dynamic array: 4 control words first, the tile workspace after them
     int *s_ctl = reinterpret_cast<int *>(smem_all);
-    float *smem = smem_all + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ph = 0;
 
@@ -152,7 +177,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void rollout_persistent_kernel(
             } while (!ok);
             if (lane == 0) {
                 s_ctl[1] = ok ? 1 : 0;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (!sched.debug_no_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         } else if (tid == 0) {
             s_ctl[1] = 1;
@@ -168,18 +193,18 @@ __global__ __launch_bounds__(kConvThreads, 2) void rollout_persistent_kernel(
             const int by = local % P.gy, bx = local / P.gy;
             switch (P.type) {
                 case PH_LSTM:
-                    if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0, smem);
-                    else conv_tile_call<4, EPI_LSTM, 2>(&P.conv, bx, by, 0, smem);
+                    if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
+                    else if constexpr (WPS <= 2) conv_tile_call<4, EPI_LSTM, 2>(&P.conv, bx, by, 0);
                     break;
-                case PH_CONV_RELU: conv_tile_call<1, EPI_BIAS_RELU, 1>(&P.conv, bx, by, 0, smem); break;
-                case PH_CONV_RAW: conv_tile_call<1, EPI_RAW_STATS, 1>(&P.conv, bx, by, 0, smem); break;
-                case PH_CONVT_RELU: conv_tile_call<4, EPI_CONVT_RELU, 1>(&P.conv, bx, by, 0, smem); break;
-                case PH_CONVT_RAW: conv_tile_call<4, EPI_CONVT_RAW_STATS, 1>(&P.conv, bx, by, 0, smem); break;
+                case PH_CONV_RELU: conv_tile_call<1, EPI_BIAS_RELU, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONV_RAW: conv_tile_call<1, EPI_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONVT_RELU: conv_tile_call<4, EPI_CONVT_RELU, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONVT_RAW: conv_tile_call<4, EPI_CONVT_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
                 case PH_FC_PARTIAL:
-                    conv_tile_call<1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx, smem);
+                    conv_tile_call<1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx);
                     break;
-                case PH_COMPOSITE: composite_tile_call<ND>(&P.comp, local % P.gx, b0, smem); break;
-                default: small_item_call(&P, b0, b1, smem); break;
+                case PH_COMPOSITE: composite_tile_call<ND>(&P.comp, local % P.gx, b0); break;
+                default: small_item_call(&P, P.type, b0, b1); break;
             }
         }
 
@@ -192,7 +217,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void rollout_persistent_kernel(
             atomicAdd(sched.stats + 2 * ph + 1, t_end - t_run);
         }
         if (wave == 0) {
-            if (lane == 0) {
+            if (lane == 0 && !sched.debug_no_fence) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }

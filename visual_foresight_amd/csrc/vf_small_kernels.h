@@ -43,7 +43,8 @@ struct SaParams {
 };
 
 // one sample, executed by the 64 lanes of one wave; sa = 32 floats of LDS scratch for this wave
-__device__ __forceinline__ void sa_sample(const SaParams &p, const int b, const int t, float *sa) {
+template <class PT>
+__device__ __forceinline__ void sa_sample(const PT &p, const int b, const int t, float *sa) {
     const int nsa = p.adim + p.sdim;
     if (t < p.adim) sa[t] = p.action[(long long)b * p.action_bstride + t];
     else if (t < nsa) sa[t] = p.state[(long long)b * p.state_bstride + (t - p.adim)];
@@ -74,7 +75,8 @@ struct FinParams {
 };
 
 // one sample per workgroup call; scratch: kTaps*16 + 16 floats of LDS
-__device__ __forceinline__ void cdna_finalize_sample(const FinParams &p, const int b, float *scratch) {
+template <class PT>
+__device__ __forceinline__ void cdna_finalize_sample(const PT &p, const int b, float *scratch) {
     const int t = threadIdx.x;
     const int n = kTaps * p.K;
     float *v = scratch, *norm = scratch + kTaps * 16;
@@ -123,9 +125,8 @@ __host__ __device__ constexpr int composite_lds_floats() {
 }
 
 // one 16x16 pixel tile of one sample
-template <int ND, int K>
-__device__ __forceinline__ void composite_tile(const CompositeParams &p, const int tile, const int b,
-                                               float *smem) {
+template <int ND, int K, class PT>
+__device__ __forceinline__ void composite_tile(const PT &p, const int tile, const int b, float *smem) {
     constexpr int TS = kCompTile, HS = TS + 4;
     constexpr int NM = K + 1;
     float *s_frame = smem;                              // [HS*HS*3]

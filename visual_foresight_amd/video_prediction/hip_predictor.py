@@ -65,7 +65,7 @@ class HipVPredEvaluation(object):
         _lib.check(self._libh.vf_create(ctypes.byref(self._c_cfg), ctypes.byref(self._handle)))
         self.set_substreams(int(hp.get('substreams', os.environ.get('VF_SUBSTREAMS', 1))))
         self.set_dedup(int(hp.get('dedup', os.environ.get('VF_DEDUP', 1))))
-        self.set_persistent(int(hp.get('persistent', os.environ.get('VF_PERSISTENT', 0))))
+        self.set_persistent(int(hp.get('persistent', os.environ.get('VF_PERSISTENT', 1))))
         self.weights = None
         self._last_M = 0
         self._last_lo = 0
