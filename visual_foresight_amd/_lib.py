@@ -12,7 +12,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, 'libvf_hip.so')
+LIB_PATH = os.environ.get('VF_LIBRARY') or os.path.join(_HERE, 'libvf_hip.so')     # override: experiments only
 SOURCES = [os.path.join(_HERE, 'csrc', f) for f in
            ('vf_engine.hip', 'vf_conv_mfma.h', 'vf_small_kernels.h', 'vf_persistent.h')] + \
           [os.path.join(REPO, 'include', 'vf_hip.h')]
@@ -41,6 +41,8 @@ def _hipcc():
 
 
 def library_is_stale():
+    if os.environ.get('VF_LIBRARY'):
+        return False
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)

@@ -23,6 +23,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Timing experiments only (tools/ubench/build_variants.sh): results are WRONG with any of these.
+#ifdef VF_EXP_NO_A
+#define VF_EXP_A(x) 0
+#else
+#define VF_EXP_A(x) (x)
+#endif
+#ifdef VF_EXP_NO_B
+#define VF_EXP_B(x) 0
+#else
+#define VF_EXP_B(x) (x)
+#endif
+
 namespace vf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -178,6 +190,25 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     const int q4 = KC >> 2;
     const int items = p.NI * tile_px * q4;
 
+    // ---- G == 4 (conv-LSTM, transposed conv): the B operand goes through LDS.  Per tap the
+    // workgroup needs K8 blocks of [4 gates][2 k-halves][32 columns] float4; wave w fetches only
+    // gate w's slice (a quarter of the global loads of the direct path, whose 4 waves each pull
+    // the whole block through L1) one tap ahead, parks it in registers during the tap's MFMAs,
+    // then writes it to the other LDS buffer; one barrier per tap.
+    f32x4 *bsm = reinterpret_cast<f32x4 *>(smem + tile_floats + 4 * p.NI + 16);  // [2][K8][4][64]
+    const float *wgate = p.Wp + ((long long)kh * Ntot + (cg * G + (wave & (G - 1))) * 32 + n) * 4;
+    const int gt0 = ch_begin * ntaps, gtN = ch_end * ntaps;
+    f32x4 breg[4];
+#define VF_LOADB(GT_)                                                                           \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
+        if (q < K8) breg[q] = *reinterpret_cast<const f32x4 *>(wgate + ((long long)(GT_) * K8 + q) * wstep);
+#define VF_WRITEB(BUF_)                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
+        if (q < K8) bsm[(((BUF_) * K8 + q) * 4 + wave) * 64 + lane] = breg[q];
+    if constexpr (G == 4) {
+        if (gt0 < gtN) { VF_LOADB(gt0) }
+    }
+
     for (int ci = ch_begin; ci < ch_end; ++ci) {
         const int s = (ci < p.seg[0].nchunk) ? 0 : 1;
         const auto &sg = p.seg[s];
@@ -185,6 +216,9 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
         const bool vec_ok = (sg.C & 3) == 0;
 
         __syncthreads();        // previous chunk fully consumed (and lnTab visible on entry)
+#ifdef VF_EXP_NO_STAGE
+        if (ci == ch_begin)
+#endif
         for (int it = tid; it < items; it += kConvThreads) {
             const int pix = it / q4, q = it - pix * q4;
             const int img = pix / tile_px, r = pix - img * tile_px;
@@ -221,29 +255,17 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
             }
             *reinterpret_cast<f32x4 *>(&smem[pix * KCpad + 4 * q]) = v;
         }
+        if constexpr (G == 4) {
+            if (ci == ch_begin) { VF_WRITEB(0) }
+        }
         __syncthreads();
 
-        // ---- K loop over (tap, k8), software pipelined: operands of step it+1 are fetched
-        // (A: LDS b128, B: L1/L2 b128 per gate) before the 8*G MFMAs of step it are issued.
-        const float *wchunk = wlane + (long long)ci * ntaps * K8 * wstep;
-        const int nit = ntaps * K8;
         const f32x4 *smem4 = reinterpret_cast<const f32x4 *>(smem);
         int ab4[MREP];                                              // in float4 units
 #pragma unroll
         for (int m = 0; m < MREP; ++m) ab4[m] = abase[m] >> 2;
         const int kcp4 = KCpad >> 2;
-        int ky = 0, kx = 0, k8 = 0;
-
         f32x4 aP[MREP], aQ[MREP], bP[G], bQ[G];
-#define VF_FETCH(A_, B_, IT_)                                                                   \
-        {                                                                                       \
-            const int ao_ = (ky * LW + kx) * kcp4 + k8 * 2;                                     \
-            _Pragma("unroll") for (int m = 0; m < MREP; ++m) A_[m] = smem4[ab4[m] + ao_];      \
-            const float *wp_ = wchunk + (long long)(IT_) * wstep;                               \
-            _Pragma("unroll") for (int g = 0; g < G; ++g)                                       \
-                B_[g] = *reinterpret_cast<const f32x4 *>(wp_ + g * 128);                        \
-            if (++k8 == K8) { k8 = 0; if (++kx == p.KW) { kx = 0; ++ky; } }                     \
-        }
 #define VF_MFMA(A_, B_)                                                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
             _Pragma("unroll") for (int g = 0; g < G; ++g) {                                     \
@@ -251,18 +273,67 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
                     acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m][j], B_[g][j], acc[m][g], 0, 0, 0); \
             }                                                                                   \
         }
-        VF_FETCH(aP, bP, 0)
-        int it = 0;
-        for (; it + 2 <= nit; it += 2) {
-            VF_FETCH(aQ, bQ, it + 1)
-            VF_MFMA(aP, bP)
-            if (it + 2 < nit) VF_FETCH(aP, bP, it + 2)
-            VF_MFMA(aQ, bQ)
-        }
-        if (it < nit) VF_MFMA(aP, bP)
+
+        if constexpr (G == 4) {
+            // ---- K loop, B through LDS: taps outer (one barrier each), k8 inner (ping-pong)
+#define VF_FETCH_L(A_, B_, Q_)                                                                  \
+            {                                                                                   \
+                _Pragma("unroll") for (int m = 0; m < MREP; ++m)                                \
+                    A_[m] = smem4[ab4[m] + VF_EXP_A(ao + (Q_) * 2)];                            \
+                _Pragma("unroll") for (int g = 0; g < G; ++g)                                   \
+                    B_[g] = bsm[((buf * K8 + (Q_)) * 4 + g) * 64 + lane];                       \
+            }
+            for (int ky = 0; ky < p.KH; ++ky) {
+                for (int kx = 0; kx < p.KW; ++kx) {
+                    const int gt = ci * ntaps + ky * p.KW + kx;
+                    const int buf = (gt - gt0) & 1;
+                    const int ao = (ky * LW + kx) * kcp4;
+                    const bool more = gt + 1 < gtN;
+                    if (more) { VF_LOADB(VF_EXP_B(gt + 1)) }
+                    VF_FETCH_L(aP, bP, 0)
+                    int q = 0;
+                    for (; q + 2 <= K8; q += 2) {
+                        VF_FETCH_L(aQ, bQ, q + 1)
+                        VF_MFMA(aP, bP)
+                        if (q + 2 < K8) VF_FETCH_L(aP, bP, q + 2)
+                        VF_MFMA(aQ, bQ)
+                    }
+                    if (q < K8) VF_MFMA(aP, bP)
+                    if (more) { VF_WRITEB(buf ^ 1) }
+                    __syncthreads();
+                }
+            }
+#undef VF_FETCH_L
+        } else {
+            // ---- K loop over (tap, k8), software pipelined: operands of step it+1 are fetched
+            // (A: LDS b128, B: L1/L2 b128) before the MFMAs of step it are issued.
+            const float *wchunk = wlane + (long long)ci * ntaps * K8 * wstep;
+            const int nit = ntaps * K8;
+            int ky = 0, kx = 0, k8 = 0;
+#define VF_FETCH(A_, B_, IT_)                                                                   \
+            {                                                                                   \
+                const int ao_ = (ky * LW + kx) * kcp4 + k8 * 2;                                 \
+                _Pragma("unroll") for (int m = 0; m < MREP; ++m) A_[m] = smem4[ab4[m] + VF_EXP_A(ao_)]; \
+                const float *wp_ = wchunk + (long long)VF_EXP_B(IT_) * wstep;                   \
+                _Pragma("unroll") for (int g = 0; g < G; ++g)                                   \
+                    B_[g] = *reinterpret_cast<const f32x4 *>(wp_ + g * 128);                    \
+                if (++k8 == K8) { k8 = 0; if (++kx == p.KW) { kx = 0; ++ky; } }                 \
+            }
+            VF_FETCH(aP, bP, 0)
+            int it = 0;
+            for (; it + 2 <= nit; it += 2) {
+                VF_FETCH(aQ, bQ, it + 1)
+                VF_MFMA(aP, bP)
+                if (it + 2 < nit) VF_FETCH(aP, bP, it + 2)
+                VF_MFMA(aQ, bQ)
+            }
+            if (it < nit) VF_MFMA(aP, bP)
 #undef VF_FETCH
+        }
 #undef VF_MFMA
     }
+#undef VF_LOADB
+#undef VF_WRITEB
 
     // ------------------------------------------------------------------ epilogue
     const int ch = cg * 32 + n;             // output channel of this lane

@@ -128,7 +128,10 @@ static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 static size_t conv_lds_bytes(const ConvLayer &l, int KC) {
     const int LH = (l.TH - 1) * l.stride + l.KH, LW = (l.TW - 1) * l.stride + l.KW;
-    return ((size_t)l.NI * LH * LW * (KC + 4) + 4 * (size_t)l.NI) * 4 + 64;
+    // A tile + LayerNorm table + reduction scratch (+ for 4-gate layers the double-buffered
+    // per-tap B blocks: 2 x KC/8 x [4 gates][64 lanes] float4)
+    const size_t b_lds = l.G == 4 ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
+    return ((size_t)l.NI * LH * LW * (KC + 4) + 4 * (size_t)l.NI) * 4 + 64 + b_lds;
 }
 
 // choose tile shape and chunk size for a layer whose GEMM row grid is Hout x Wout
@@ -152,7 +155,7 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
     }
     const int maxC = std::max(l.segC[0], l.nseg > 1 ? l.segC[1] : 0);
     int KC = 32;
-    while (KC > 8 && (KC > round_up(maxC, 8) || conv_lds_bytes(l, KC) > 72 * 1024 ||
+    while (KC > 8 && (KC > round_up(maxC, 8) || conv_lds_bytes(l, KC) > 78 * 1024 ||
                       l.segC[0] % KC || (l.nseg > 1 && l.segC[1] % KC)))
         KC >>= 1;
     l.KC = KC;
