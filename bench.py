@@ -194,6 +194,14 @@ def main():
         'host_ms_per_step_outside_predictor': 1e3 * (elapsed - score_time[0]) / args.steps,
         'best_score_last_plan': float(np.min(out['plan_stat']['scores_itr%d' % (iters - 1)])),
     }
+    # HBM traffic cannot be counted from inside the process; it is taken from the committed rocprofv3
+    # PMC run of this same command (tools/pmc_hbm.sh), when one exists for the default workload
+    traffic_file = os.path.join(REPO, 'profiles', 'r01_c_hbm_traffic.json')
+    if (os.path.exists(traffic_file) and getattr(ctrl.predictor, 'persistent', False) and M == 200 and T == 13
+            and iters == 3):
+        with open(traffic_file) as f:
+            result['roofline']['traffic'] = json.load(f)['hbm_bytes_per_launch']
+        result['roofline']['traffic_source'] = 'profiles/r01_c_hbm_traffic.json (rocprofv3 PMC, offline)'
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ctx = {'context_frames': frames, 'context_actions': np.zeros((1, 4)),
                'context_states': states,

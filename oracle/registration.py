@@ -1,0 +1,59 @@
+"""ORACLE (test infrastructure): loop restatement of the reference's registration arithmetic.
+
+Follows ``/root/reference/visual_mpc/policy/cem_controllers/register_gtruth_controller.py``
+``get_warp_err`` :113-173 and the trade-off normalisation of ``register_gtruth`` :88-91, written
+with explicit loops.  PARITY UNPINNED: the reference file cannot be imported (it needs
+``visual_mpc.registration_network`` and two visualizer modules that are not in the snapshot,
+``:4,5,7``) and the reference has no tests, so no golden vector could be minted; this restatement
+is checked against the product's vectorised version only.  One documented deviation from the
+text of the reference: in point mode (``register_region=False``) the reference leaves
+``region_tradeoff = True`` (``:118``) and therefore never fills the warp errors (``:163-170`` is
+dead), which makes every trade-off NaN; both this oracle and the product use the pixel-L2 error of
+``:165-170`` in point mode, which is evidently what was meant.
+"""
+import numpy as np
+
+
+def warp_err_loops(icam, pix_t0, goal_pix, start_image, goal_image, start_warp_pts, goal_warp_pts,
+                   warped_start, warped_goal, register_gtruth, register_region):
+    H, W = start_image.shape[1:3]
+    nreg, ntask = len(register_gtruth), len(pix_t0)
+    errs = np.zeros((ntask, nreg))
+    desig = np.zeros((ntask, nreg, 2))
+    width = 5 if H >= 96 else 2
+    for p in range(ntask):
+        r = 0
+        for name in ('start', 'goal'):
+            if name not in register_gtruth:
+                continue
+            if name == 'start':
+                pix, ref, pts, warped, hi_r, hi_c = pix_t0[p], start_image, start_warp_pts, warped_start, H - 1, W - 1
+            else:
+                pix, ref, pts, warped, hi_r, hi_c = goal_pix[p], goal_image, goal_warp_pts, warped_goal, H, W
+            if register_region:
+                r0, r1 = min(max(pix[0] - width, 0), hi_r), min(max(pix[0] + width + 1, 0), hi_r)
+                c0, c1 = min(max(pix[1] - width, 0), hi_c), min(max(pix[1] + width + 1, 0), hi_c)
+                acc, xs, ys = [], [], []
+                for y in range(r0, r1):
+                    for x in range(c0, c1):
+                        acc.extend(((ref[icam][y, x] - warped[icam][y, x]) ** 2).tolist())
+                        xs.append(pts[icam][y, x, 0]); ys.append(pts[icam][y, x, 1])
+                errs[p, r] = sum(acc) / len(acc)
+                desig[p, r] = (np.median(ys), np.median(xs))
+            else:
+                d = ref[icam][pix[0], pix[1]] - warped[icam][pix[0], pix[1]]
+                errs[p, r] = np.sqrt(np.sum(d * d))
+                desig[p, r] = (pts[icam][pix[0], pix[1], 1], pts[icam][pix[0], pix[1], 0])
+            r += 1
+    return errs, desig
+
+
+def tradeoff_loops(warperrs):
+    ncam, ntask, nreg = warperrs.shape
+    out = np.zeros_like(warperrs)
+    for p in range(ntask):
+        total = sum(1.0 / warperrs[c, p, r] for c in range(ncam) for r in range(nreg))
+        for c in range(ncam):
+            for r in range(nreg):
+                out[c, p, r] = (1.0 / warperrs[c, p, r]) / total
+    return out

@@ -210,3 +210,38 @@ def test_launch_strategies_are_bit_identical():
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             np.testing.assert_array_equal(a, b)
+
+
+def test_two_view_predictor_matches_per_view_oracle():
+    """BASELINE configs[2] shape in miniature: 2 views x 2 designated pixels, one engine per view."""
+    from visual_foresight_amd.video_prediction.multiview_predictor import MultiViewHipPredictor
+    H = W = 32
+    T, M, nd, ncam = 2, 6, 2, 2
+    hp = dict(designated_pixel_count=nd, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,
+              sequence_length=T + 2, ncam=ncam)
+    pred = MultiViewHipPredictor('', hp)
+    cfg = CdnaConfig(height=H, width=W, ndesig=nd, sequence_length=T + 2)
+    weights = [CdnaWeights.random(cfg, seed=10 + c, bias_scale=0.05, ln_jitter=0.1) for c in range(ncam)]
+    pred.restore(weights)
+    rs = np.random.RandomState(77)
+    desig = rs.randint(0, H, (ncam, nd, 2))
+    ctx = {'context_frames': rs.randint(0, 256, (3, ncam, H, W, 3)).astype(np.uint8),
+           'context_actions': rs.normal(0, 0.05, (2, 4)), 'context_states': rs.normal(0, 0.1, (3, 5)),
+           'context_pixel_distributions': pixel_cost.one_hot_distrib(desig, 2, ncam, H, W, nd)}
+    actions = rs.normal(0, 0.1, (M, T, 4))
+    goal = rs.randint(0, H, (ncam, nd, 2))
+    scores, per_task = pred.score(ctx, {'actions': actions}, goal)
+    got = pred(ctx, {'actions': actions})
+    assert got['predicted_frames'].shape == (M, T, ncam, H, W, 3)
+    want_d = []
+    for c in range(ncam):
+        view_ctx = MultiViewHipPredictor._view_context(ctx, c)
+        f, d, s = _oracle(weights[c], view_ctx, actions)
+        assert np.abs(got['predicted_frames'][:, :, c] - f[:, :, 0]).max() <= 1e-5
+        want_d.append(d)
+    want_d = np.concatenate(want_d, axis=2)
+    want, want_pt = pixel_cost.eval_pixel_cost(want_d, goal, 10.)
+    np.testing.assert_allclose(per_task, want_pt, rtol=1e-5)        # camera-major task order
+    np.testing.assert_allclose(scores, want, rtol=1e-5)
+    best = pred.fetch_pixel_distributions(int(np.argmin(scores)))
+    assert best.shape == (T, ncam, H, W, nd)

@@ -19,7 +19,10 @@ import numpy as np
 from .cem_base_controller import CEMBaseController
 
 
-def _default_predictor_class():
+def _default_predictor_class(ncam=1):
+    if ncam > 1:
+        from visual_foresight_amd.video_prediction.multiview_predictor import MultiViewHipPredictor
+        return MultiViewHipPredictor
     from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
     return HipVPredEvaluation
 
@@ -39,7 +42,7 @@ class PixelCostController(CEMBaseController):
         }
         predictor_class = self._hp.predictor_class
         if predictor_class is None:
-            predictor_class = _default_predictor_class()
+            predictor_class = _default_predictor_class(ag_params.get('ncam', 1))
         if getattr(predictor_class, 'wants_agent_params', False):
             # the HIP predictor is shape-specialised at construction (no checkpoint json to read
             # adim/sdim/size/T from), so it is told what the controller will ask of it
@@ -107,6 +110,9 @@ class PixelCostController(CEMBaseController):
                 context, {'actions': actions}, goal_pix=self._goal_pix,
                 finalweight=self._hp.finalweight,
                 only_take_first_view=self._hp.only_take_first_view)
+            weights = self._task_weights()
+            if weights is not None:
+                scores = np.sum(scores_per_task * np.asarray(weights).reshape(1, -1), axis=1)
             self._log_task_scores(scores, scores_per_task)
             if self._hp.predictor_propagation and cem_itr == self._hp.iterations - 1:
                 bestind = scores.argsort()[0]
@@ -120,6 +126,10 @@ class PixelCostController(CEMBaseController):
         if self._verbose_condition(cem_itr):
             self._visualize(cem_itr, scores)
         return scores
+
+    def _task_weights(self):
+        """Per-(camera, designated pixel) score weights, or None for the reference's plain mean."""
+        return None
 
     def _visualize(self, cem_itr, scores):
         """Hook for plan visualisation (the reference renders an HTML/GIF page, :88-131).
@@ -151,7 +161,11 @@ class PixelCostController(CEMBaseController):
         scores_per_task = np.stack(per_task, axis=1)
         if self._hp.only_take_first_view:
             scores_per_task = scores_per_task[:, 0][:, None]
-        scores = np.mean(scores_per_task, axis=1)
+        weights = self._task_weights()
+        if weights is not None:
+            scores = np.sum(scores_per_task * np.asarray(weights).reshape(1, -1), axis=1)
+        else:
+            scores = np.mean(scores_per_task, axis=1)
         self._log_task_scores(scores, scores_per_task)
 
         if self._hp.predictor_propagation and cem_itr == self._hp.iterations - 1:
