@@ -81,14 +81,20 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # one rank per GPU over RCCL; VF_BENCH_BACKEND=gloo lets several ranks share one GPU for dry runs
+    backend = os.environ.get('VF_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(backend)
     if world != args.gpus and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
-    dev = torch.device('cuda', local_rank)
+    dev = torch.device('cuda', dev_index)
 
     from visual_foresight_amd.policy.cem_controllers import PixelCostController
     from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
@@ -162,7 +168,7 @@ def main():
         ctrl.predictor.set_profiling(False)
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -54,7 +54,7 @@ class HipVPredEvaluation(object):
             raise _lib.VfError('HipVPredEvaluation needs a ROCm GPU (no CPU fallback)')
         # one process drives one GPU; under torchrun LOCAL_RANK picks it
         local_rank = int(os.environ.get('LOCAL_RANK', 0)) if _dist_info()[1] > 1 else 0
-        self.device_index = int(first_gpu) + local_rank
+        self.device_index = (int(first_gpu) + local_rank) % max(torch.cuda.device_count(), 1)
         self.device = torch.device('cuda', self.device_index)
         self._libh = _lib.load_library()
         c = self.cfg
@@ -222,7 +222,12 @@ class HipVPredEvaluation(object):
                                                 self._stream()))
         if world > 1:
             import torch.distributed as dist
-            dist.all_reduce(out)        # exactly one rank holds the sample, the others add zeros
+            if dist.get_backend() == 'gloo':
+                host = out.cpu()
+                dist.all_reduce(host)
+                out = host.to(self.device)
+            else:
+                dist.all_reduce(out)    # exactly one rank holds the sample, the others add zeros
         elif not have:
             raise IndexError('sample %d is not resident (last chunk holds [%d, %d))'
                              % (sample_index, self._last_lo, self._last_lo + self._last_M))

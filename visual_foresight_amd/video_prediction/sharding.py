@@ -38,8 +38,12 @@ def all_gather_rows(local, M):
         out = torch.empty((M,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous())
         return out
-    padded = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    padded[:local.shape[0]] = local
+    # gloo gathers host tensors only: stage device rows through the host (tests / single-GPU dry runs)
+    via_host = dist.get_backend() == 'gloo' and local.is_cuda
+    src = local.cpu() if via_host else local
+    padded = torch.zeros((width,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    padded[:src.shape[0]] = src
     bufs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded)
-    return torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0)
+    out = torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0)
+    return out.to(local.device) if via_host else out
