@@ -245,3 +245,27 @@ def test_two_view_predictor_matches_per_view_oracle():
     np.testing.assert_allclose(scores, want, rtol=1e-5)
     best = pred.fetch_pixel_distributions(int(np.argmin(scores)))
     assert best.shape == (T, ncam, H, W, nd)
+
+
+def test_shared_unit_cache_across_rollouts():
+    """The context-only (batch-1) units are computed once per context and reused by later rollouts."""
+    H = W = 32
+    T, M = 3, 21
+    rs = np.random.RandomState(41)
+    ctx_a, ctx_b = _context(H, W, 1, rs), _context(H, W, 1, rs)
+    acts1, acts2 = rs.normal(0, 0.1, (M, T, 4)), rs.normal(0, 0.1, (M, T, 4))
+    goal = np.array([[[5, 9]]])
+    for persistent in (1, 0):
+        pred, _ = _predictor(H, W, T, 1, bs=M)
+        pred.set_persistent(persistent)
+        pred.score(ctx_a, {'actions': acts1}, goal)            # computes and caches the shared units
+        cached, _ = pred.score(ctx_a, {'actions': acts2}, goal)   # reuses them
+        pred.set_dedup(1)                                       # invalidates the cache
+        pred._ctx_key = None
+        fresh, _ = pred.score(ctx_a, {'actions': acts2}, goal)
+        np.testing.assert_array_equal(cached, fresh)
+        other, _ = pred.score(ctx_b, {'actions': acts2}, goal)  # new context: must not reuse
+        ref, _ = _predictor(H, W, T, 1, bs=M)[0].score(ctx_b, {'actions': acts2}, goal)
+        np.testing.assert_array_equal(other, ref)
+        assert not np.array_equal(other, fresh)
+        assert pred.device_status() == 0

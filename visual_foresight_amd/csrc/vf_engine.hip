@@ -281,18 +281,25 @@ struct vf_handle {
     bool persistent = false;
     int n_cu = 256;
     float *actions_buf = nullptr;
-    PhaseDesc *d_phases = nullptr;
+    struct SchedCache {                 // device copy of one schedule + the key it was built for
+        PhaseDesc *d_phases = nullptr;
+        int B = -1, groups = 0, offset = 0, items = 0, counters = 0, phases = 0;
+        bool dedup = true;
+        int32_t goal[2 * kMaxDesig] = {0};
+        double flops = 0.0;
+        size_t lds = 0;
+        std::vector<int> types, nitems;
+    } sched[2];                         // [0]: full rollout, [1]: shared units skipped (cached)
+    int last_sched = 0;
     size_t sched_capacity = 0, counter_capacity = 0;
     int *d_sync = nullptr;              // [ticket, status, counters...]
     unsigned long long *d_stats = nullptr;  // debugging aid (VF_PERSIST_STATS): per-phase wait/run ticks
-    std::vector<int> sched_types, sched_nitems;
-    int sched_B = -1, sched_items = 0, sched_counters = 0, sched_phases = 0;
-    int n_groups = 1, group_offset = 9, sched_groups = 0, sched_offset = 0;
+    int n_groups = 1, group_offset = 9;
     int persist_wgs_per_cu = 2;
-    bool sched_dedup = true;
-    int32_t sched_goal[2 * kMaxDesig] = {0};
-    double sched_flops = 0.0;
-    size_t sched_lds = 0;
+
+    // cross-rollout cache of the shared (batch-1, context-only) units
+    bool cache_shared = true, shared_valid = false;
+    int shared_cfg = -1;
 
     // sub-batch streams (forked from / joined to the caller's stream inside vf_rollout)
     int n_sub = 1;
@@ -532,7 +539,8 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     VF_ALLOC(h->actions_buf, (size_t)Bc * h->T * cfg->adim);
     h->sched_capacity = ((size_t)h->S * 20 + 8) * kMaxSubBatches;
     h->counter_capacity = ((size_t)h->S * 20 + 8) * ((size_t)Bc + kMaxSubBatches);
-    VF_ALLOC(h->d_phases, h->sched_capacity);
+    VF_ALLOC(h->sched[0].d_phases, h->sched_capacity);
+    VF_ALLOC(h->sched[1].d_phases, h->sched_capacity);
     VF_ALLOC(h->d_sync, 2 + h->counter_capacity);
     if (hipMemset(h->d_sync, 0, 2 * sizeof(int)) != hipSuccess) {
         vf_destroy(h);
@@ -634,6 +642,7 @@ int vf_load_weights(vf_handle *h, const float *blob, size_t n_floats) {
         return rc;
     VF_HIP_CHECK(hipDeviceSynchronize());
     h->have_weights = true;
+    h->shared_valid = false;
     return VF_OK;
 }
 
@@ -652,6 +661,7 @@ int vf_set_context(vf_handle *h, const uint8_t *d_frames, const float *d_states,
                        d_ctx_distrib, h->ctx_distrib, n_d);
     VF_HIP_CHECK(hipGetLastError());
     h->have_context = true;
+    h->shared_valid = false;        // the shared units are functions of the context
     return VF_OK;
 }
 
@@ -697,9 +707,12 @@ static BatchView make_view(vf_handle *h, const float *d_actions, int b0) {
 // to a sink, together with the units it depends on.  LaunchSink enqueues one kernel per unit
 // (stream order makes the dependencies implicit); ScheduleSink records the units as phases of
 // the persistent launch (vf_persistent.h) with explicit per-sample dependencies.
+static const int kSkipped = 1 << 30;      // id of a unit whose cached result is reused
+
 struct LaunchSink {
     vf_handle *h;
     hipStream_t st;
+    static int skipped() { return VF_OK; }
 
     int conv(int type, const ConvLayer &l, const ConvParams &p, std::initializer_list<int>) {
         switch (type) {
@@ -758,7 +771,7 @@ struct ScheduleSink {
         next_ticket += n_items; next_counter += counters;
         P.ndep = 0;
         for (int d : deps) {
-            if (d < 0) continue;
+            if (d < 0 || d == kSkipped) continue;
             const PhaseDesc &Q = phases[d];
             PhaseDep &dp = P.dep[P.ndep++];
             dp.cnt_base = Q.cnt_base;
@@ -810,6 +823,7 @@ struct ScheduleSink {
         return add(P, ntiles * p.B, p.B, deps);
     }
     static bool failed(int rc) { return rc < 0; }
+    static int skipped() { return kSkipped; }
 };
 
 // Context de-duplication: while a step's inputs are the context, part of the network sees the
@@ -818,9 +832,13 @@ struct ScheduleSink {
 // enc1, enc2: the per-sample action only enters at enc3).  Those units run once with batch 1
 // into the "shared" buffers and their consumers read them with batch stride 0; the arithmetic
 // per sample is unchanged, so results are bit-identical to the redundant evaluation.
+//
+// The shared units depend only on the context and the weights, so they are also cached ACROSS
+// rollouts: the CEM iterations of one planning call keep the same context, and every rollout
+// after the first skips them (`skip_shared`) and reads the shared buffers of the first.
 template <class Sink>
 static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, int B, const int32_t *goal_pix,
-                        Sink &sink) {
+                        Sink &sink, bool skip_shared) {
     const vf_config &c = h->cfg;
     const int H = h->H, W = h->W, T = h->T, ND = h->ND, nc = c.n_context;
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
@@ -845,6 +863,8 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
 #define VF_EMIT(var, expr)                 \
     const int var = (expr);                \
     if (Sink::failed(var)) return var;
+// a shared unit whose result is still valid from an earlier rollout is not emitted again
+#define VF_EMIT_SH(var, shared, expr) VF_EMIT(var, ((shared) && skip_shared) ? Sink::skipped() : (expr))
 
     int last = -1;      // terminal unit of the previous step
     for (int s = 0; s < h->S; ++s) {
@@ -868,7 +888,7 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
         sp.state_out = produce ? v.states_all + (size_t)t_out * c.sdim : nullptr;
         sp.state_out_bstride = (long long)T * c.sdim;
         sp.sbias = D.sbias;
-        VF_EMIT(u_sa, sink.sa(sp, {last}))
+        VF_EMIT_SH(u_sa, all_sh, sink.sa(sp, {last}))
 
         // ---- encoder
         const float *frame_in; long long frame_bs;
@@ -877,7 +897,7 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
 
         ConvParams p = make_params(h->enc0, BE, plain(frame_in, frame_bs), nullptr);
         p.out = E.enc0_o; p.stats = E.st_enc0;
-        VF_EMIT(u_enc0, sink.conv(PH_CONV_RAW, h->enc0, p, {last}))
+        VF_EMIT_SH(u_enc0, enc_sh, sink.conv(PH_CONV_RAW, h->enc0, p, {last}))
 
         SegArg enc0_n = normed(E.enc0_o, bs(enc_sh, (long long)H2 * W2 * 32), E.st_enc0, h->enc0.stats_nparts,
                                enc_sh, (long long)H2 * W2 * 32, h->d_ln_g[0], h->d_ln_b[0], 32, 1);
@@ -899,41 +919,41 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
             q.cstate_in = I.c_state[k]; q.cin_bstride = bs(in_sh, per);
             return q;
         };
-        VF_EMIT(u_l1, sink.conv(PH_LSTM, h->lstm[0], lstm_params(0, enc0_n), {u_enc0}))
-        VF_EMIT(u_l2, sink.conv(PH_LSTM, h->lstm[1], lstm_params(1, h_normed(0)), {u_l1}))
+        VF_EMIT_SH(u_l1, lstm_shared(0, s), sink.conv(PH_LSTM, h->lstm[0], lstm_params(0, enc0_n), {u_enc0}))
+        VF_EMIT_SH(u_l2, lstm_shared(1, s), sink.conv(PH_LSTM, h->lstm[1], lstm_params(1, h_normed(0)), {u_l1}))
 
         p = make_params(h->enc1, BE, h_normed(1), nullptr);
         p.out = E.enc1_o;
-        VF_EMIT(u_enc1, sink.conv(PH_CONV_RELU, h->enc1, p, {u_l2}))
+        VF_EMIT_SH(u_enc1, enc_sh, sink.conv(PH_CONV_RELU, h->enc1, p, {u_l2}))
 
-        VF_EMIT(u_l3, sink.conv(PH_LSTM, h->lstm[2],
+        VF_EMIT_SH(u_l3, lstm_shared(2, s), sink.conv(PH_LSTM, h->lstm[2],
                                 lstm_params(2, plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]))), {u_enc1}))
-        VF_EMIT(u_l4, sink.conv(PH_LSTM, h->lstm[3], lstm_params(3, h_normed(2)), {u_l3}))
+        VF_EMIT_SH(u_l4, lstm_shared(3, s), sink.conv(PH_LSTM, h->lstm[3], lstm_params(3, h_normed(2)), {u_l3}))
 
         p = make_params(h->enc2, BE, h_normed(3), nullptr);
         p.out = E.enc2_o;
-        VF_EMIT(u_enc2, sink.conv(PH_CONV_RELU, h->enc2, p, {u_l4}))
+        VF_EMIT_SH(u_enc2, enc_sh, sink.conv(PH_CONV_RELU, h->enc2, p, {u_l4}))
 
         p = make_params(h->enc3, BD, plain(E.enc2_o, bs(enc_sh, (long long)H8 * W8 * L[3])), nullptr);
         p.out = D.enc3_o; p.sbias = D.sbias; p.sbias_ld = L[3];
-        VF_EMIT(u_enc3, sink.conv(PH_CONV_RELU, h->enc3, p, {u_enc2, u_sa}))
+        VF_EMIT_SH(u_enc3, all_sh, sink.conv(PH_CONV_RELU, h->enc3, p, {u_enc2, u_sa}))
 
-        VF_EMIT(u_l5, sink.conv(PH_LSTM, h->lstm[4],
+        VF_EMIT_SH(u_l5, lstm_shared(4, s), sink.conv(PH_LSTM, h->lstm[4],
                                 lstm_params(4, plain(D.enc3_o, bs(all_sh, (long long)H8 * W8 * L[3]))), {u_enc3}))
         SegArg h5n = h_normed(4);
 
         // ---- decoder
         p = make_params(h->convt1, BD, h5n, nullptr);
         p.out = D.enc4_o;
-        VF_EMIT(u_t1, sink.conv(PH_CONVT_RELU, h->convt1, p, {u_l5}))
-        VF_EMIT(u_l6, sink.conv(PH_LSTM, h->lstm[5],
+        VF_EMIT_SH(u_t1, all_sh, sink.conv(PH_CONVT_RELU, h->convt1, p, {u_l5}))
+        VF_EMIT_SH(u_l6, lstm_shared(5, s), sink.conv(PH_LSTM, h->lstm[5],
                                 lstm_params(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))), {u_t1}))
 
         SegArg enc1_s = plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]));
         p = make_params(h->convt2, BD, h_normed(5), &enc1_s);
         p.out = D.enc5_o;
-        VF_EMIT(u_t2, sink.conv(PH_CONVT_RELU, h->convt2, p, {u_l6}))
-        VF_EMIT(u_l7, sink.conv(PH_LSTM, h->lstm[6],
+        VF_EMIT_SH(u_t2, all_sh, sink.conv(PH_CONVT_RELU, h->convt2, p, {u_l6}))
+        VF_EMIT_SH(u_l7, lstm_shared(6, s), sink.conv(PH_LSTM, h->lstm[6],
                                 lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))), {u_t2}))
         last = u_l7;
 
@@ -982,6 +1002,7 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
             last = u_comp;
         }
     }
+#undef VF_EMIT_SH
 #undef VF_EMIT
     return VF_OK;
 }
@@ -1001,11 +1022,18 @@ static int zero_shared_state(vf_handle *h, const BatchView &sh, hipStream_t st) 
 }
 
 static int run_steps(vf_handle *h, const BatchView &v, const BatchView &sh, int B, const int32_t *goal_pix,
-                     hipStream_t st) {
-    int rc = zero_shared_state(h, sh, st);
-    if (rc) return rc;
+                     hipStream_t st, bool skip_shared) {
+    if (!skip_shared) {
+        int rc = zero_shared_state(h, sh, st);
+        if (rc) return rc;
+    }
     LaunchSink sink{h, st};
-    return emit_rollout(h, v, sh, B, goal_pix, sink);
+    return emit_rollout(h, v, sh, B, goal_pix, sink, skip_shared);
+}
+
+// Are the shared buffers of configuration `cfg` (launch mode and split) still valid?
+static bool shared_cache_hit(vf_handle *h, int cfg) {
+    return h->dedup && h->cache_shared && h->shared_valid && h->shared_cfg == cfg;
 }
 
 template <int ND, int WPS>
@@ -1035,17 +1063,19 @@ static int launch_persistent_t(vf_handle *h, const Schedule &sc, int grid, size_
 static int run_persistent(vf_handle *h, const float *d_actions, int B, const int32_t *goal_pix, hipStream_t st) {
     int rc;
     // the schedule holds pointers into the handle's own action buffer, so it only depends on
-    // (B, goal pixels) and is rebuilt when those change
+    // (B, goal pixels, options) and is rebuilt when those change
     const size_t act_bytes = (size_t)B * h->T * h->cfg.adim * sizeof(float);
     VF_HIP_CHECK(hipMemcpyAsync(h->actions_buf, d_actions, act_bytes, hipMemcpyDeviceToDevice, st));
     const int ngroups = std::max(1, std::min({h->n_groups, kMaxSubBatches, B / 8}));
-    bool rebuild = h->sched_B != B || h->sched_dedup != h->dedup || h->sched_groups != ngroups ||
-                   h->sched_offset != h->group_offset;
-    for (int d = 0; d < 2 * h->ND; ++d) rebuild = rebuild || h->sched_goal[d] != goal_pix[d];
+    const int cfg = 1000 + ngroups;
+    const bool skip_shared = shared_cache_hit(h, cfg);
+    vf_handle::SchedCache &sc_host = h->sched[skip_shared ? 1 : 0];
+    bool rebuild = sc_host.B != B || sc_host.dedup != h->dedup || sc_host.groups != ngroups ||
+                   sc_host.offset != h->group_offset;
+    for (int d = 0; d < 2 * h->ND; ++d) rebuild = rebuild || sc_host.goal[d] != goal_pix[d];
     if (rebuild) {
         // Sample groups: each group of samples gets its own phase list (own shared buffers, own
-        // counters); the lists are merged with a phase offset so that while one group is in the
-        // narrow 8x8 / 16x16 middle of the network another one is in the wide 32x32 layers.
+        // counters); the lists are merged with a phase offset (tuning knob; 1 group by default).
         std::vector<ScheduleSink> sinks(ngroups);
         int counters = 0;
         double flops = 0.0;
@@ -1054,7 +1084,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
             const int b0 = (int)((long long)B * g / ngroups), b1 = (int)((long long)B * (g + 1) / ngroups);
             sinks[g].next_counter = counters;
             if ((rc = emit_rollout(h, make_view(h, h->actions_buf, b0), h->shared_views[g], b1 - b0, goal_pix,
-                                   sinks[g])) < 0)
+                                   sinks[g], skip_shared)) < 0)
                 return rc;
             counters = sinks[g].next_counter;
             flops += sinks[g].flops;
@@ -1078,22 +1108,24 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
             return fail(VF_ERR_INVALID, "persistent schedule exceeds its preallocated capacity");
         // an earlier rollout may still be reading the device copy
         VF_HIP_CHECK(hipStreamSynchronize(st));
-        VF_HIP_CHECK(hipMemcpy(h->d_phases, merged.data(), merged.size() * sizeof(PhaseDesc),
+        VF_HIP_CHECK(hipMemcpy(sc_host.d_phases, merged.data(), merged.size() * sizeof(PhaseDesc),
                                hipMemcpyHostToDevice));
-        h->sched_B = B; h->sched_dedup = h->dedup; h->sched_groups = ngroups; h->sched_offset = h->group_offset;
-        for (int d = 0; d < 2 * h->ND; ++d) h->sched_goal[d] = goal_pix[d];
-        h->sched_items = ticket; h->sched_counters = counters;
-        h->sched_phases = (int)merged.size();
-        h->sched_types.clear(); h->sched_nitems.clear();
-        for (const PhaseDesc &P : merged) { h->sched_types.push_back(P.type); h->sched_nitems.push_back(P.n_items); }
-        h->sched_flops = flops;
-        h->sched_lds = std::max(max_lds, (size_t)composite_lds_floats<kMaxDesig, 10>() * 4) + 16;
+        sc_host.B = B; sc_host.dedup = h->dedup; sc_host.groups = ngroups; sc_host.offset = h->group_offset;
+        for (int d = 0; d < 2 * h->ND; ++d) sc_host.goal[d] = goal_pix[d];
+        sc_host.items = ticket; sc_host.counters = counters;
+        sc_host.phases = (int)merged.size();
+        sc_host.types.clear(); sc_host.nitems.clear();
+        for (const PhaseDesc &P : merged) { sc_host.types.push_back(P.type); sc_host.nitems.push_back(P.n_items); }
+        sc_host.flops = flops;
+        sc_host.lds = std::max(max_lds, (size_t)composite_lds_floats<kMaxDesig, 10>() * 4) + 16;
     }
-    for (int g = 0; g < ngroups; ++g)
-        if ((rc = zero_shared_state(h, h->shared_views[g], st))) return rc;
-    VF_HIP_CHECK(hipMemsetAsync(h->d_sync, 0, (2 + (size_t)h->sched_counters) * sizeof(int), st));
+    h->last_sched = skip_shared ? 1 : 0;
+    if (!skip_shared)
+        for (int g = 0; g < ngroups; ++g)
+            if ((rc = zero_shared_state(h, h->shared_views[g], st))) return rc;
+    VF_HIP_CHECK(hipMemsetAsync(h->d_sync, 0, (2 + (size_t)sc_host.counters) * sizeof(int), st));
     Schedule sc;
-    sc.phases = h->d_phases; sc.n_phases = h->sched_phases; sc.total_items = h->sched_items;
+    sc.phases = sc_host.d_phases; sc.n_phases = sc_host.phases; sc.total_items = sc_host.items;
     sc.ticket = h->d_sync; sc.status = h->d_sync + 1; sc.counters = h->d_sync + 2;
     sc.stats = nullptr;
     sc.debug_no_fence = getenv("VF_DEBUG_NO_FENCE") ? 1 : 0;
@@ -1108,8 +1140,8 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         sc.stats = h->d_stats;
     }
     // resident workgroups per CU: bounded by the LDS a workgroup needs (160 KiB per CU)
-    const int by_lds = (int)std::max<size_t>(1, (160 * 1024) / h->sched_lds);
-    const int grid = std::min(h->sched_items, h->n_cu * std::min(h->persist_wgs_per_cu, by_lds));
+    const int by_lds = (int)std::max<size_t>(1, (160 * 1024) / sc_host.lds);
+    const int grid = std::min(sc_host.items, h->n_cu * std::min(h->persist_wgs_per_cu, by_lds));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) {
         while (h->ev_pool.size() < h->ev_used + 2) {
@@ -1121,17 +1153,19 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         VF_HIP_CHECK(hipEventRecord(e0, st));
     }
     switch (h->ND) {
-        case 1: rc = launch_persistent_t<1>(h, sc, grid, h->sched_lds, st); break;
-        case 2: rc = launch_persistent_t<2>(h, sc, grid, h->sched_lds, st); break;
-        case 3: rc = launch_persistent_t<3>(h, sc, grid, h->sched_lds, st); break;
-        default: rc = launch_persistent_t<4>(h, sc, grid, h->sched_lds, st); break;
+        case 1: rc = launch_persistent_t<1>(h, sc, grid, sc_host.lds, st); break;
+        case 2: rc = launch_persistent_t<2>(h, sc, grid, sc_host.lds, st); break;
+        case 3: rc = launch_persistent_t<3>(h, sc, grid, sc_host.lds, st); break;
+        default: rc = launch_persistent_t<4>(h, sc, grid, sc_host.lds, st); break;
     }
     if (rc) return rc;
     if (h->profiling) {
         VF_HIP_CHECK(hipEventRecord(e1, st));
         h->ev_used += 2;
-        h->prof_flops += h->sched_flops;
+        h->prof_flops += sc_host.flops;
     }
+    h->shared_valid = h->dedup;
+    h->shared_cfg = cfg;
     return VF_OK;
 }
 
@@ -1155,19 +1189,24 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
     if (h->persistent) {
         if ((rc = run_persistent(h, d_actions, B, goal_pix, st))) return rc;
     } else if (nsub == 1) {
-        if ((rc = run_steps(h, make_view(h, d_actions, 0), h->shared_views[0], B, goal_pix, st))) return rc;
+        const bool skip = shared_cache_hit(h, 1);
+        if ((rc = run_steps(h, make_view(h, d_actions, 0), h->shared_views[0], B, goal_pix, st, skip))) return rc;
+        h->shared_valid = h->dedup; h->shared_cfg = 1;
     } else {
+        const bool skip = shared_cache_hit(h, 100 + nsub);
         VF_HIP_CHECK(hipEventRecord(h->ev_fork, st));
         for (int i = 0; i < nsub; ++i) {
             const int b0 = (int)((long long)B * i / nsub), b1 = (int)((long long)B * (i + 1) / nsub);
             hipStream_t ss = i == 0 ? st : h->sub_streams[i - 1];
             if (i > 0) VF_HIP_CHECK(hipStreamWaitEvent(ss, h->ev_fork, 0));
-            if ((rc = run_steps(h, make_view(h, d_actions, b0), h->shared_views[i], b1 - b0, goal_pix, ss))) return rc;
+            if ((rc = run_steps(h, make_view(h, d_actions, b0), h->shared_views[i], b1 - b0, goal_pix, ss, skip)))
+                return rc;
             if (i > 0) {
                 VF_HIP_CHECK(hipEventRecord(h->ev_join[i - 1], ss));
                 VF_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join[i - 1], 0));
             }
         }
+        h->shared_valid = h->dedup; h->shared_cfg = 100 + nsub;
     }
     hipLaunchKernelGGL(scores_kernel, dim3((B + 63) / 64), dim3(64), 0, st, h->sums, h->sums_step_stride, B,
                        h->T, h->ND, h->ntiles, finalweight, d_scores, d_scores_per_task);
@@ -1199,8 +1238,9 @@ int vf_debug_phase_stats(vf_handle *h, int32_t max_phases, int32_t *types, int32
     if (!h || !h->d_stats) return fail(VF_ERR_INVALID, "no phase statistics (set VF_PERSIST_STATS)");
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
     VF_HIP_CHECK(hipDeviceSynchronize());
-    const int n = std::min<int>(max_phases, h->sched_phases);
-    for (int i = 0; i < n; ++i) { types[i] = h->sched_types[i]; items[i] = h->sched_nitems[i]; }
+    const vf_handle::SchedCache &sc = h->sched[h->last_sched];
+    const int n = std::min<int>(max_phases, sc.phases);
+    for (int i = 0; i < n; ++i) { types[i] = sc.types[i]; items[i] = sc.nitems[i]; }
     VF_HIP_CHECK(hipMemcpy(wait_run, h->d_stats, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return n;
 }
@@ -1208,6 +1248,8 @@ int vf_debug_phase_stats(vf_handle *h, int32_t max_phases, int32_t *types, int32
 int vf_set_dedup(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->dedup = enable != 0;
+    h->shared_valid = false;
+    if (const char *e = getenv("VF_CACHE_SHARED")) h->cache_shared = atoi(e) != 0;
     return VF_OK;
 }
 
