@@ -44,6 +44,9 @@ def parse():
     ap.add_argument('--samples-per-gpu', type=int, default=200)
     ap.add_argument('--horizon', type=int, default=13)
     ap.add_argument('--iterations', type=int, default=3)
+    ap.add_argument('--ncam', type=int, default=1, help='views (BASELINE configs[2] uses 2)')
+    ap.add_argument('--ndesig', type=int, default=1, help='designated pixels per view')
+    ap.add_argument('--selection-frac', type=float, default=0.0)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-samples', type=int, default=128)
@@ -103,10 +106,17 @@ def main():
     T, iters = args.horizon, args.iterations
     M = args.samples_per_gpu * (world if args.scaling == 'weak' else 1)
     ag_params = {'adim': 4, 'sdim': 5, 'image_height': H, 'image_width': W}
+    if args.ncam != 1:
+        ag_params['ncam'] = args.ncam
     # overrides equal to a default raise (reference policy.py:57-58), hence the conditionals
-    policy = {'type': PixelCostController, 'predictor_class': HipVPredEvaluation,
-              'repeat': 1, 'rejection_sampling': False, 'verbose': False,
+    policy = {'type': PixelCostController, 'repeat': 1, 'rejection_sampling': False, 'verbose': False,
               'vpred_batch_size': max(args.samples_per_gpu, 1)}
+    if args.ncam == 1:
+        policy['predictor_class'] = HipVPredEvaluation      # (ncam > 1: the multi-view default)
+    if args.ndesig != 1:
+        policy['designated_pixel_count'] = args.ndesig
+    if args.selection_frac:
+        policy['selection_frac'] = args.selection_frac
     if T != 5:
         policy['nactions'] = T
     if M != 200:
@@ -121,9 +131,11 @@ def main():
 
     # synthetic inputs: identical on every rank
     np.random.seed(0)
-    frames = np.random.RandomState(1).randint(0, 256, (2, 1, H, W, 3)).astype(np.uint8)
+    frames = np.random.RandomState(1).randint(0, 256, (2, args.ncam, H, W, 3)).astype(np.uint8)
     states = np.random.RandomState(2).normal(0, .1, (2, 5))
-    desig, goal = [[32, 32]], [[16, 48]]
+    npix = args.ncam * args.ndesig
+    desig = [[32 - 3 * i, 32 + 2 * i] for i in range(npix)]
+    goal = [[16 + 2 * i, 48 - 3 * i] for i in range(npix)]
 
     def plan():
         return ctrl.act(t=1, i_tr=0, desig_pix=desig, goal_pix=goal, images=frames, state=states)
@@ -157,22 +169,23 @@ def main():
         for _ in range(args.warmup):
             plan()
         score_time[0] = 0.0
-        ctrl.predictor.set_profiling(True)
+        prof_pred = ctrl.predictor.views[0] if hasattr(ctrl.predictor, 'views') else ctrl.predictor
+        prof_pred.set_profiling(True)
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = plan()
         sync()
         elapsed = time.perf_counter() - t0
-        kernel_ms, launches, flops, busy_ms = ctrl.predictor.get_profile()
-        ctrl.predictor.set_profiling(False)
+        kernel_ms, launches, flops, busy_ms = prof_pred.get_profile()
+        prof_pred.set_profiling(False)
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    frames_per_s = M * T * iters * args.steps / elapsed
+    frames_per_s = M * T * args.ncam * iters * args.steps / elapsed
     result = {
         'metric': 'predicted frames/sec (whole node), 200-sample x 13-step x 64x64 CEM',
         'value': frames_per_s, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
@@ -183,11 +196,12 @@ def main():
         'config': {'workload': 'BASELINE configs[1]: CDNA predictor, %d samples/GPU x horizon %d x %dx%d, '
                                '%d CEM iters, pixel-distance cost, random-init weights' %
                                (args.samples_per_gpu, T, H, W, iters),
-                   'num_samples': M, 'horizon': T, 'iterations': iters, 'sharding': 'samples over %d rank(s)' % world},
+                   'num_samples': M, 'horizon': T, 'iterations': iters, 'views': args.ncam,
+                   'designated_pixels_per_view': args.ndesig, 'sharding': 'samples over %d rank(s)' % world},
         'roofline': {'bound': 'mfma',
                      'kernel': ('rollout_persistent_kernel (one launch per rollout: every conv-LSTM / conv / '
                                 'transposed-conv / FC tile of all steps; FLOPs = algorithmic MFMA work of the launch)'
-                                if getattr(ctrl.predictor, 'persistent', False) else
+                                if getattr(prof_pred, 'persistent', False) else
                                 'conv_mfma_kernel<4,EPI_LSTM> (fused conv-LSTM gate GEMM, one launch per layer per step)'),
                      'achieved': flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else None,
                      'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -195,7 +209,7 @@ def main():
                      'traffic': None, 'launches': launches,
                      'avg_launch_us': 1e3 * kernel_ms / max(launches, 1),
                      'busy_ms': busy_ms, 'achieved_while_busy': flops / (busy_ms * 1e-3) / 1e12 if busy_ms > 0 else None,
-                     'substreams': ctrl.predictor.substreams,
+                     'substreams': prof_pred.substreams,
                      'kernel_time_share': busy_ms * 1e-3 / elapsed},
         'host_ms_per_step_outside_predictor': 1e3 * (elapsed - score_time[0]) / args.steps,
         'best_score_last_plan': float(np.min(out['plan_stat']['scores_itr%d' % (iters - 1)])),
@@ -203,17 +217,18 @@ def main():
     # HBM traffic cannot be counted from inside the process; it is taken from the committed rocprofv3
     # PMC run of this same command (tools/pmc_hbm.sh), when one exists for the default workload
     traffic_file = os.path.join(REPO, 'profiles', 'r01_c_hbm_traffic.json')
-    if (os.path.exists(traffic_file) and getattr(ctrl.predictor, 'persistent', False) and M == 200 and T == 13
-            and iters == 3):
+    if (os.path.exists(traffic_file) and getattr(prof_pred, 'persistent', False) and M == 200 and T == 13
+            and iters == 3 and npix == 1):
         with open(traffic_file) as f:
             result['roofline']['traffic'] = json.load(f)['hbm_bytes_per_launch']
         result['roofline']['traffic_source'] = 'profiles/r01_c_hbm_traffic.json (rocprofv3 PMC, offline)'
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        ctx = {'context_frames': frames, 'context_actions': np.zeros((1, 4)),
+        ctx = {'context_frames': frames[:, :1], 'context_actions': np.zeros((1, 4)),
                'context_states': states,
-               'context_pixel_distributions': ctrl._switch_on_pix(np.array(desig).reshape(1, 1, 2))}
+               'context_pixel_distributions': ctrl._switch_on_pix(
+                   np.array(desig).reshape(args.ncam, args.ndesig, 2))[:, :1]}
         acts = np.random.RandomState(3).normal(0, 0.05, (args.cpu_samples, T, 4))
-        result['cpu_baseline'] = cpu_baseline(ctrl.predictor.weights, ctx, acts, np.array(goal).reshape(1, 1, 2))
+        result['cpu_baseline'] = cpu_baseline(prof_pred.weights, ctx, acts, np.array(goal[:args.ndesig]).reshape(1, -1, 2))
     elif rank == 0:
         result['cpu_baseline'] = None
     if rank == 0:
