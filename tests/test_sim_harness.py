@@ -1,0 +1,55 @@
+"""The rollout harness drives a reference-shaped config end to end (CPU: fake predictor)."""
+import contextlib
+import io
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from tests.helpers.fake_predictor import make_fake_predictor_class
+from visual_foresight_amd.policy.cem_controllers import PixelCostController
+from visual_foresight_amd.sim import Sim, SyntheticAgent, SyntheticPushEnv
+
+
+def _config(tmp_path, predictor_class, T_plan=5, steps=5):
+    agent = {'type': SyntheticAgent, 'env': (SyntheticPushEnv, {'seed': 3}), 'data_save_dir': str(tmp_path),
+             'T': steps, 'image_height': 16, 'image_width': 16}
+    policy = {'type': PixelCostController, 'predictor_class': predictor_class, 'replan_interval': 3,
+              'num_samples': 24, 'rejection_sampling': False, 'repeat': 1, 'verbose': False}
+    return {'agent': agent, 'policy': policy, 'start_index': 0, 'end_index': 1, 'save_data': True,
+            'save_raw_images': True, 'ngroup': 1000}
+
+
+def test_sim_runs_and_writes_reference_layout(tmp_path):
+    cfg = _config(tmp_path, make_fake_predictor_class(5, 16, 16))
+    np.random.seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        results = Sim(cfg).run()
+    assert len(results) == 2 and all('final_goal_distance' in r for r in results)
+    traj = os.path.join(str(tmp_path), 'train', 'traj_group0', 'traj1')
+    for name in ('agent_data.pkl', 'obs_dict.pkl', 'policy_out.pkl'):
+        assert os.path.exists(os.path.join(traj, name))
+    policy_out = pickle.load(open(os.path.join(traj, 'policy_out.pkl'), 'rb'))
+    assert len(policy_out) == 5
+    assert policy_out[0]['actions'].shape == (4,) and np.all(policy_out[0]['actions'] == 0)   # t < start_planning
+    assert 'scores_itr2' in policy_out[1]['plan_stat']
+    obs = pickle.load(open(os.path.join(traj, 'obs_dict.pkl'), 'rb'))
+    assert obs['state'].shape == (6, 5) and 'images' not in obs
+    assert np.load(os.path.join(traj, 'images0', 'im_5.npy')).shape == (16, 16, 3)
+
+
+@pytest.mark.gpu
+def test_sim_with_hip_predictor_and_propagation(tmp_path):
+    cfg = _config(tmp_path, None, steps=4)
+    cfg['agent'].update(image_height=32, image_width=32)
+    cfg['policy'].pop('predictor_class')
+    cfg['policy'].update(predictor_propagation=True, replan_interval=2, nactions=4, iterations=2)
+    cfg['end_index'] = 0
+    np.random.seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim = Sim(cfg)
+        sim.run()
+    chosen = sim.policy._chosen_distrib
+    assert chosen.shape == (4, 1, 32, 32, 1)
+    np.testing.assert_allclose(chosen.sum(axis=(2, 3)), 1.0, atol=1e-5)

@@ -1,0 +1,104 @@
+"""Rollout harness with the reference's calling convention and on-disk layout.
+
+Mirrors the parts of ``visual_mpc/sim/simulator.py`` (``Sim`` :10-93) and
+``visual_mpc/agent/general_agent.py`` (``rollout`` :174-228) that the planner interacts with, so a
+config dict shaped like the reference's ``experiments/**/hparams.py`` (``{'agent': {...},
+'policy': {'type': ..., ...}, ...}``) drives the planner end to end without MuJoCo:
+
+* the policy is built as ``config['policy']['type'](agent_hyperparams, config['policy'], gpu_id, ngpu)``
+  (reference ``simulator.py:21``) and ``reset()`` before every trajectory (``:47``);
+* every step calls ``policy.act(**get_policy_args(policy, obs, t, i_tr, agent_data))`` with the growing
+  history ``obs = {'images': [t+1, ncam, H, W, 3], 'state': [t+1, sdim]}`` (``general_agent.py:196-206``);
+* ``save_raw_images`` writes ``traj_group{g}/traj{i}/{agent_data,obs_dict,policy_out}.pkl`` plus the
+  frames (``simulator.py:64-93``; frames as ``.npy`` - there is no image codec in this stack).
+"""
+import os
+import pickle as pkl
+import shutil
+
+import numpy as np
+
+from visual_foresight_amd.policy.policy import get_policy_args
+from .synthetic_env import SyntheticPushEnv
+
+
+class SyntheticAgent(object):
+    """``agent = {'type': SyntheticAgent, 'env': (EnvClass, env_params), 'T': ..., 'image_height': ...}``"""
+
+    def __init__(self, hyperparams):
+        self._hyperparams = hyperparams
+        env_class, env_params = hyperparams.get('env', (SyntheticPushEnv, {}))
+        env_params = dict(env_params, height=hyperparams['image_height'], width=hyperparams['image_width'],
+                          ncam=hyperparams.get('ncam', 1), adim=hyperparams.get('adim', 4),
+                          sdim=hyperparams.get('sdim', 5))
+        self.env = env_class(**env_params)
+        self._hyperparams.setdefault('adim', self.env.adim)
+        self._hyperparams.setdefault('sdim', self.env.sdim)
+        self.T = hyperparams['T']
+
+    def sample(self, policy, i_tr):
+        return self.rollout(policy, i_tr)
+
+    def rollout(self, policy, i_tr):
+        obs = self.env.reset()
+        history = {'images': [obs['images']], 'state': [obs['state']]}
+        agent_data = {'traj_ok': True}
+        policy_outs = []
+        for t in range(self.T):
+            agent_data['desig_pix'] = self.env.get_desig_pix()
+            agent_data['goal_pix'] = self.env.get_goal_pix()
+            agent_data['verbose_worker'] = None
+            obs_hist = {k: np.stack(v, 0) for k, v in history.items()}
+            pi_t = policy.act(**get_policy_args(policy, obs_hist, t, i_tr, agent_data))
+            policy_outs.append(pi_t)
+            obs = self.env.step(pi_t['actions'])
+            history['images'].append(obs['images'])
+            history['state'].append(obs['state'])
+        agent_data['final_goal_distance'] = self.env.goal_distance()
+        agent_data.pop('verbose_worker')
+        return agent_data, {k: np.stack(v, 0) for k, v in history.items()}, policy_outs
+
+    def cleanup(self):
+        pass
+
+
+class Sim(object):
+    def __init__(self, config, gpu_id=0, ngpu=1, logger=None, task_mode='train'):
+        self._hyperparams = config
+        self.agent = config['agent']['type'](config['agent'])
+        self.agentparams = config['agent']
+        self.policyparams = config['policy']
+        self.agentparams['gpu_id'] = gpu_id
+        self.policy = config['policy']['type'](self.agent._hyperparams, config['policy'], gpu_id, ngpu)
+        self.task_mode = task_mode
+
+    def run(self):
+        results = []
+        for i in range(self._hyperparams['start_index'], self._hyperparams['end_index'] + 1):
+            results.append(self.take_sample(i))
+        self.agent.cleanup()
+        return results
+
+    def take_sample(self, sample_index):
+        self.policy.reset()
+        agent_data, obs_dict, policy_out = self.agent.sample(self.policy, sample_index)
+        if self._hyperparams.get('save_data', True) and self._hyperparams.get('save_raw_images', False):
+            self._save_raw_data(sample_index, agent_data, obs_dict, policy_out)
+        return agent_data
+
+    def _save_raw_data(self, itr, agent_data, obs_dict, policy_outputs):
+        group = itr // self._hyperparams.get('ngroup', 1000)
+        traj = os.path.join(self.agentparams['data_save_dir'], self.task_mode, 'traj_group%d' % group,
+                            'traj%d' % itr)
+        if os.path.exists(traj):
+            shutil.rmtree(traj)
+        os.makedirs(traj)
+        obs_dict = dict(obs_dict)
+        images = obs_dict.pop('images')
+        for c in range(images.shape[1]):
+            os.mkdir(os.path.join(traj, 'images%d' % c))
+            for t in range(images.shape[0]):
+                np.save(os.path.join(traj, 'images%d' % c, 'im_%d.npy' % t), images[t, c])
+        for name, obj in (('agent_data', agent_data), ('obs_dict', obs_dict), ('policy_out', policy_outputs)):
+            with open(os.path.join(traj, name + '.pkl'), 'wb') as f:
+                pkl.dump(obj, f)
