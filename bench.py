@@ -14,10 +14,12 @@ x 64x64, pixel-distance cost, random-init CDNA predictor, synthetic context fram
 sharded by sample, one RCCL all-gather of the score rows per iteration).
 
 Prints ONE JSON line on rank 0: ``value`` = predicted frames / second over the whole job
-(M * T * iterations * K / wall), plus CEM iterations / second, the roofline of the dominant
-kernel (fused conv-LSTM gate GEMM; fp32 MFMA bound) measured with HIP events on the launch
-stream, and the CPU baseline (the oracle restatement timed on the host cores on a bounded
-sample; rank 0, N=1 only).
+(M * T * views * iterations * K / wall) in the PRIMARY precision mode - exact fp32 MFMA - plus CEM
+iterations / second, the roofline of the dominant kernel measured with HIP events on the launch
+stream, and the CPU baseline (the oracle restatement timed on the host cores on a bounded sample;
+rank 0, N=1 only).  ``alt_precision`` repeats the timed loop with the conv-LSTM GEMMs in the
+split-bf16 mode (six bf16 MFMA products per multiply, fp32 accumulate, fp32-class accuracy; see
+csrc/vf_conv_bf16x6.h) and says whether it selected the same elites.
 """
 import argparse
 import contextlib
@@ -34,6 +36,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: dense bf16 MFMA
 
 
 def parse():
@@ -48,6 +51,9 @@ def parse():
     ap.add_argument('--ndesig', type=int, default=1, help='designated pixels per view')
     ap.add_argument('--selection-frac', type=float, default=0.0)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--precision', choices=('fp32', 'bf16x6'), default=os.environ.get('VF_PRECISION', 'fp32'),
+                    help='primary precision mode (the other one is reported as alt_precision)')
+    ap.add_argument('--no-alt', action='store_true', help='skip the alt_precision measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-samples', type=int, default=128)
     return ap.parse_args()
@@ -76,166 +82,212 @@ def cpu_baseline(weights, ctx, actions, goal):
                       % (actions.shape[0], T, dt)}
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
+class Bench(object):
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.args, self.torch, self.dist = args, torch, dist
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        # one rank per GPU over RCCL; VF_BENCH_BACKEND=gloo lets several ranks share one GPU for dry runs
+        self.backend = os.environ.get('VF_BENCH_BACKEND', 'nccl')
+        dev_index = local_rank % max(torch.cuda.device_count(), 1)
+        if self.world > 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            torch.cuda.set_device(dev_index)
+            if self.backend == 'nccl':
+                dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+            else:
+                dist.init_process_group(self.backend)
+        if self.world != args.gpus and self.rank == 0:
+            print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, self.world), file=sys.stderr)
+        self.dev = torch.device('cuda', dev_index)
+        self.H = self.W = 64
+        self.M = args.samples_per_gpu * (self.world if args.scaling == 'weak' else 1)
+        # synthetic inputs: identical on every rank
+        self.frames = np.random.RandomState(1).randint(0, 256, (2, args.ncam, self.H, self.W, 3)).astype(np.uint8)
+        self.states = np.random.RandomState(2).normal(0, .1, (2, 5))
+        npix = args.ncam * args.ndesig
+        self.desig = [[32 - 3 * i, 32 + 2 * i] for i in range(npix)]
+        self.goal = [[16 + 2 * i, 48 - 3 * i] for i in range(npix)]
+        # The sampler's 52x52 SVD / covariance refits are tiny: BLAS worker threads only add wake-up
+        # latency there (several ms per CEM iteration on a 256-core host), so host math runs on 1 thread.
+        # (a fresh guard per measurement: a threadpool_limits object restores the old limits on exit)
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    # one rank per GPU over RCCL; VF_BENCH_BACKEND=gloo lets several ranks share one GPU for dry runs
-    backend = os.environ.get('VF_BENCH_BACKEND', 'nccl')
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(dev_index)
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
-        else:
-            dist.init_process_group(backend)
-    if world != args.gpus and rank == 0:
-        print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
-    dev = torch.device('cuda', dev_index)
+    @staticmethod
+    def blas_guard():
+        try:
+            from threadpoolctl import threadpool_limits
+            return threadpool_limits(limits=1, user_api='blas')
+        except ImportError:
+            return contextlib.nullcontext()
 
-    from visual_foresight_amd.policy.cem_controllers import PixelCostController
-    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+    def sync(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
 
-    H = W = 64
-    T, iters = args.horizon, args.iterations
-    M = args.samples_per_gpu * (world if args.scaling == 'weak' else 1)
-    ag_params = {'adim': 4, 'sdim': 5, 'image_height': H, 'image_width': W}
-    if args.ncam != 1:
-        ag_params['ncam'] = args.ncam
-    # overrides equal to a default raise (reference policy.py:57-58), hence the conditionals
-    policy = {'type': PixelCostController, 'repeat': 1, 'rejection_sampling': False, 'verbose': False,
-              'vpred_batch_size': max(args.samples_per_gpu, 1)}
-    if args.ncam == 1:
-        policy['predictor_class'] = HipVPredEvaluation      # (ncam > 1: the multi-view default)
-    if args.ndesig != 1:
-        policy['designated_pixel_count'] = args.ndesig
-    if args.selection_frac:
-        policy['selection_frac'] = args.selection_frac
-    if T != 5:
-        policy['nactions'] = T
-    if M != 200:
-        policy['num_samples'] = M
-    if iters != 3:
-        policy['iterations'] = iters
-    if policy['vpred_batch_size'] == 200:
-        policy.pop('vpred_batch_size')
-    with contextlib.redirect_stdout(io.StringIO()):
-        ctrl = PixelCostController(ag_params, policy, 0, 1)
-        ctrl.reset()
+    def build_controller(self, precision):
+        from visual_foresight_amd.policy.cem_controllers import PixelCostController
+        from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+        a = self.args
+        ag_params = {'adim': 4, 'sdim': 5, 'image_height': self.H, 'image_width': self.W}
+        if a.ncam != 1:
+            ag_params['ncam'] = a.ncam
+        # overrides equal to a default raise (reference policy.py:57-58), hence the conditionals
+        policy = {'type': PixelCostController, 'repeat': 1, 'rejection_sampling': False, 'verbose': False}
+        if a.ncam == 1:
+            policy['predictor_class'] = HipVPredEvaluation      # (ncam > 1: the multi-view default)
+        if a.samples_per_gpu != 200:
+            policy['vpred_batch_size'] = max(a.samples_per_gpu, 1)
+        if a.ndesig != 1:
+            policy['designated_pixel_count'] = a.ndesig
+        if a.selection_frac:
+            policy['selection_frac'] = a.selection_frac
+        if a.horizon != 5:
+            policy['nactions'] = a.horizon
+        if self.M != 200:
+            policy['num_samples'] = self.M
+        if a.iterations != 3:
+            policy['iterations'] = a.iterations
+        os.environ['VF_PRECISION'] = precision      # read by HipVPredEvaluation (also inside multi-view)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ctrl = PixelCostController(ag_params, policy, 0, 1)
+            ctrl.reset()
+        return ctrl
 
-    # synthetic inputs: identical on every rank
-    np.random.seed(0)
-    frames = np.random.RandomState(1).randint(0, 256, (2, args.ncam, H, W, 3)).astype(np.uint8)
-    states = np.random.RandomState(2).normal(0, .1, (2, 5))
-    npix = args.ncam * args.ndesig
-    desig = [[32 - 3 * i, 32 + 2 * i] for i in range(npix)]
-    goal = [[16 + 2 * i, 48 - 3 * i] for i in range(npix)]
-
-    def plan():
-        return ctrl.act(t=1, i_tr=0, desig_pix=desig, goal_pix=goal, images=frames, state=states)
-
-    def sync():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    # The sampler's 52x52 SVD / covariance refits are tiny: BLAS worker threads only add wake-up
-    # latency there (several ms per CEM iteration on a 256-core host), so host math runs on 1 thread.
-    try:
-        from threadpoolctl import threadpool_limits
-        blas_guard = threadpool_limits(limits=1, user_api='blas')
-    except ImportError:
-        blas_guard = contextlib.nullcontext()
-
-    score_time = [0.0]
-    inner_score = ctrl.predictor.score
-
-    def timed_score(*a, **k):
-        t = time.perf_counter()
-        out = inner_score(*a, **k)
-        score_time[0] += time.perf_counter() - t
-        return out
-    ctrl.predictor.score = timed_score
-
-    with contextlib.redirect_stdout(io.StringIO()), blas_guard:
-        ctrl.act(t=0, i_tr=0, desig_pix=desig, goal_pix=goal, images=frames[:1], state=states[:1])
-        for _ in range(args.warmup):
-            plan()
-        score_time[0] = 0.0
+    def measure(self, precision):
+        """Warm up, then time exactly --steps planning calls.  Returns the raw measurements."""
+        a, torch = self.args, self.torch
+        ctrl = self.build_controller(precision)
         prof_pred = ctrl.predictor.views[0] if hasattr(ctrl.predictor, 'views') else ctrl.predictor
-        prof_pred.set_profiling(True)
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = plan()
-        sync()
-        elapsed = time.perf_counter() - t0
-        kernel_ms, launches, flops, busy_ms = prof_pred.get_profile()
-        prof_pred.set_profiling(False)
+        score_time = [0.0]
+        inner_score = ctrl.predictor.score
 
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        def timed_score(*args_, **kw):
+            t = time.perf_counter()
+            out = inner_score(*args_, **kw)
+            score_time[0] += time.perf_counter() - t
+            return out
+        ctrl.predictor.score = timed_score
 
-    frames_per_s = M * T * args.ncam * iters * args.steps / elapsed
-    result = {
-        'metric': 'predicted frames/sec (whole node), 200-sample x 13-step x 64x64 CEM',
-        'value': frames_per_s, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-        'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
-        'data': 'synthetic',
-        'cem_iters_per_sec': iters * args.steps / elapsed,
-        'config': {'workload': 'BASELINE configs[1]: CDNA predictor, %d samples/GPU x horizon %d x %dx%d, '
-                               '%d CEM iters, pixel-distance cost, random-init weights' %
-                               (args.samples_per_gpu, T, H, W, iters),
-                   'num_samples': M, 'horizon': T, 'iterations': iters, 'views': args.ncam,
-                   'designated_pixels_per_view': args.ndesig, 'sharding': 'samples over %d rank(s)' % world},
-        'roofline': {'bound': 'mfma',
-                     'kernel': ('rollout_persistent_kernel (one launch per rollout: every conv-LSTM / conv / '
-                                'transposed-conv / FC tile of all steps; FLOPs = algorithmic MFMA work of the launch)'
-                                if getattr(prof_pred, 'persistent', False) else
-                                'conv_mfma_kernel<4,EPI_LSTM> (fused conv-LSTM gate GEMM, one launch per layer per step)'),
-                     'achieved': flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else None,
-                     'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': (flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if kernel_ms > 0 else None,
-                     'traffic': None, 'launches': launches,
-                     'avg_launch_us': 1e3 * kernel_ms / max(launches, 1),
-                     'busy_ms': busy_ms, 'achieved_while_busy': flops / (busy_ms * 1e-3) / 1e12 if busy_ms > 0 else None,
-                     'substreams': prof_pred.substreams,
-                     'kernel_time_share': busy_ms * 1e-3 / elapsed},
-        'host_ms_per_step_outside_predictor': 1e3 * (elapsed - score_time[0]) / args.steps,
-        'best_score_last_plan': float(np.min(out['plan_stat']['scores_itr%d' % (iters - 1)])),
-    }
-    # HBM traffic cannot be counted from inside the process; it is taken from the committed rocprofv3
-    # PMC run of this same command (tools/pmc_hbm.sh), when one exists for the default workload
-    traffic_file = os.path.join(REPO, 'profiles', 'r01_c_hbm_traffic.json')
-    if (os.path.exists(traffic_file) and getattr(prof_pred, 'persistent', False) and M == 200 and T == 13
-            and iters == 3 and npix == 1):
-        with open(traffic_file) as f:
-            result['roofline']['traffic'] = json.load(f)['hbm_bytes_per_launch']
-        result['roofline']['traffic_source'] = 'profiles/r01_c_hbm_traffic.json (rocprofv3 PMC, offline)'
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        ctx = {'context_frames': frames[:, :1], 'context_actions': np.zeros((1, 4)),
-               'context_states': states,
-               'context_pixel_distributions': ctrl._switch_on_pix(
-                   np.array(desig).reshape(args.ncam, args.ndesig, 2))[:, :1]}
-        acts = np.random.RandomState(3).normal(0, 0.05, (args.cpu_samples, T, 4))
-        result['cpu_baseline'] = cpu_baseline(prof_pred.weights, ctx, acts, np.array(goal[:args.ndesig]).reshape(1, -1, 2))
-    elif rank == 0:
-        result['cpu_baseline'] = None
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
+        def plan():
+            return ctrl.act(t=1, i_tr=0, desig_pix=self.desig, goal_pix=self.goal, images=self.frames,
+                            state=self.states)
+
+        np.random.seed(0)       # same candidate stream for every rank and every precision mode
+        with contextlib.redirect_stdout(io.StringIO()), self.blas_guard():
+            ctrl.act(t=0, i_tr=0, desig_pix=self.desig, goal_pix=self.goal, images=self.frames[:1],
+                     state=self.states[:1])
+            for _ in range(a.warmup):
+                plan()
+            score_time[0] = 0.0
+            prof_pred.set_profiling(True)
+            self.sync()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                out = plan()
+            self.sync()
+            elapsed = time.perf_counter() - t0
+            kernel_ms, launches, flops, busy_ms = prof_pred.get_profile()
+            prof_pred.set_profiling(False)
+        if self.world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == 'nccl' else 'cpu')
+            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return dict(ctrl=ctrl, prof_pred=prof_pred, elapsed=elapsed, kernel_ms=kernel_ms, launches=launches,
+                    flops=flops, busy_ms=busy_ms, host_ms=1e3 * (elapsed - score_time[0]) / a.steps,
+                    elites=[int(i) for i in ctrl._best_indices],
+                    best=float(np.min(out['plan_stat']['scores_itr%d' % (a.iterations - 1)])))
+
+    def roofline(self, m, precision):
+        persistent = getattr(m['prof_pred'], 'persistent', False)
+        tf = m['flops'] / (m['kernel_ms'] * 1e-3) / 1e12 if m['kernel_ms'] > 0 else None
+        r = {'bound': 'mfma',
+             'kernel': ('rollout_persistent_kernel (one launch per rollout: every conv-LSTM / conv / '
+                        'transposed-conv / FC tile of all steps; FLOPs = algorithmic MFMA work of the launch)'
+                        if persistent else
+                        'conv_mfma_kernel<4,EPI_LSTM> (fused conv-LSTM gate GEMM, one launch per layer per step)'),
+             'achieved': tf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+             'frac': tf / PEAK_FP32_MFMA_TFLOPS if tf else None, 'traffic': None,
+             'launches': m['launches'], 'avg_launch_us': 1e3 * m['kernel_ms'] / max(m['launches'], 1),
+             'kernel_time_share': m['busy_ms'] * 1e-3 / m['elapsed']}
+        if precision == 'bf16x6':
+            # the same algorithmic (fp32-equivalent) FLOPs cost six bf16 MFMA FLOPs each in the
+            # conv-LSTM tiles; quote that rate against the bf16 MFMA peak as well
+            r['note'] = ('achieved/peak/frac are fp32-EQUIVALENT algorithmic FLOP/s against the fp32 MFMA peak; '
+                         'the conv-LSTM tiles execute 6 bf16 MFMA FLOPs per algorithmic FLOP')
+            r['bf16_mfma_tflops'] = 6.0 * tf if tf else None
+            r['bf16_mfma_frac_of_peak'] = 6.0 * tf / PEAK_BF16_MFMA_TFLOPS if tf else None
+        return r
+
+    def run(self):
+        a = self.args
+        T, iters = a.horizon, a.iterations
+        primary = a.precision
+        m = self.measure(primary)
+        frames_total = self.M * T * a.ncam * iters * a.steps
+        result = {
+            'metric': 'predicted frames/sec (whole node), 200-sample x 13-step x 64x64 CEM',
+            'value': frames_total / m['elapsed'], 'unit': 'frames/s', 'n_gpus': self.world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': 1e3 * m['elapsed'] / a.steps,
+            'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
+            'dtype': 'f32' if primary == 'fp32' else 'f32 emulated by 6 bf16 MFMA products (fp32 accumulate)',
+            'data': 'synthetic',
+            'cem_iters_per_sec': iters * a.steps / m['elapsed'],
+            'config': {'workload': 'BASELINE configs[1]: CDNA predictor, %d samples/GPU x horizon %d x %dx%d, '
+                                   '%d CEM iters, pixel-distance cost, random-init weights' %
+                                   (a.samples_per_gpu, T, self.H, self.W, iters),
+                       'num_samples': self.M, 'horizon': T, 'iterations': iters, 'views': a.ncam,
+                       'designated_pixels_per_view': a.ndesig, 'precision': primary,
+                       'sharding': 'samples over %d rank(s)' % self.world},
+            'roofline': self.roofline(m, primary),
+            'host_ms_per_step_outside_predictor': m['host_ms'],
+            'best_score_last_plan': m['best'],
+        }
+        # HBM traffic cannot be counted from inside the process; it is taken from the committed rocprofv3
+        # PMC run of this same command (tools/pmc_hbm.sh), when one exists for the default workload
+        traffic_file = os.path.join(REPO, 'profiles', 'r01_c_hbm_traffic.json')
+        if (os.path.exists(traffic_file) and getattr(m['prof_pred'], 'persistent', False) and self.M == 200
+                and T == 13 and iters == 3 and a.ncam * a.ndesig == 1 and primary == 'fp32'):
+            with open(traffic_file) as f:
+                result['roofline']['traffic'] = json.load(f)['hbm_bytes_per_launch']
+            result['roofline']['traffic_source'] = 'profiles/r01_c_hbm_traffic.json (rocprofv3 PMC, offline)'
+
+        if not a.no_alt:
+            other = 'bf16x6' if primary == 'fp32' else 'fp32'
+            am = self.measure(other)
+            result['alt_precision'] = {
+                'precision': other,
+                'what': ('conv-LSTM gate GEMMs as six bf16 MFMA products per multiply (3-way exact operand split, '
+                         'fp32 accumulate); everything else fp32' if other == 'bf16x6' else 'exact fp32 MFMA'),
+                'value': frames_total / am['elapsed'], 'unit': 'frames/s',
+                'ms_per_step': 1e3 * am['elapsed'] / a.steps,
+                'cem_iters_per_sec': iters * a.steps / am['elapsed'],
+                'roofline': self.roofline(am, other),
+                'elites_identical_to_primary': am['elites'] == m['elites'],
+                'best_score_last_plan': am['best'],
+            }
+
+        if self.rank == 0 and self.world == 1 and not a.no_cpu_baseline:
+            ctrl = m['ctrl']
+            ctx = {'context_frames': self.frames[:, :1], 'context_actions': np.zeros((1, 4)),
+                   'context_states': self.states,
+                   'context_pixel_distributions': ctrl._switch_on_pix(
+                       np.array(self.desig).reshape(a.ncam, a.ndesig, 2))[:, :1]}
+            acts = np.random.RandomState(3).normal(0, 0.05, (a.cpu_samples, T, 4))
+            result['cpu_baseline'] = cpu_baseline(m['prof_pred'].weights, ctx, acts,
+                                                  np.array(self.goal[:a.ndesig]).reshape(1, -1, 2))
+        elif self.rank == 0:
+            result['cpu_baseline'] = None
+        if self.rank == 0:
+            print(json.dumps(result))
+        if self.world > 1:
+            self.dist.destroy_process_group()
 
 
 if __name__ == '__main__':
-    main()
+    Bench(parse()).run()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 1
+#define VF_ABI_VERSION 2
 
 typedef enum vf_status {
     VF_OK = 0,
@@ -56,6 +56,12 @@ typedef struct vf_config {
     int32_t num_masks;          /* CDNA kernels K (masks = K + 1) */
     int32_t max_batch;          /* run_batch_size: most samples per vf_rollout call */
     int32_t device;             /* HIP device ordinal */
+    int32_t precision;          /* arithmetic of the conv-LSTM gate GEMMs (96 % of the work):
+                                 * 0 = exact fp32 MFMA (default);
+                                 * 1 = fp32 emulated with six bf16 MFMA products per multiply
+                                 *     (3-way exact operand split, fp32 accumulate; fp32-class
+                                 *     accuracy, see csrc/vf_conv_bf16x6.h).  Everything else is
+                                 *     fp32 in both modes. */
 } vf_config;
 
 typedef struct vf_handle vf_handle;

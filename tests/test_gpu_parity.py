@@ -25,10 +25,10 @@ from visual_foresight_amd import _lib                                   # noqa: 
 from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights   # noqa: E402
 
 
-def _predictor(H, W, T, nd, bs, seed=3, n_context=2):
+def _predictor(H, W, T, nd, bs, seed=3, n_context=2, precision='fp32'):
     from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
     hp = dict(designated_pixel_count=nd, run_batch_size=bs, adim=4, sdim=5, image_height=H,
-              image_width=W, sequence_length=T + n_context, n_context=n_context)
+              image_width=W, sequence_length=T + n_context, n_context=n_context, precision=precision)
     pred = HipVPredEvaluation('', hp)
     cfg = CdnaConfig(height=H, width=W, ndesig=nd, sequence_length=T + n_context, n_context=n_context)
     weights = CdnaWeights.random(cfg, seed=seed, bias_scale=0.05, ln_jitter=0.1)
@@ -269,3 +269,33 @@ def test_shared_unit_cache_across_rollouts():
         np.testing.assert_array_equal(other, ref)
         assert not np.array_equal(other, fresh)
         assert pred.device_status() == 0
+
+
+@pytest.mark.parametrize('H,W,T,M,nd', [(64, 64, 3, 5, 1), (48, 64, 2, 5, 2), (32, 32, 4, 9, 1)])
+def test_split_bf16_mode_has_fp32_class_accuracy(H, W, T, M, nd):
+    """precision='bf16x6' (conv-LSTM GEMMs as six bf16 MFMA products per multiply) against the
+    float64 oracle: it must sit within 4x of the distance the exact-fp32 path sits at, and inside
+    the same absolute tolerances as the fp32 path."""
+    rs = np.random.RandomState(H + T)
+    ctx = _context(H, W, nd, rs)
+    actions = rs.normal(0, 0.1, (M, T, 4))
+    goal = rs.randint(0, min(H, W), (1, nd, 2))
+    errs = {}
+    for prec in ('fp32', 'bf16x6'):
+        for persistent in (1, 0):
+            pred, weights = _predictor(H, W, T, nd, bs=M, precision=prec)
+            pred.set_persistent(persistent)
+            scores, _ = pred.score(ctx, {'actions': actions}, goal)
+            got = pred(ctx, {'actions': actions})
+            f, d, s = _oracle(weights, ctx, actions, torch.float64)
+            want, _ = pixel_cost.eval_pixel_cost(d.astype(np.float32), goal, 10.)
+            dmax = d.max(axis=(3, 4), keepdims=True)
+            errs[(prec, persistent)] = (np.abs(got['predicted_frames'] - f).max(),
+                                        (np.abs(got['predicted_pixel_distributions'] - d) / dmax).max(),
+                                        np.abs(scores / want - 1).max())
+    for persistent in (1, 0):
+        e32, e16 = errs[('fp32', persistent)], errs[('bf16x6', persistent)]
+        assert e16[0] <= 1e-5 and e16[1] <= 2e-5 and e16[2] <= 1e-5
+        assert e16[0] <= 4 * e32[0] + 1e-7 and e16[1] <= 4 * e32[1] + 1e-7, (e32, e16)
+    # the two launch strategies agree bit-for-bit within a precision mode
+    assert errs[('bf16x6', 1)] == errs[('bf16x6', 0)]

@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""GPU box: accuracy of the two precision modes against the float64 oracle + elite agreement."""
+import os, sys, contextlib, io
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights
+from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+from oracle.cdna_predictor import OracleCdna
+from oracle import pixel_cost
+
+H = W = 64
+T, M = 13, 12
+rs = np.random.RandomState(5)
+ctx = {'context_frames': rs.randint(0, 256, (2, 1, H, W, 3)).astype(np.uint8), 'context_actions': rs.normal(0, .05, (1, 4)),
+       'context_states': rs.normal(0, .1, (2, 5)), 'context_pixel_distributions': pixel_cost.one_hot_distrib([[[32, 32]]], 2, 1, H, W, 1)}
+acts = rs.normal(0, 0.05, (M, T, 4))
+goal = np.array([[[16, 48]]])
+cfg = CdnaConfig(sequence_length=T + 2)
+weights = CdnaWeights.random(cfg, seed=0)
+f64, d64, s64 = OracleCdna(weights, torch.float64).rollout(ctx['context_frames'], ctx['context_actions'], ctx['context_pixel_distributions'], ctx['context_states'], acts)
+f32, d32, s32 = OracleCdna(weights, torch.float32).rollout(ctx['context_frames'], ctx['context_actions'], ctx['context_pixel_distributions'], ctx['context_states'], acts)
+want64, _ = pixel_cost.eval_pixel_cost(d64, goal, 10.)
+print('T=%d horizon, %d samples, 64x64; errors vs the float64 oracle (max over everything)' % (T, M))
+print('%-22s frames %.3g  distrib(rel plane max) %.3g' % ('torch-CPU fp32 oracle', np.abs(f32 - f64).max(), (np.abs(d32 - d64) / d64.max((3, 4), keepdims=True)).max()))
+scores = {}
+for prec in ('fp32', 'bf16x6'):
+    pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2, precision=prec)).restore(weights)
+    sc, _ = pred.score(ctx, {'actions': acts}, goal)
+    got = pred(ctx, {'actions': acts})
+    scores[prec] = sc
+    print('%-22s frames %.3g  distrib(rel plane max) %.3g  scores rel %.3g' % ('HIP ' + prec,
+          np.abs(got['predicted_frames'] - f64).max(),
+          (np.abs(got['predicted_pixel_distributions'] - d64) / d64.max((3, 4), keepdims=True)).max(),
+          np.abs(sc / want64 - 1).max()))
+print('score order identical (fp32 vs bf16x6):', np.array_equal(scores['fp32'].argsort(), scores['bf16x6'].argsort()),
+      ' vs float64 oracle:', np.array_equal(scores['bf16x6'].argsort(), want64.argsort()))
+print('min score gap %.3g  max |fp32 - bf16x6| %.3g' % (np.diff(np.sort(want64)).min(), np.abs(scores['fp32'] - scores['bf16x6']).max()))

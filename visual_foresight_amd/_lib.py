@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get('VF_LIBRARY') or os.path.join(_HERE, 'libvf_hip.so')     # override: experiments only
 SOURCES = [os.path.join(_HERE, 'csrc', f) for f in
-           ('vf_engine.hip', 'vf_conv_mfma.h', 'vf_small_kernels.h', 'vf_persistent.h')] + \
+           ('vf_engine.hip', 'vf_conv_mfma.h', 'vf_small_kernels.h', 'vf_persistent.h', 'vf_conv_bf16x6.h')] + \
           [os.path.join(REPO, 'include', 'vf_hip.h')]
 
 EXPORTS = ('vf_abi_version', 'vf_last_error', 'vf_weight_count', 'vf_create', 'vf_destroy',
@@ -30,7 +30,7 @@ class VfError(RuntimeError):
 class VfConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ('height', 'width', 'adim', 'sdim', 'ndesig', 'n_context', 'sequence_length',
-                 'num_masks', 'max_batch', 'device')]
+                 'num_masks', 'max_batch', 'device', 'precision')]
 
 
 def _hipcc():
@@ -104,8 +104,8 @@ def load_library():
     for name in ('vf_create', 'vf_destroy', 'vf_load_weights', 'vf_set_context', 'vf_rollout',
                  'vf_export'):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.vf_abi_version() != 1:
-        raise VfError('libvf_hip.so ABI version %d, expected 1' % lib.vf_abi_version())
+    if lib.vf_abi_version() != 2:
+        raise VfError('libvf_hip.so ABI version %d, expected 2' % lib.vf_abi_version())
     _lib = lib
     return lib
 

@@ -81,6 +81,7 @@ struct ConvParams {
     int ncg;                // groups of 32 output channels
     int Cout;               // real output channels per gate
     const float *Wp;        // packed weights
+    const unsigned short *Wp16;  // split-bf16 packed weights (vf_conv_bf16x6.h) or null
     const float *bias;      // packed [ncg][G][32]
     const float *sbias;     // optional per-sample bias [B][sbias_ld]
     int sbias_ld;
@@ -106,6 +107,114 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+
+// Shared epilogue of the fp32 and the split-bf16 tiles: accumulators (MFMA 32x32 C layout) ->
+// bias / activation / cell update / stores + deterministic LayerNorm partial sums.
+template <int G, int EPI, int MREP, class PT>
+__device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G], const int bx, const int by,
+                                              const int bz, double *red) {
+    constexpr int WROWS = MREP * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    const int cg = by;
+    const int tiles_per_img = p.tilesY * p.tilesX;
+    const int px_per_img = p.TH * p.TW;
+    int bimg0, ty0, tx0, tile_id;
+    if (p.NI == 1) {
+        bimg0 = bx / tiles_per_img;
+        tile_id = bx % tiles_per_img;
+        ty0 = (tile_id / p.tilesX) * p.TH;
+        tx0 = (tile_id % p.tilesX) * p.TW;
+    } else {
+        bimg0 = bx * p.NI;
+        tile_id = 0; ty0 = 0; tx0 = 0;
+    }
+    const int ch = cg * 32 + n;             // output channel of this lane
+    float bias_g[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) bias_g[g] = (EPI == EPI_PARTIAL) ? 0.f : p.bias[(cg * G + g) * 32 + n];
+
+    float ssum = 0.f, ssq = 0.f;            // LayerNorm partials over this lane's outputs
+
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * WROWS + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int img = row / p.RPI, rem = row % p.RPI;
+            const int y = ty0 + rem / p.TW, x = tx0 + rem % p.TW;
+            const int b = bimg0 + img;
+            const bool ok = img < p.NI && rem < px_per_img && b < p.B && y < p.Hout && x < p.Wout;
+            if (!ok) continue;
+            if constexpr (EPI == EPI_LSTM) {
+                const long long o = (((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch;
+                const float gi = acc[m][0][r] + bias_g[0];
+                const float gj = acc[m][1 % G][r] + bias_g[1 % G];
+                const float gf = acc[m][2 % G][r] + bias_g[2 % G];
+                const float go = acc[m][3 % G][r] + bias_g[3 % G];
+                const float c_old = p.cstate_in[(long long)b * p.cin_bstride +
+                                                ((long long)y * p.Wout + x) * p.Cout + ch];
+                const float c_new = fmaf(c_old, sigmoidf_(gf + 1.0f), sigmoidf_(gi) * tanhf_(gj));
+                const float h_new = tanhf_(c_new) * sigmoidf_(go);
+                p.cstate[o] = c_new;
+                p.out[o] = h_new;
+                ssum += h_new; ssq = fmaf(h_new, h_new, ssq);
+            } else if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_RAW_STATS) {
+                if (ch < p.Cout) {
+                    float v = acc[m][0][r] + bias_g[0];
+                    if (p.sbias) v += p.sbias[(long long)b * p.sbias_ld + ch];
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                    p.out[(((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch] = v;
+                    ssum += v; ssq = fmaf(v, v, ssq);
+                }
+            } else if constexpr (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS) {
+                if (ch < p.Cout) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int oy = 2 * y + (g >> 1), ox = 2 * x + (g & 1);
+                        float v = acc[m][g][r] + bias_g[g];
+                        if (EPI == EPI_CONVT_RELU) v = fmaxf(v, 0.f);
+                        p.out[(((long long)b * (2 * p.Hout) + oy) * (2 * p.Wout) + ox) * p.Cout + ch] = v;
+                        ssum += v; ssq = fmaf(v, v, ssq);
+                    }
+                }
+            } else {    // EPI_PARTIAL: [split][B][n_valid]
+                if (ch < p.n_valid)
+                    p.out[((long long)bz * p.B + b) * p.n_valid + ch] = acc[m][0][r];
+            }
+        }
+    }
+
+    if constexpr (EPI == EPI_LSTM || EPI == EPI_RAW_STATS || EPI == EPI_CONVT_RAW_STATS) {
+        // deterministic reduction: lane -> wave (xor butterfly) -> fixed-order sum over waves
+        const double wsum = wave_sum((double)ssum), wsq = wave_sum((double)ssq);
+        __syncthreads();
+        if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
+        __syncthreads();
+        if (p.NI == 1) {
+            if (tid == 0 && bimg0 < p.B) {
+                double su = 0.0, sq = 0.0;
+                for (int w = 0; w < 4; ++w) { su += red[2 * w]; sq += red[2 * w + 1]; }
+                double *dst = p.stats + ((long long)bimg0 * p.stats_nparts + tile_id * p.ncg + cg) * 2;
+                dst[0] = su; dst[1] = sq;
+            }
+        } else {
+            // RPI is a multiple of WROWS here: wave w owns image slot (w*WROWS)/RPI entirely or
+            // shares it with its neighbours; sum the waves of each image in fixed order
+            const int waves_per_img = p.RPI / WROWS;
+            if (lane == 0 && (wave % waves_per_img) == 0) {
+                const int img = wave / waves_per_img;
+                const int b = bimg0 + img;
+                if (img < p.NI && b < p.B) {
+                    double su = 0.0, sq = 0.0;
+                    for (int w = 0; w < waves_per_img; ++w) { su += red[2 * (wave + w)]; sq += red[2 * (wave + w) + 1]; }
+                    double *dst = p.stats + ((long long)b * p.stats_nparts + cg) * 2;
+                    dst[0] = su; dst[1] = sq;
+                }
+            }
+        }
+    }
 }
 
 // One workgroup tile.  (bx, by, bz) = (row tile, channel group, K split); smem = the workgroup's
@@ -335,92 +444,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #undef VF_LOADB
 #undef VF_WRITEB
 
-    // ------------------------------------------------------------------ epilogue
-    const int ch = cg * 32 + n;             // output channel of this lane
-    float bias_g[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) bias_g[g] = (EPI == EPI_PARTIAL) ? 0.f : p.bias[(cg * G + g) * 32 + n];
-
-    float ssum = 0.f, ssq = 0.f;            // LayerNorm partials over this lane's outputs
-
-#pragma unroll
-    for (int m = 0; m < MREP; ++m) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave * WROWS + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int img = row / p.RPI, rem = row % p.RPI;
-            const int y = ty0 + rem / p.TW, x = tx0 + rem % p.TW;
-            const int b = bimg0 + img;
-            const bool ok = img < p.NI && rem < px_per_img && b < p.B && y < p.Hout && x < p.Wout;
-            if (!ok) continue;
-            if constexpr (EPI == EPI_LSTM) {
-                const long long o = (((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch;
-                const float gi = acc[m][0][r] + bias_g[0];
-                const float gj = acc[m][1 % G][r] + bias_g[1 % G];
-                const float gf = acc[m][2 % G][r] + bias_g[2 % G];
-                const float go = acc[m][3 % G][r] + bias_g[3 % G];
-                const float c_old = p.cstate_in[(long long)b * p.cin_bstride +
-                                                ((long long)y * p.Wout + x) * p.Cout + ch];
-                const float c_new = fmaf(c_old, sigmoidf_(gf + 1.0f), sigmoidf_(gi) * tanhf_(gj));
-                const float h_new = tanhf_(c_new) * sigmoidf_(go);
-                p.cstate[o] = c_new;
-                p.out[o] = h_new;
-                ssum += h_new; ssq = fmaf(h_new, h_new, ssq);
-            } else if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_RAW_STATS) {
-                if (ch < p.Cout) {
-                    float v = acc[m][0][r] + bias_g[0];
-                    if (p.sbias) v += p.sbias[(long long)b * p.sbias_ld + ch];
-                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                    p.out[(((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch] = v;
-                    ssum += v; ssq = fmaf(v, v, ssq);
-                }
-            } else if constexpr (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS) {
-                if (ch < p.Cout) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        const int oy = 2 * y + (g >> 1), ox = 2 * x + (g & 1);
-                        float v = acc[m][g][r] + bias_g[g];
-                        if (EPI == EPI_CONVT_RELU) v = fmaxf(v, 0.f);
-                        p.out[(((long long)b * (2 * p.Hout) + oy) * (2 * p.Wout) + ox) * p.Cout + ch] = v;
-                        ssum += v; ssq = fmaf(v, v, ssq);
-                    }
-                }
-            } else {    // EPI_PARTIAL: [split][B][n_valid]
-                if (ch < p.n_valid)
-                    p.out[((long long)bz * p.B + b) * p.n_valid + ch] = acc[m][0][r];
-            }
-        }
-    }
-
-    if constexpr (EPI == EPI_LSTM || EPI == EPI_RAW_STATS || EPI == EPI_CONVT_RAW_STATS) {
-        // deterministic reduction: lane -> wave (xor butterfly) -> fixed-order sum over waves
-        const double wsum = wave_sum((double)ssum), wsq = wave_sum((double)ssq);
-        __syncthreads();
-        if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
-        __syncthreads();
-        if (p.NI == 1) {
-            if (tid == 0 && bimg0 < p.B) {
-                double su = 0.0, sq = 0.0;
-                for (int w = 0; w < 4; ++w) { su += red[2 * w]; sq += red[2 * w + 1]; }
-                double *dst = p.stats + ((long long)bimg0 * p.stats_nparts + tile_id * p.ncg + cg) * 2;
-                dst[0] = su; dst[1] = sq;
-            }
-        } else {
-            // RPI is a multiple of WROWS here: wave w owns image slot (w*WROWS)/RPI entirely or
-            // shares it with its neighbours; sum the waves of each image in fixed order
-            const int waves_per_img = p.RPI / WROWS;
-            if (lane == 0 && (wave % waves_per_img) == 0) {
-                const int img = wave / waves_per_img;
-                const int b = bimg0 + img;
-                if (img < p.NI && b < p.B) {
-                    double su = 0.0, sq = 0.0;
-                    for (int w = 0; w < waves_per_img; ++w) { su += red[2 * (wave + w)]; sq += red[2 * (wave + w) + 1]; }
-                    double *dst = p.stats + ((long long)b * p.stats_nparts + cg) * 2;
-                    dst[0] = su; dst[1] = sq;
-                }
-            }
-        }
-    }
+    conv_epilogue<G, EPI, MREP>(p, acc, bx, by, bz, red);
 }
 
 template <int G, int EPI, int MREP>

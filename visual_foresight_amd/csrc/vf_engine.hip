@@ -18,6 +18,7 @@
 #include "../../include/vf_hip.h"
 #include "vf_conv_mfma.h"
 #include "vf_small_kernels.h"
+#include "vf_conv_bf16x6.h"
 #include "vf_persistent.h"
 
 namespace vf {
@@ -116,6 +117,8 @@ struct ConvLayer {
     int segC[2], nseg;
     int KC, nchunk[2];
     int mrep;                       // MFMA row blocks per wave: the workgroup covers 128 * mrep rows
+    int prec = 0;                   // 1: split-bf16 tile (conv-LSTM only)
+    unsigned short *d_w16 = nullptr;
     int NI, TH, TW, RPI, tilesY, tilesX;
     int ncg, Cout;
     int nsplit, chunks_per_split, n_valid;
@@ -158,9 +161,14 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
     while (KC > 8 && (KC > round_up(maxC, 8) || conv_lds_bytes(l, KC) > 78 * 1024 ||
                       l.segC[0] % KC || (l.nseg > 1 && l.segC[1] % KC)))
         KC >>= 1;
+    if (l.prec == 1) KC = kBfKC;        // the split-bf16 tile stages 16-channel chunks
     l.KC = KC;
     for (int s = 0; s < 2; ++s) l.nchunk[s] = s < l.nseg ? (l.segC[s] + KC - 1) / KC : 0;
     l.lds_bytes = conv_lds_bytes(l, KC);
+    if (l.prec == 1) {
+        const int LH = (l.TH - 1) * l.stride + l.KH, LW = (l.TW - 1) * l.stride + l.KW;
+        l.lds_bytes = bf16x6_lds_bytes(l.NI, LH, LW);
+    }
     l.stats_nparts = (l.NI == 1 ? l.tilesY * l.tilesX : 1) * l.ncg;
 }
 
@@ -203,6 +211,53 @@ static std::vector<float> pack_weights(const ConvLayer &l, const float *w, int K
                                 out[dst] = w[(((size_t)ky * KWc + kx) * Cin + cin) * Ctot + ocol];
                             }
                         }
+    }
+    return out;
+}
+
+static unsigned short bf16_rne(float x) {        // round-to-nearest-even, as v_cvt_pk_bf16_f32
+    unsigned u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static float bf16_to_f32(unsigned short h) {
+    unsigned u = (unsigned)h << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+// canonical LSTM weights [5][5][Cin][4C] -> three exact bf16 pieces, packed
+// [chunk16][tap][cg][gate][plane][k-half][32 columns][8 channels]   (vf_conv_bf16x6.h)
+static std::vector<unsigned short> pack_weights_bf16x3(const ConvLayer &l, const float *w, int Cin, int Ctot) {
+    const int ntaps = l.KH * l.KW, nchunks = l.nchunk[0] + l.nchunk[1];
+    std::vector<unsigned short> out((size_t)nchunks * ntaps * l.ncg * 4 * 3 * 64 * 8, 0);
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int s = ci < l.nchunk[0] ? 0 : 1;
+        const int c0 = (s == 0 ? ci : ci - l.nchunk[0]) * kBfKC;
+        const int seg_off = s == 0 ? 0 : l.segC[0];
+        for (int tap = 0; tap < ntaps; ++tap)
+            for (int cgi = 0; cgi < l.ncg; ++cgi)
+                for (int g = 0; g < 4; ++g)
+                    for (int kh = 0; kh < 2; ++kh)
+                        for (int nn = 0; nn < 32; ++nn)
+                            for (int j = 0; j < 8; ++j) {
+                                const int c = c0 + kh * 8 + j, co = cgi * 32 + nn;
+                                if (c >= l.segC[s] || co >= l.Cout) continue;
+                                const float x = w[((size_t)tap * Cin + seg_off + c) * Ctot + g * l.Cout + co];
+                                const unsigned short p0 = bf16_rne(x);
+                                const float r1 = x - bf16_to_f32(p0);
+                                const unsigned short p1 = bf16_rne(r1);
+                                const unsigned short p2 = bf16_rne(r1 - bf16_to_f32(p1));
+                                const unsigned short pc[3] = {p0, p1, p2};
+                                for (int pl = 0; pl < 3; ++pl) {
+                                    const size_t unit = ((((size_t)(ci * ntaps + tap) * l.ncg + cgi) * 4 + g) * 3 + pl) * 64 +
+                                                        kh * 32 + nn;
+                                    out[unit * 8 + j] = pc[pl];
+                                }
+                            }
     }
     return out;
 }
@@ -337,13 +392,14 @@ static int validate(const vf_config *c) {
         return fail(VF_ERR_INVALID, "need adim, sdim >= 1 and adim + sdim <= 32");
     if (c->num_masks != 10) return fail(VF_ERR_INVALID, "num_masks must be 10 in this build");
     if (c->max_batch < 1) return fail(VF_ERR_INVALID, "max_batch must be >= 1");
+    if (c->precision != 0 && c->precision != 1) return fail(VF_ERR_INVALID, "precision must be 0 (fp32) or 1 (split bf16)");
     return VF_OK;
 }
 
 static void init_layer(ConvLayer &l, const char *name, PackMode mode, int Hin, int Win, int Hout, int Wout,
                        int KH, int KW, int stride, int pad, int c0, int c1, int Cout, bool stats,
-                       bool fc = false, int mrep = 1) {
-    l.name = name; l.mode = mode; l.G = (mode == PACK_PLAIN) ? 1 : 4; l.mrep = mrep;
+                       bool fc = false, int mrep = 1, int prec = 0) {
+    l.name = name; l.mode = mode; l.G = (mode == PACK_PLAIN) ? 1 : 4; l.mrep = mrep; l.prec = prec;
     l.Hin = Hin; l.Win = Win; l.Hout = Hout; l.Wout = Wout;
     l.KH = KH; l.KW = KW; l.stride = stride; l.pad = pad;
     l.segC[0] = c0; l.segC[1] = c1; l.nseg = c1 > 0 ? 2 : 1;
@@ -377,9 +433,24 @@ static int launch_conv_m(const ConvLayer &l, const ConvParams &p, hipStream_t st
 
 // which (G, EPI, MREP) instances exist: LSTM in both tile heights, the FC with 256 rows (it has
 // few rows and a long K), every other layer with 128-row tiles
+template <int MREP>
+static int launch_lstm_bf16x6(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
+    static size_t configured = 0;
+    if (l.lds_bytes > configured) {
+        VF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_lstm_bf16x6_kernel<MREP>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes));
+        configured = l.lds_bytes;
+    }
+    const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
+    hipLaunchKernelGGL((conv_lstm_bf16x6_kernel<MREP>), dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
+    VF_HIP_CHECK(hipGetLastError());
+    return VF_OK;
+}
+
 template <int G, int EPI>
 static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     if constexpr (EPI == EPI_LSTM) {
+        if (l.prec == 1) return l.mrep == 1 ? launch_lstm_bf16x6<1>(l, p, st) : launch_lstm_bf16x6<2>(l, p, st);
         return l.mrep == 1 ? launch_conv_m<G, EPI, 1>(l, p, st) : launch_conv_m<G, EPI, 2>(l, p, st);
     } else if constexpr (EPI == EPI_PARTIAL) {
         return launch_conv_m<G, EPI, 2>(l, p, st);
@@ -411,7 +482,7 @@ static ConvParams make_params(const ConvLayer &l, int B, const SegArg &s0, const
     p.Hin = l.Hin; p.Win = l.Win; p.Hout = l.Hout; p.Wout = l.Wout;
     p.KH = l.KH; p.KW = l.KW; p.stride = l.stride; p.pad = l.pad; p.KC = l.KC;
     p.NI = l.NI; p.TH = l.TH; p.TW = l.TW; p.RPI = l.RPI; p.tilesY = l.tilesY; p.tilesX = l.tilesX;
-    p.ncg = l.ncg; p.Cout = l.Cout; p.Wp = l.d_w; p.bias = l.d_b;
+    p.ncg = l.ncg; p.Cout = l.Cout; p.Wp = l.d_w; p.Wp16 = l.d_w16; p.bias = l.d_b;
     p.chunks_per_split = l.chunks_per_split; p.n_valid = l.n_valid;
     p.stats_nparts = l.stats_nparts;
     return p;
@@ -475,18 +546,18 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     if (const char *e = getenv("VF_LSTM_MREP"))
         for (int k = 0; k < 7 && e[k]; ++k) lstm_mrep[k] = e[k] == '2' ? 2 : 1;
     init_layer(h->enc0, "enc0", PACK_PLAIN, H, W, H2, W2, 5, 5, 2, 1, 3, 0, 32, true);
-    init_layer(h->lstm[0], "lstm1", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, 32, L[0], L[0], true, false, lstm_mrep[0]);
-    init_layer(h->lstm[1], "lstm2", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[0], L[1], L[1], true, false, lstm_mrep[1]);
+    init_layer(h->lstm[0], "lstm1", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, 32, L[0], L[0], true, false, lstm_mrep[0], cfg->precision);
+    init_layer(h->lstm[1], "lstm2", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[0], L[1], L[1], true, false, lstm_mrep[1], cfg->precision);
     init_layer(h->enc1, "enc1", PACK_PLAIN, H2, W2, H4, W4, 3, 3, 2, 0, L[1], 0, L[1], false);
-    init_layer(h->lstm[2], "lstm3", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[1], L[2], L[2], true, false, lstm_mrep[2]);
-    init_layer(h->lstm[3], "lstm4", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[2], L[3], L[3], true, false, lstm_mrep[3]);
+    init_layer(h->lstm[2], "lstm3", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[1], L[2], L[2], true, false, lstm_mrep[2], cfg->precision);
+    init_layer(h->lstm[3], "lstm4", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[2], L[3], L[3], true, false, lstm_mrep[3], cfg->precision);
     init_layer(h->enc2, "enc2", PACK_PLAIN, H4, W4, H8, W8, 3, 3, 2, 0, L[3], 0, L[3], false);
     init_layer(h->enc3, "enc3", PACK_PLAIN, H8, W8, H8, W8, 1, 1, 1, 0, L[3], 0, L[3], false);
-    init_layer(h->lstm[4], "lstm5", PACK_LSTM, H8, W8, H8, W8, 5, 5, 1, 2, L[3], L[4], L[4], true, false, lstm_mrep[4]);
+    init_layer(h->lstm[4], "lstm5", PACK_LSTM, H8, W8, H8, W8, 5, 5, 1, 2, L[3], L[4], L[4], true, false, lstm_mrep[4], cfg->precision);
     init_layer(h->convt1, "convt1", PACK_CONVT, H8, W8, H8, W8, 2, 2, 1, 1, L[4], 0, L[4], false);
-    init_layer(h->lstm[5], "lstm6", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[4], L[5], L[5], true, false, lstm_mrep[5]);
+    init_layer(h->lstm[5], "lstm6", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[4], L[5], L[5], true, false, lstm_mrep[5], cfg->precision);
     init_layer(h->convt2, "convt2", PACK_CONVT, H4, W4, H4, W4, 2, 2, 1, 1, L[5], L[1], L[5], false);
-    init_layer(h->lstm[6], "lstm7", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[5], L[6], L[6], true, false, lstm_mrep[6]);
+    init_layer(h->lstm[6], "lstm7", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[5], L[6], L[6], true, false, lstm_mrep[6], cfg->precision);
     init_layer(h->convt3, "convt3", PACK_CONVT, H2, W2, H2, W2, 2, 2, 1, 1, L[6], 32, 32, true);
     // CDNA FC as a K-split GEMM over 1x1 "images"
     init_layer(h->fc, "cdna", PACK_PLAIN, 1, 1, 1, 1, 1, 1, 1, 0, H8 * W8 * L[4], 0, kTaps * h->K, false, true, 2);
@@ -612,6 +683,11 @@ int vf_load_weights(vf_handle *h, const float *blob, size_t n_floats) {
         }
         int r = upload(h, &l.d_w, wp.data(), wp.size());
         if (r) return r;
+        if (l.prec == 1) {
+            std::vector<unsigned short> w16 = pack_weights_bf16x3(l, blob + w->offset, w->shape[2], w->shape[3]);
+            if ((r = dev_alloc(h, &l.d_w16, w16.size()))) return r;
+            VF_HIP_CHECK(hipMemcpy(l.d_w16, w16.data(), w16.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        }
         return upload(h, &l.d_b, bp.data(), bp.size());
     };
     ConvLayer *layers[] = {&h->enc0, &h->lstm[0], &h->lstm[1], &h->enc1, &h->lstm[2], &h->lstm[3], &h->enc2,
@@ -797,6 +873,7 @@ struct ScheduleSink {
         P.gy = l.ncg;
         P.whole = type == PH_FC_PARTIAL;
         P.mrep = l.mrep;
+        P.prec = l.prec;
         max_lds = std::max(max_lds, l.lds_bytes);
         const double rows = (double)p.B * l.Hout * l.Wout;
         const double taps = l.mode == PACK_CONVT ? 9.0 / 4.0 * 4.0 : (double)l.KH * l.KW;   // real taps

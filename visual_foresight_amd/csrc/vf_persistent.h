@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include "vf_conv_mfma.h"
 #include "vf_small_kernels.h"
+#include "vf_conv_bf16x6.h"
 
 namespace vf {
 
@@ -45,6 +46,7 @@ struct PhaseDesc {
     int NI, tiles_per_img;  // conv phases: how an item maps to samples
     int whole;              // 1: completion is counted once per item on counter 0
     int mrep;               // MFMA row blocks per wave of this conv phase (1 or 2)
+    int prec;               // 0: fp32 MFMA tile, 1: split-bf16 conv-LSTM tile
     int cnt_base;
     int ndep;
     PhaseDep dep[kMaxDeps];
@@ -111,6 +113,10 @@ __device__ __forceinline__ float *tile_lds() {
 template <int G, int EPI, int MREP>
 __device__ __noinline__ void conv_tile_call(const ConvParams *p, int bx, int by, int bz) {
     conv_tile<G, EPI, MREP>(const_params(p), bx, by, bz, tile_lds());
+}
+template <int MREP>
+__device__ __noinline__ void lstm_bf16x6_tile_call(const ConvParams *p, int bx, int by) {
+    conv_lstm_bf16x6_tile<MREP>(const_params(p), bx, by, tile_lds());
 }
 template <int ND>
 __device__ __noinline__ void composite_tile_call(const CompositeParams *p, int tile, int b) {
@@ -193,7 +199,10 @@ __global__ __launch_bounds__(kConvThreads, WPS) void rollout_persistent_kernel(
             const int by = local % P.gy, bx = local / P.gy;
             switch (P.type) {
                 case PH_LSTM:
-                    if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
+                    if (P.prec == 1) {
+                        if (P.mrep == 1) lstm_bf16x6_tile_call<1>(&P.conv, bx, by);
+                        else if constexpr (WPS <= 2) lstm_bf16x6_tile_call<2>(&P.conv, bx, by);
+                    } else if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
                     else if constexpr (WPS <= 2) conv_tile_call<4, EPI_LSTM, 2>(&P.conv, bx, by, 0);
                     break;
                 case PH_CONV_RELU: conv_tile_call<1, EPI_BIAS_RELU, 1>(&P.conv, bx, by, 0); break;

@@ -58,9 +58,13 @@ class HipVPredEvaluation(object):
         self.device = torch.device('cuda', self.device_index)
         self._libh = _lib.load_library()
         c = self.cfg
+        # 'fp32' (default): exact fp32 MFMA.  'bf16x6': fp32 emulated by six bf16 MFMA products in the
+        # conv-LSTM gate GEMMs (fp32-class accuracy, not bit-identical to 'fp32').
+        precision = hp.get('precision', os.environ.get('VF_PRECISION', 'fp32'))
+        self.precision = {'fp32': 0, '0': 0, 0: 0, 'bf16x6': 1, '1': 1, 1: 1}[precision]
         self._c_cfg = _lib.VfConfig(c.height, c.width, c.adim, c.sdim, c.ndesig, c.n_context,
                                     c.sequence_length, c.num_masks, self.run_batch_size,
-                                    self.device_index)
+                                    self.device_index, self.precision)
         self._handle = ctypes.c_void_p()
         _lib.check(self._libh.vf_create(ctypes.byref(self._c_cfg), ctypes.byref(self._handle)))
         self.set_substreams(int(hp.get('substreams', os.environ.get('VF_SUBSTREAMS', 1))))
