@@ -2,7 +2,7 @@
 # Build timing-experiment variants of the library (WRONG results, timing only) next to this script.
 cd "$(dirname "$0")"
 SRC=../../visual_foresight_amd/csrc/vf_engine.hip
-for v in NO_A NO_B NO_STAGE; do
+for v in ${VARIANTS:-NO_A NO_B NO_STAGE}; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC -DVF_EXP_$v -o libvf_exp_$v.so $SRC &
 done
 wait

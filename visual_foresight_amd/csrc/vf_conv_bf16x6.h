@@ -178,7 +178,7 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx,
                 const int buf = gt & 1;
                 const int ao = (ky * LW + kx) * kBfRowUnits;
                 const bool more = gt + 1 < gtN;
-                if (more) { VF_LOADB16(gt + 1) }
+                if (more) { VF_LOADB16(VF_EXP_B(gt + 1)) }
                 bf16x8 a[3][MREP], bw[3][G];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
@@ -197,7 +197,9 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx,
                 VF_T(2, 0) VF_T(0, 2) VF_T(1, 1) VF_T(1, 0) VF_T(0, 1) VF_T(0, 0)
 #undef VF_T
                 if (more) { VF_WRITEB16(buf ^ 1) }
+#ifndef VF_EXP_NO_TAP_BARRIER
                 __syncthreads();
+#endif
             }
         }
     }
@@ -206,6 +208,11 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx,
     conv_epilogue<G, EPI_LSTM, MREP>(p, acc, bx, by, 0, red);
 }
 
+// Measured alternatives (B=1024, per-layer launches, fp32-equivalent TF/s of this kernel): this
+// version 219.9; B loads free 226.7; no per-tap barrier 238.6 (wrong results, timing only); a 3-stage
+// pipeline (third B buffer, fragments of tap t+1 fetched under the MFMAs of tap t) 225.7 but 222 VGPRs,
+// which spills once the tile is an out-of-line body of the persistent kernel.  219.9 x 6 = 1.32 PF/s of
+// bf16 MFMA is where tuned bf16 GEMMs on random data land on this chip (power-limited clocks).
 template <int MREP>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_lstm_bf16x6_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -399,7 +399,7 @@ static int validate(const vf_config *c) {
 static void init_layer(ConvLayer &l, const char *name, PackMode mode, int Hin, int Win, int Hout, int Wout,
                        int KH, int KW, int stride, int pad, int c0, int c1, int Cout, bool stats,
                        bool fc = false, int mrep = 1, int prec = 0) {
-    l.name = name; l.mode = mode; l.G = (mode == PACK_PLAIN) ? 1 : 4; l.mrep = mrep; l.prec = prec;
+    l.name = name; l.mode = mode; l.G = (mode == PACK_PLAIN) ? 1 : 4; l.mrep = prec == 1 ? 1 : mrep; l.prec = prec;
     l.Hin = Hin; l.Win = Win; l.Hout = Hout; l.Wout = Wout;
     l.KH = KH; l.KW = KW; l.stride = stride; l.pad = pad;
     l.segC[0] = c0; l.segC[1] = c1; l.nseg = c1 > 0 ? 2 : 1;
@@ -450,7 +450,7 @@ static int launch_lstm_bf16x6(const ConvLayer &l, const ConvParams &p, hipStream
 template <int G, int EPI>
 static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     if constexpr (EPI == EPI_LSTM) {
-        if (l.prec == 1) return l.mrep == 1 ? launch_lstm_bf16x6<1>(l, p, st) : launch_lstm_bf16x6<2>(l, p, st);
+        if (l.prec == 1) return launch_lstm_bf16x6<1>(l, p, st);        // 128-row tiles only
         return l.mrep == 1 ? launch_conv_m<G, EPI, 1>(l, p, st) : launch_conv_m<G, EPI, 2>(l, p, st);
     } else if constexpr (EPI == EPI_PARTIAL) {
         return launch_conv_m<G, EPI, 2>(l, p, st);

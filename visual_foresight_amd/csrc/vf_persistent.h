@@ -200,8 +200,7 @@ __global__ __launch_bounds__(kConvThreads, WPS) void rollout_persistent_kernel(
             switch (P.type) {
                 case PH_LSTM:
                     if (P.prec == 1) {
-                        if (P.mrep == 1) lstm_bf16x6_tile_call<1>(&P.conv, bx, by);
-                        else if constexpr (WPS <= 2) lstm_bf16x6_tile_call<2>(&P.conv, bx, by);
+                        lstm_bf16x6_tile_call<1>(&P.conv, bx, by);      // 128-row tiles only
                     } else if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
                     else if constexpr (WPS <= 2) conv_tile_call<4, EPI_LSTM, 2>(&P.conv, bx, by, 0);
                     break;
