@@ -226,6 +226,9 @@ template <int G, int EPI, int MREP, class PT>
 __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int by, const int bz,
                                           float *smem) {
     constexpr int WROWS = MREP * 32;    // GEMM rows per wave
+    // B through LDS pays for the long-K conv-LSTM tiles; the transposed convs (4 taps, 2-4 chunks)
+    // lose more to its per-tap barrier than they gain, so they read B straight from L1/L2
+    constexpr bool kBLds = (EPI == EPI_LSTM);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     const int KC = p.KC, KCpad = KC + 4, K8 = KC >> 3;
@@ -314,7 +317,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #define VF_WRITEB(BUF_)                                                                         \
     _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
         if (q < K8) bsm[(((BUF_) * K8 + q) * 4 + wave) * 64 + lane] = breg[q];
-    if constexpr (G == 4) {
+    if constexpr (kBLds) {
         if (gt0 < gtN) { VF_LOADB(gt0) }
     }
 
@@ -364,7 +367,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
             }
             *reinterpret_cast<f32x4 *>(&smem[pix * KCpad + 4 * q]) = v;
         }
-        if constexpr (G == 4) {
+        if constexpr (kBLds) {
             if (ci == ch_begin) { VF_WRITEB(0) }
         }
         __syncthreads();
@@ -383,7 +386,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
             }                                                                                   \
         }
 
-        if constexpr (G == 4) {
+        if constexpr (kBLds) {
             // ---- K loop, B through LDS: taps outer (one barrier each), k8 inner (ping-pong)
 #define VF_FETCH_L(A_, B_, Q_)                                                                  \
             {                                                                                   \

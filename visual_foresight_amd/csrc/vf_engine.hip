@@ -133,7 +133,7 @@ static size_t conv_lds_bytes(const ConvLayer &l, int KC) {
     const int LH = (l.TH - 1) * l.stride + l.KH, LW = (l.TW - 1) * l.stride + l.KW;
     // A tile + LayerNorm table + reduction scratch (+ for 4-gate layers the double-buffered
     // per-tap B blocks: 2 x KC/8 x [4 gates][64 lanes] float4)
-    const size_t b_lds = l.G == 4 ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
+    const size_t b_lds = l.mode == PACK_LSTM ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
     return ((size_t)l.NI * LH * LW * (KC + 4) + 4 * (size_t)l.NI) * 4 + 64 + b_lds;
 }
 
