@@ -299,3 +299,29 @@ def test_split_bf16_mode_has_fp32_class_accuracy(H, W, T, M, nd):
         assert e16[0] <= 4 * e32[0] + 1e-7 and e16[1] <= 4 * e32[1] + 1e-7, (e32, e16)
     # the two launch strategies agree bit-for-bit within a precision mode
     assert errs[('bf16x6', 1)] == errs[('bf16x6', 0)]
+
+
+@pytest.mark.parametrize('H,W,adim,sdim,T,M', [(128, 128, 4, 5, 2, 2), (48, 64, 3, 3, 3, 4), (64, 96, 5, 5, 2, 3)])
+def test_other_resolutions_and_action_state_dims(H, W, adim, sdim, T, M):
+    """128x128 (BASELINE config 5 resolution), the sim cart-gripper's adim = sdim = 3, a wide frame."""
+    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+    hp = dict(designated_pixel_count=1, run_batch_size=M, adim=adim, sdim=sdim, image_height=H, image_width=W,
+              sequence_length=T + 2)
+    pred = HipVPredEvaluation('', hp)
+    cfg = CdnaConfig(height=H, width=W, adim=adim, sdim=sdim, sequence_length=T + 2)
+    weights = CdnaWeights.random(cfg, seed=8, bias_scale=0.05, ln_jitter=0.1)
+    pred.restore(weights)
+    rs = np.random.RandomState(H + adim)
+    ctx = {'context_frames': rs.randint(0, 256, (2, 1, H, W, 3)).astype(np.uint8),
+           'context_actions': rs.normal(0, 0.05, (1, adim)), 'context_states': rs.normal(0, 0.1, (2, sdim)),
+           'context_pixel_distributions': pixel_cost.one_hot_distrib([[[H // 2, W // 3]]], 2, 1, H, W, 1)}
+    actions = rs.normal(0, 0.1, (M, T, adim))
+    goal = np.array([[[H // 4, W // 2]]])
+    scores, _ = pred.score(ctx, {'actions': actions}, goal)
+    got = pred(ctx, {'actions': actions})
+    f, d, s = _oracle(weights, ctx, actions)
+    assert np.abs(got['predicted_frames'] - f).max() <= 1e-5
+    assert (np.abs(got['predicted_pixel_distributions'] - d) / d.max(axis=(3, 4), keepdims=True)).max() <= 2e-5
+    assert np.abs(got['predicted_states'] - s).max() <= 1e-6
+    want, _ = pixel_cost.eval_pixel_cost(d, goal, 10.)
+    np.testing.assert_allclose(scores, want, rtol=1e-5)

@@ -161,6 +161,8 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
     while (KC > 8 && (KC > round_up(maxC, 8) || conv_lds_bytes(l, KC) > 78 * 1024 ||
                       l.segC[0] % KC || (l.nseg > 1 && l.segC[1] % KC)))
         KC >>= 1;
+    if (l.mode == PACK_LSTM)
+        if (const char *e = getenv("VF_LSTM_KC")) KC = std::min(KC, std::max(8, atoi(e)));   // tuning knob
     if (l.prec == 1) KC = kBfKC;        // the split-bf16 tile stages 16-channel chunks
     l.KC = KC;
     for (int s = 0; s < 2; ++s) l.nchunk[s] = s < l.nseg ? (l.segC[s] + KC - 1) / KC : 0;
