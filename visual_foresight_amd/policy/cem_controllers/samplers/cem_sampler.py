@@ -1,37 +1,40 @@
-"""Sampler interface of the CEM controller (reference ``samplers/cem_sampler.py:7-55``)."""
+"""Interface between the CEM controller and its proposal distribution.
+
+Counterpart of the reference's ``visual_mpc/policy/cem_controllers/samplers/cem_sampler.py:7-55``.
+A sampler proposes float64 action sequences ``[M, T, adim]`` - once from scratch at the start of a
+planning call and once per refit - and keeps two histories the proposals may condition on: the
+actions that were actually executed and the tails of the elite plans at the time.
+"""
 import numpy as np
 
 
 class CEMSampler(object):
-    """Proposal distribution over action sequences ``[M, T, adim]``.
-
-    A sampler also keeps the history of executed actions (``chosen_actions``) and of the
-    remaining best plans, because some proposals are conditioned on what was executed.
-    """
-
     def __init__(self, hp, adim, sdim, **kwargs):
         self._hp = hp
-        self._adim, self.b_sdim = adim, sdim
-        self._chosen_actions = []
-        self._best_action_plans = []
-
-    def sample_initial_actions(self, t, nsamples, current_state):
-        """First proposal of a planning call -> float64 ``[nsamples, T, adim]``."""
-        raise NotImplementedError
-
-    def sample_next_actions(self, n_samples, best_actions, scores):
-        """Refit on the elites (ascending cost) and draw the next proposal."""
-        raise NotImplementedError
-
-    def log_best_action(self, action, best_action_plans):
-        """Record the executed action and the tails of the elite plans (ascending cost)."""
-        self._chosen_actions.append(action.copy())
-        self._best_action_plans.append(best_action_plans)
-
-    @property
-    def chosen_actions(self):
-        return np.array(self._chosen_actions)
+        self._adim = adim
+        self.b_sdim = sdim
+        self._chosen_actions = []       # one [adim] array per control step
+        self._best_action_plans = []    # per control step: [K, remaining T, adim] or None
 
     @staticmethod
     def get_default_hparams():
+        """Hyper-parameters this sampler adds to the controller's (name -> default)."""
         return {}
+
+    def sample_initial_actions(self, t, nsamples, current_state):
+        """First proposal of a planning call at time ``t`` -> ``[nsamples, T, adim]``."""
+        raise NotImplementedError
+
+    def sample_next_actions(self, n_samples, best_actions, scores):
+        """Refit on ``best_actions`` (ascending ``scores``) and draw ``[n_samples, T, adim]``."""
+        raise NotImplementedError
+
+    def log_best_action(self, action, best_action_plans):
+        """Remember the executed action and what is left of the elite plans after it."""
+        self._best_action_plans.append(best_action_plans)
+        self._chosen_actions.append(action.copy())
+
+    @property
+    def chosen_actions(self):
+        """Executed actions so far as one ``[t, adim]`` array."""
+        return np.array(self._chosen_actions)

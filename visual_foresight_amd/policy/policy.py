@@ -1,15 +1,15 @@
 """Policy base class and the agent -> policy argument binding.
 
-Mirrors the public surface of the reference's ``visual_mpc/policy/policy.py``:
+Same public surface as the reference's ``visual_mpc/policy/policy.py``:
 
-* ``get_policy_args`` (reference ``policy.py:9-46``): the agent never passes positional
-  arguments to ``policy.act``; it inspects the signature of ``act`` and fills every
-  parameter *by name* from the observation dict, the per-step agent data, or the
-  loop counters.  A parameter without a default that nobody can supply is an error.
-* ``Policy._override_defaults`` (reference ``policy.py:51-63``): applies a ``policyparams``
-  dict on top of the HParams defaults.  Two quirks are part of the contract because existing
-  experiment files depend on them: overriding with a value *equal* to the default raises
-  ``ValueError``, and parameters whose default is ``None`` are assigned without a type check.
+* ``get_policy_args`` (reference :9-46) - the agent never passes positional arguments to
+  ``policy.act``; it looks at the *names* of ``act``'s parameters and fills each one from the
+  observation dict, the per-step agent data or the loop counters.  A parameter nobody can
+  supply and that has no default is an error.
+* ``Policy._override_defaults`` (reference :51-63) - lays a ``policyparams`` dict over the HParams
+  defaults.  Two quirks are part of the contract because existing experiment files rely on
+  them: an override *equal* to the default raises ``ValueError``, and a parameter whose default
+  is ``None`` is assigned without a type check.
 """
 import abc
 import inspect
@@ -18,61 +18,60 @@ import numpy as np
 
 from visual_foresight_amd.hparams import HParams
 
-_EMPTY = inspect.Parameter.empty
+_MISSING = inspect.Parameter.empty
+
+
+def _lookup(name, default, obs, t, i_tr, step_data):
+    """Value for one ``act`` parameter, in the reference's precedence order."""
+    if name in obs:
+        return obs[name]
+    if step_data is not None and name in step_data:
+        return step_data[name]
+    specials = {'t': t, 'i_tr': i_tr, 'obs': obs, 'step_data': step_data}
+    if name in specials:
+        return specials[name]
+    if name == 'goal_pos':
+        return step_data['goal_pos']
+    return default
 
 
 def get_policy_args(policy, obs, t, i_tr, step_data=None):
-    """Build the kwargs dict for ``policy.act`` (reference ``policy.py:9-46``).
+    """kwargs for ``policy.act`` bound by parameter name (reference ``policy.py:9-46``).
 
-    Lookup order per parameter name: ``obs`` -> ``step_data`` -> the special names
-    ``t`` / ``i_tr`` / ``obs`` / ``step_data`` / ``goal_pos`` -> the parameter's default.
+    :param obs: observation dict of the agent (``images``, ``state``, ...)
+    :param step_data: per-step agent data (``desig_pix``, ``goal_pix``, ``verbose_worker``, ...)
     """
-    bound = {}
+    kwargs = {}
     for name, param in inspect.signature(policy.act).parameters.items():
-        if name in obs:
-            value = obs[name]
-        elif step_data is not None and name in step_data:
-            value = step_data[name]
-        elif name == 't':
-            value = t
-        elif name == 'i_tr':
-            value = i_tr
-        elif name == 'obs':
-            value = obs
-        elif name == 'step_data':
-            value = step_data
-        elif name == 'goal_pos':
-            value = step_data['goal_pos']
-        else:
-            value = param.default
-        if value is _EMPTY:
+        value = _lookup(name, param.default, obs, t, i_tr, step_data)
+        if value is _MISSING:
             raise ValueError("Required Policy Param {} not set in agent".format(name))
-        bound[name] = value
-    return bound
+        kwargs[name] = value
+    return kwargs
 
 
 class Policy(abc.ABC):
-    """Abstract policy: ``act`` returns a dict with at least the key ``'actions'``."""
-
-    def _override_defaults(self, policyparams):
-        for name, value in policyparams.items():
-            if name == 'type':          # 'type' names the policy class itself
-                continue
-            print('overriding param {} to value {}'.format(name, value))
-            # getattr -> AttributeError for names that are not hyper-parameters
-            if np.all(value == getattr(self._hp, name)):
-                raise ValueError("attribute is {} is identical to default value!!".format(name))
-            if name in self._hp and self._hp.get(name) is None:
-                setattr(self._hp, name, value)      # None default: no type to check against
-            else:
-                self._hp.set_hparam(name, value)
+    """``act`` returns a dict whose ``'actions'`` entry is the action for this time step."""
 
     def _default_hparams(self):
         return HParams()
 
+    def _override_defaults(self, policyparams):
+        hp = self._hp
+        for name, value in policyparams.items():
+            if name == 'type':                  # names the policy class, not a hyper-parameter
+                continue
+            print('overriding param {} to value {}'.format(name, value))
+            current = getattr(hp, name)         # AttributeError for names that are not hyper-parameters
+            if np.all(value == current):
+                raise ValueError("attribute is {} is identical to default value!!".format(name))
+            if name in hp and hp.get(name) is None:
+                setattr(hp, name, value)        # a None default carries no type to check against
+            else:
+                hp.set_hparam(name, value)
+
     @abc.abstractmethod
     def act(self, *args):
-        """Request the needed inputs as named parameters; return ``{'actions': ...}``."""
         raise NotImplementedError("Must be implemented in subclass.")
 
     def reset(self):
@@ -80,6 +79,8 @@ class Policy(abc.ABC):
 
 
 class DummyPolicy(object):
+    """Accepts the standard constructor arguments and does nothing."""
+
     def __init__(self, ag_params, policyparams, gpu_id, ngpu):
         pass
 
@@ -91,7 +92,7 @@ class DummyPolicy(object):
 
 
 class NullPolicy(Policy):
-    """Always returns a zero action (reference ``policy.py:97-118``)."""
+    """Zero action at every step (reference ``policy.py:97-118``)."""
 
     def __init__(self, ag_params, policyparams, gpu_id, ngpu):
         self._adim = ag_params['adim']
