@@ -325,3 +325,41 @@ def test_other_resolutions_and_action_state_dims(H, W, adim, sdim, T, M):
     assert np.abs(got['predicted_states'] - s).max() <= 1e-6
     want, _ = pixel_cost.eval_pixel_cost(d, goal, 10.)
     np.testing.assert_allclose(scores, want, rtol=1e-5)
+
+
+def test_config2_planning_call_elites_match_oracle():
+    """BASELINE configs[1] at full size: 200 samples x horizon 13 x 64x64, 3 CEM iterations.
+
+    The same controller is driven by the CPU oracle (host cost path of the reference) and by the
+    HIP predictor in both precision modes.  Iteration i+1 samples from the elites of iteration i,
+    so matching final elites means every iteration selected identically."""
+    from visual_foresight_amd.policy.cem_controllers import PixelCostController
+    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ag = {'adim': 4, 'sdim': 5, 'image_height': 64, 'image_width': 64}
+    base = {'nactions': 13, 'repeat': 1, 'rejection_sampling': False, 'verbose': False}
+    factory = lambda cfg: CdnaWeights.random(cfg, seed=0)
+    frames = np.random.RandomState(1).randint(0, 256, (2, 1, 64, 64, 3)).astype(np.uint8)
+    states = np.random.RandomState(2).normal(0, .1, (2, 5))
+
+    def run(predictor_class):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ctrl = PixelCostController(dict(ag), dict(base, predictor_class=predictor_class), 0, 1)
+            ctrl.reset()
+            np.random.seed(0)
+            ctrl.act(t=0, i_tr=0, desig_pix=[[32, 32]], goal_pix=[[16, 48]], images=frames[:1], state=states[:1])
+            out = ctrl.act(t=1, i_tr=0, desig_pix=[[32, 32]], goal_pix=[[16, 48]], images=frames, state=states)
+        return out, ctrl._best_indices.copy()
+
+    class HipSplit(HipVPredEvaluation):
+        def __init__(self, model_path, hparams, n_gpus=1, first_gpu=0):
+            super(HipSplit, self).__init__(model_path, dict(hparams, precision='bf16x6'), n_gpus, first_gpu)
+
+    ora, ora_idx = run(make_oracle_predictor_class(factory))
+    for cls in (HipVPredEvaluation, HipSplit):
+        hip, hip_idx = run(cls)
+        for itr in range(3):
+            key = 'scores_itr%d' % itr
+            np.testing.assert_allclose(hip['plan_stat'][key], ora['plan_stat'][key], rtol=1e-5)
+        np.testing.assert_array_equal(hip_idx, ora_idx)
+        np.testing.assert_array_equal(hip['actions'], ora['actions'])
