@@ -50,6 +50,9 @@ def parse():
     ap.add_argument('--ncam', type=int, default=1, help='views (BASELINE configs[2] uses 2)')
     ap.add_argument('--ndesig', type=int, default=1, help='designated pixels per view')
     ap.add_argument('--selection-frac', type=float, default=0.0)
+    ap.add_argument('--image-size', type=int, default=64, help='square frame size (BASELINE configs[4] uses 128)')
+    ap.add_argument('--latent-draws', type=int, default=0,
+                    help='stochastic predictor: z-draws per action (BASELINE configs[4] uses 5)')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--precision', choices=('fp32', 'bf16x6'), default=os.environ.get('VF_PRECISION', 'fp32'),
                     help='primary precision mode (the other one is reported as alt_precision)')
@@ -104,14 +107,15 @@ class Bench(object):
         if self.world != args.gpus and self.rank == 0:
             print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, self.world), file=sys.stderr)
         self.dev = torch.device('cuda', dev_index)
-        self.H = self.W = 64
+        self.H = self.W = args.image_size
         self.M = args.samples_per_gpu * (self.world if args.scaling == 'weak' else 1)
         # synthetic inputs: identical on every rank
         self.frames = np.random.RandomState(1).randint(0, 256, (2, args.ncam, self.H, self.W, 3)).astype(np.uint8)
         self.states = np.random.RandomState(2).normal(0, .1, (2, 5))
         npix = args.ncam * args.ndesig
-        self.desig = [[32 - 3 * i, 32 + 2 * i] for i in range(npix)]
-        self.goal = [[16 + 2 * i, 48 - 3 * i] for i in range(npix)]
+        k = self.H // 64 or 1
+        self.desig = [[k * (32 - 3 * i), k * (32 + 2 * i)] for i in range(npix)]
+        self.goal = [[k * (16 + 2 * i), k * (48 - 3 * i)] for i in range(npix)]
         # The sampler's 52x52 SVD / covariance refits are tiny: BLAS worker threads only add wake-up
         # latency there (several ms per CEM iteration on a 256-core host), so host math runs on 1 thread.
         # (a fresh guard per measurement: a threadpool_limits object restores the old limits on exit)
@@ -139,7 +143,10 @@ class Bench(object):
             ag_params['ncam'] = a.ncam
         # overrides equal to a default raise (reference policy.py:57-58), hence the conditionals
         policy = {'type': PixelCostController, 'repeat': 1, 'rejection_sampling': False, 'verbose': False}
-        if a.ncam == 1:
+        if a.latent_draws:
+            from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
+            policy['predictor_class'] = StochasticHipPredictor.with_options(n_latent=a.latent_draws)
+        elif a.ncam == 1:
             policy['predictor_class'] = HipVPredEvaluation      # (ncam > 1: the multi-view default)
         if a.samples_per_gpu != 200:
             policy['vpred_batch_size'] = max(a.samples_per_gpu, 1)
@@ -164,6 +171,7 @@ class Bench(object):
         a, torch = self.args, self.torch
         ctrl = self.build_controller(precision)
         prof_pred = ctrl.predictor.views[0] if hasattr(ctrl.predictor, 'views') else ctrl.predictor
+        prof_pred = getattr(prof_pred, 'engine', prof_pred)     # stochastic wrapper -> its engine
         score_time = [0.0]
         inner_score = ctrl.predictor.score
 
@@ -229,7 +237,7 @@ class Bench(object):
         T, iters = a.horizon, a.iterations
         primary = a.precision
         m = self.measure(primary)
-        frames_total = self.M * T * a.ncam * iters * a.steps
+        frames_total = self.M * max(a.latent_draws, 1) * T * a.ncam * iters * a.steps
         result = {
             'metric': 'predicted frames/sec (whole node), 200-sample x 13-step x 64x64 CEM',
             'value': frames_total / m['elapsed'], 'unit': 'frames/s', 'n_gpus': self.world, 'steps': a.steps,
@@ -243,6 +251,7 @@ class Bench(object):
                                    (a.samples_per_gpu, T, self.H, self.W, iters),
                        'num_samples': self.M, 'horizon': T, 'iterations': iters, 'views': a.ncam,
                        'designated_pixels_per_view': a.ndesig, 'precision': primary,
+                       'latent_draws_per_action': a.latent_draws,
                        'sharding': 'samples over %d rank(s)' % self.world},
             'roofline': self.roofline(m, primary),
             'host_ms_per_step_outside_predictor': m['host_ms'],
@@ -252,7 +261,8 @@ class Bench(object):
         # PMC run of this same command (tools/pmc_hbm.sh), when one exists for the default workload
         traffic_file = os.path.join(REPO, 'profiles', 'r01_c_hbm_traffic.json')
         if (os.path.exists(traffic_file) and getattr(m['prof_pred'], 'persistent', False) and self.M == 200
-                and T == 13 and iters == 3 and a.ncam * a.ndesig == 1 and primary == 'fp32'):
+                and T == 13 and iters == 3 and a.ncam * a.ndesig == 1 and primary == 'fp32'
+                and self.H == 64 and not a.latent_draws):
             with open(traffic_file) as f:
                 result['roofline']['traffic'] = json.load(f)['hbm_bytes_per_launch']
             result['roofline']['traffic_source'] = 'profiles/r01_c_hbm_traffic.json (rocprofv3 PMC, offline)'
@@ -274,11 +284,12 @@ class Bench(object):
 
         if self.rank == 0 and self.world == 1 and not a.no_cpu_baseline:
             ctrl = m['ctrl']
-            ctx = {'context_frames': self.frames[:, :1], 'context_actions': np.zeros((1, 4)),
+            adim = m['prof_pred'].cfg.adim          # 4 (+ zdim for the stochastic predictor)
+            ctx = {'context_frames': self.frames[:, :1], 'context_actions': np.zeros((1, adim)),
                    'context_states': self.states,
                    'context_pixel_distributions': ctrl._switch_on_pix(
                        np.array(self.desig).reshape(a.ncam, a.ndesig, 2))[:, :1]}
-            acts = np.random.RandomState(3).normal(0, 0.05, (a.cpu_samples, T, 4))
+            acts = np.random.RandomState(3).normal(0, 0.05, (a.cpu_samples, T, adim))
             result['cpu_baseline'] = cpu_baseline(m['prof_pred'].weights, ctx, acts,
                                                   np.array(self.goal[:a.ndesig]).reshape(1, -1, 2))
         elif self.rank == 0:

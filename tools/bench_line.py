@@ -1,8 +1,12 @@
 #!/usr/bin/env python
-"""Condense a bench.py JSON line (stdin) to one readable line."""
+"""Condense a bench.py JSON line to one readable line:  bench_line.py FILE [label]   (FILE '-' = stdin)."""
 import json
 import sys
-r = json.loads(sys.stdin.read().strip().splitlines()[-1])
+if len(sys.argv) < 2:
+    sys.exit('usage: bench_line.py FILE|- [label]')     # never block on a terminal-less stdin by accident
+src = sys.stdin if sys.argv[1] == '-' else open(sys.argv[1])
+r = json.loads(src.read().strip().splitlines()[-1])
+sys.argv = sys.argv[:1] + sys.argv[2:]
 rf = r['roofline']
 print('%s M=%d: %.0f frames/s  %.2f iters/s  %.1f ms/step | %s: %.1f TF/s frac %.3f  launches %d avg %.1f us  share %.3f host %.1f ms' % (
     sys.argv[1] if len(sys.argv) > 1 else '', r['config']['num_samples'], r['value'], r['cem_iters_per_sec'],

@@ -181,6 +181,37 @@ class HipVPredEvaluation(object):
             raise ValueError('actions must be [M, %d, %d], got %s' % (T, self.cfg.adim, actions.shape))
         return actions
 
+    def _score_local(self, context, actions, goal_pix, finalweight):
+        """Roll ALL given action sequences on this rank (no sharding) -> (scores, per_task) float64."""
+        torch = self._torch
+        actions = self._check_actions(actions)
+        nd = self.cfg.ndesig
+        goal = np.asarray(goal_pix).reshape(self.n_cam, nd, 2)[0]
+        n = actions.shape[0]
+        with torch.cuda.device(self.device):
+            self._set_context(context)
+            local = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32)).to(self.device)
+            scores = torch.empty(n, dtype=torch.float32, device=self.device)
+            per_task = torch.empty((n, nd), dtype=torch.float32, device=self.device)
+            bs = self.run_batch_size
+            for c0 in range(0, n, bs):
+                c1 = min(c0 + bs, n)
+                self._rollout_chunk(local[c0:c1], goal, finalweight, scores[c0:c1], per_task[c0:c1])
+                self._last_lo, self._last_M = c0, c1 - c0
+            return scores.cpu().numpy().astype(np.float64), per_task.cpu().numpy().astype(np.float64)
+
+    def fetch_pixel_distributions_local(self, local_index):
+        """Like fetch_pixel_distributions, for an index into the block passed to _score_local."""
+        torch, c = self._torch, self.cfg
+        T = self.sequence_length - self.n_context
+        k = local_index - self._last_lo
+        if not 0 <= k < self._last_M:
+            raise IndexError('sample %d is not resident' % local_index)
+        out = torch.zeros((T, c.height, c.width, c.ndesig), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._libh.vf_export(self._handle, int(k), 1, None, out.data_ptr(), None, self._stream()))
+        return out.cpu().numpy()[:, None]
+
     def score(self, context, inputs, goal_pix, finalweight=10., only_take_first_view=False):
         """Fused rollout + expected-pixel-distance cost.  Returns (scores[M], scores_per_task[M, nd]) float64.
 
