@@ -259,13 +259,13 @@ class Bench(object):
         }
         # HBM traffic cannot be counted from inside the process; it is taken from the committed rocprofv3
         # PMC run of this same command (tools/pmc_hbm.sh), when one exists for the default workload
-        traffic_file = os.path.join(REPO, 'profiles', 'r01_c_hbm_traffic.json')
+        traffic_file = os.path.join(REPO, 'profiles', 'r01_h_hbm_traffic.json')
         if (os.path.exists(traffic_file) and getattr(m['prof_pred'], 'persistent', False) and self.M == 200
                 and T == 13 and iters == 3 and a.ncam * a.ndesig == 1 and primary == 'fp32'
                 and self.H == 64 and not a.latent_draws):
             with open(traffic_file) as f:
                 result['roofline']['traffic'] = json.load(f)['hbm_bytes_per_launch']
-            result['roofline']['traffic_source'] = 'profiles/r01_c_hbm_traffic.json (rocprofv3 PMC, offline)'
+            result['roofline']['traffic_source'] = 'profiles/r01_h_hbm_traffic.json (rocprofv3 PMC, offline)'
 
         if not a.no_alt:
             other = 'bf16x6' if primary == 'fp32' else 'fp32'
