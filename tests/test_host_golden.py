@@ -260,3 +260,33 @@ def test_act_traces_match_reference(golden_dir):
             trace.append(ctrl._t_since_replan)
         assert trace == case['t_since_replan']
         assert list(fake.calls) == case['predictor_calls']
+
+
+def test_pred_util_context_and_chunking_match_reference(golden_dir):
+    """Row a13: get_context / rollout_predictions against outputs of the reference's pred_util."""
+    import types
+    from visual_foresight_amd.video_prediction.pred_util import get_context, rollout_predictions
+    g, meta = _arrays(golden_dir, 'pred_util'), _meta(golden_dir, 'pred_util')
+    images, state = g['ctx/images'], g['ctx/state']
+    f, s = get_context(2, 4, state, images, types.SimpleNamespace(state_append=[0.5, -1.0]))
+    assert f.dtype == np.float32 and f.shape == g['ctx/frames_out'].shape
+    np.testing.assert_array_equal(f, g['ctx/frames_out'])
+    np.testing.assert_array_equal(s, g['ctx/states_out'])
+    f3, s3 = get_context(2, 3, state, images, None)
+    np.testing.assert_array_equal(f3, g['ctx/frames_out_t3'])
+    np.testing.assert_array_equal(s3, g['ctx/states_out_t3'])
+
+    seen = []
+
+    def recording_predictor(input_images=None, input_state=None, input_actions=None, input_one_hot_images=None):
+        seen.append(np.array(input_actions))
+        b = input_actions.shape[0]
+        tag = input_actions.sum((1, 2))
+        return tag[:, None] * np.ones((b, 2)), tag[:, None] + np.ones((b, 3)), None
+
+    gi, gd, gs = rollout_predictions(recording_predictor, 200, g['roll/actions'], f, s, None)
+    assert [list(x.shape) for x in seen] == meta['chunk_shapes'] and len(seen) == meta['n_runs']
+    assert np.abs(seen[-1][50:]).sum() == g['roll/last_chunk_sum_padded_rows'][0] == 0.0
+    np.testing.assert_array_equal(np.concatenate(gi, 0), g['roll/gen_images'])
+    np.testing.assert_array_equal(np.concatenate(gd, 0), g['roll/gen_distrib'])
+    assert all(x is None for x in gs) == meta['gen_state_all_none']

@@ -181,23 +181,31 @@ class HipVPredEvaluation(object):
             raise ValueError('actions must be [M, %d, %d], got %s' % (T, self.cfg.adim, actions.shape))
         return actions
 
-    def _score_local(self, context, actions, goal_pix, finalweight):
-        """Roll ALL given action sequences on this rank (no sharding) -> (scores, per_task) float64."""
+    def _score_device(self, context, actions, goal_pix, finalweight, index_base=0):
+        """Roll ALL given action sequences on this rank -> device tensors (scores[n], per_task[n, nd]).
+
+        ``index_base`` is the global index of ``actions[0]`` (what ``fetch_pixel_distributions`` is asked for).
+        """
         torch = self._torch
-        actions = self._check_actions(actions)
         nd = self.cfg.ndesig
         goal = np.asarray(goal_pix).reshape(self.n_cam, nd, 2)[0]
         n = actions.shape[0]
-        with torch.cuda.device(self.device):
-            self._set_context(context)
-            local = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32)).to(self.device)
-            scores = torch.empty(n, dtype=torch.float32, device=self.device)
-            per_task = torch.empty((n, nd), dtype=torch.float32, device=self.device)
-            bs = self.run_batch_size
-            for c0 in range(0, n, bs):
-                c1 = min(c0 + bs, n)
-                self._rollout_chunk(local[c0:c1], goal, finalweight, scores[c0:c1], per_task[c0:c1])
-                self._last_lo, self._last_M = c0, c1 - c0
+        self._set_context(context)
+        local = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32)).to(self.device)
+        scores = torch.empty(n, dtype=torch.float32, device=self.device)
+        per_task = torch.empty((n, nd), dtype=torch.float32, device=self.device)
+        bs = self.run_batch_size
+        for c0 in range(0, n, bs):
+            c1 = min(c0 + bs, n)
+            self._rollout_chunk(local[c0:c1], goal, finalweight, scores[c0:c1], per_task[c0:c1])
+            self._last_lo, self._last_M = index_base + c0, c1 - c0
+        return scores, per_task
+
+    def _score_local(self, context, actions, goal_pix, finalweight):
+        """Like ``score`` but without sharding or collectives -> (scores, per_task) float64."""
+        actions = self._check_actions(actions)
+        with self._torch.cuda.device(self.device):
+            scores, per_task = self._score_device(context, actions, goal_pix, finalweight)
             return scores.cpu().numpy().astype(np.float64), per_task.cpu().numpy().astype(np.float64)
 
     def fetch_pixel_distributions_local(self, local_index):
@@ -219,23 +227,12 @@ class HipVPredEvaluation(object):
         ``M <= run_batch_size`` (the reference default, ``pixel_cost_controller.py:31``) that is
         the whole local shard.
         """
-        torch = self._torch
         actions = self._check_actions(inputs['actions'])
         M = actions.shape[0]
-        nd = self.cfg.ndesig
-        goal = np.asarray(goal_pix).reshape(self.n_cam, nd, 2)[0]
         rank, world = _dist_info()
         lo, hi = shard_bounds(M, rank, world)
-        with torch.cuda.device(self.device):
-            self._set_context(context)
-            local = torch.from_numpy(np.ascontiguousarray(actions[lo:hi], dtype=np.float32)).to(self.device)
-            scores = torch.empty(hi - lo, dtype=torch.float32, device=self.device)
-            per_task = torch.empty((hi - lo, nd), dtype=torch.float32, device=self.device)
-            bs = self.run_batch_size
-            for c0 in range(0, hi - lo, bs):
-                c1 = min(c0 + bs, hi - lo)
-                self._rollout_chunk(local[c0:c1], goal, finalweight, scores[c0:c1], per_task[c0:c1])
-                self._last_lo, self._last_M = lo + c0, c1 - c0
+        with self._torch.cuda.device(self.device):
+            scores, per_task = self._score_device(context, actions[lo:hi], goal_pix, finalweight, index_base=lo)
             if world > 1:
                 scores, per_task = self._all_gather(scores, per_task, M, world)
             scores_np = scores.cpu().numpy().astype(np.float64)
@@ -275,6 +272,50 @@ class HipVPredEvaluation(object):
             raise IndexError('sample %d is not resident (last chunk holds [%d, %d))'
                              % (sample_index, self._last_lo, self._last_lo + self._last_M))
         return out.cpu().numpy()[:, None]
+
+    def predictor_func(self):
+        """The legacy boundary (reference ``video_prediction/setup_predictor.py:164-200``): a callable
+
+            ``f(input_images=, input_one_hot_images=, input_state=, input_actions=) -> (gen_images, gen_distrib, gen_states)``
+
+        as ``rollout_predictions`` (``pred_util.py:21-48``) drives it.  ``input_images`` is the batch-1
+        float context ``[1, n_context, 1, H, W, 3]`` in [0, 1] (``get_context``), ``input_state``
+        ``[1, n_context, sdim]``, ``input_one_hot_images`` ``[1, n_context, 1, H, W, ndesig]`` or None and
+        ``input_actions`` ``[B, sequence_length (or sequence_length - 1), adim]`` whose first
+        ``n_context - 1`` steps are the executed actions (identical for every row, as the reference
+        tiles them).  Returns the ``sequence_length - n_context`` future frames
+        ``[B, T, 1, H, W, 3]``, distributions ``[B, T, 1, H, W, ndesig]`` (None without input
+        distributions) and states ``[B, T, sdim]``.
+        """
+        nc, c = self.n_context, self.cfg
+        T = self.sequence_length - nc
+
+        def predictor_func(input_images=None, input_one_hot_images=None, input_state=None, input_actions=None):
+            acts = np.asarray(input_actions, dtype=np.float64)
+            if acts.ndim != 3 or acts.shape[1] not in (self.sequence_length, self.sequence_length - 1):
+                raise ValueError('input_actions must be [B, %d, %d], got %s'
+                                 % (self.sequence_length, c.adim, acts.shape))
+            ctx_actions, future = acts[:, :nc - 1], acts[:, nc - 1:nc - 1 + T]
+            padding = ~acts.reshape(acts.shape[0], -1).any(axis=1)      # zero rows of a padded last chunk
+            if nc > 1 and not np.all((ctx_actions == ctx_actions[:1]).all(axis=(1, 2)) | padding):
+                raise ValueError('the first n_context-1 actions are context and must be the same for every row')
+            frames = np.asarray(input_images)[0]
+            if frames.dtype != np.uint8:        # get_context hands over float frames in [0, 1]
+                frames = np.rint(frames * 255.).astype(np.uint8)
+            if input_one_hot_images is None:
+                distrib = np.zeros((nc, 1, c.height, c.width, c.ndesig), np.float32)
+                distrib[:, :, 0, 0, :] = 1.0
+            else:
+                distrib = np.asarray(input_one_hot_images, dtype=np.float32)[0]
+            context = {'context_frames': frames, 'context_states': np.asarray(input_state)[0],
+                       'context_actions': ctx_actions[0] if nc > 1 else np.zeros((1, c.adim)),
+                       'context_pixel_distributions': distrib}
+            out = self(context, {'actions': future})
+            return (out['predicted_frames'],
+                    None if input_one_hot_images is None else out['predicted_pixel_distributions'],
+                    out['predicted_states'])
+
+        return predictor_func
 
     def __call__(self, context, inputs):
         """Reference-compatible path: materialise all predicted frames and distributions on the host."""
