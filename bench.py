@@ -42,8 +42,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: dense bf16 MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--samples-per-gpu', type=int, default=200)
     ap.add_argument('--horizon', type=int, default=13)
     ap.add_argument('--iterations', type=int, default=3)
@@ -196,8 +196,10 @@ class Bench(object):
             prof_pred.set_profiling(True)
             self.sync()
             t0 = time.perf_counter()
+            marks = [t0]
             for _ in range(a.steps):
-                out = plan()
+                out = plan()                    # synchronous: returns after the scores are back on the host
+                marks.append(time.perf_counter())
             self.sync()
             elapsed = time.perf_counter() - t0
             kernel_ms, launches, flops, busy_ms = prof_pred.get_profile()
@@ -206,7 +208,9 @@ class Bench(object):
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == 'nccl' else 'cpu')
             self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-        return dict(ctrl=ctrl, prof_pred=prof_pred, elapsed=elapsed, kernel_ms=kernel_ms, launches=launches,
+        per_call = 1e3 * np.diff(marks)
+        return dict(ctrl=ctrl, prof_pred=prof_pred, elapsed=elapsed,
+                    call_ms=[float(np.percentile(per_call, q)) for q in (50, 10, 90)], kernel_ms=kernel_ms, launches=launches,
                     flops=flops, busy_ms=busy_ms, host_ms=1e3 * (elapsed - score_time[0]) / a.steps,
                     elites=[int(i) for i in ctrl._best_indices],
                     best=float(np.min(out['plan_stat']['scores_itr%d' % (a.iterations - 1)])))
@@ -242,6 +246,7 @@ class Bench(object):
             'metric': 'predicted frames/sec (whole node), 200-sample x 13-step x 64x64 CEM',
             'value': frames_total / m['elapsed'], 'unit': 'frames/s', 'n_gpus': self.world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': 1e3 * m['elapsed'] / a.steps,
+            'ms_per_step_median_p10_p90': m['call_ms'],
             'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
             'dtype': 'f32' if primary == 'fp32' else 'f32 emulated by 6 bf16 MFMA products (fp32 accumulate)',
             'data': 'synthetic',
@@ -276,6 +281,7 @@ class Bench(object):
                          'fp32 accumulate); everything else fp32' if other == 'bf16x6' else 'exact fp32 MFMA'),
                 'value': frames_total / am['elapsed'], 'unit': 'frames/s',
                 'ms_per_step': 1e3 * am['elapsed'] / a.steps,
+                'ms_per_step_median_p10_p90': am['call_ms'],
                 'cem_iters_per_sec': iters * a.steps / am['elapsed'],
                 'roofline': self.roofline(am, other),
                 'elites_identical_to_primary': am['elites'] == m['elites'],

@@ -37,6 +37,18 @@
 
 namespace vf {
 
+#ifdef VF_TILE_STATS
+// Diagnostic build only (hipcc -DVF_TILE_STATS, read by tools/tile_stats.py): where a conv-LSTM item spends
+// its time.  [layer key][0] entry->first MFMA, [1] K loop, [2] epilogue, [3] items, [4] staging of later chunks;
+// row 15: [5] ticket fetch, [6] publish, [7] items of the persistent scheduler.
+__device__ unsigned long long g_tile_clk[16][8];
+#define VF_TS_NOW() (threadIdx.x == 0 ? wall_clock64() : 0ull)
+#define VF_TS_ADD(KEY_, SLOT_, DT_) do { if (threadIdx.x == 0) atomicAdd(&g_tile_clk[KEY_][SLOT_], (unsigned long long)(DT_)); } while (0)
+#else
+#define VF_TS_NOW() 0ull
+#define VF_TS_ADD(KEY_, SLOT_, DT_) do { } while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -251,6 +263,9 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
         tile_id = 0; ty0 = 0; tx0 = 0;
     }
 
+    [[maybe_unused]] const unsigned long long ts0 = VF_TS_NOW();
+    [[maybe_unused]] unsigned long long ts1 = 0, ts_stage = 0;
+    [[maybe_unused]] const int ts_key = (((p.seg[0].C + (p.nseg > 1 ? p.seg[1].C : 0)) >> 5) & 7) + (p.Hout >= 32 ? 0 : 8);
     // ---- LayerNorm statistics of the producing layers (this workgroup's samples only)
     for (int i = tid; i < p.nseg * p.NI; i += kConvThreads) {
         const int s = i / p.NI, img = i % p.NI;
@@ -328,6 +343,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
         const bool vec_ok = (sg.C & 3) == 0;
 
         __syncthreads();        // previous chunk fully consumed (and lnTab visible on entry)
+        [[maybe_unused]] const unsigned long long ts_s0 = VF_TS_NOW();
 #ifdef VF_EXP_NO_STAGE
         if (ci == ch_begin)
 #endif
@@ -371,6 +387,9 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
             if (ci == ch_begin) { VF_WRITEB(0) }
         }
         __syncthreads();
+#ifdef VF_TILE_STATS
+        if (ci == ch_begin) ts1 = VF_TS_NOW(); else ts_stage += VF_TS_NOW() - ts_s0;
+#endif
 
         const f32x4 *smem4 = reinterpret_cast<const f32x4 *>(smem);
         int ab4[MREP];                                              // in float4 units
@@ -447,7 +466,16 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #undef VF_LOADB
 #undef VF_WRITEB
 
+    [[maybe_unused]] const unsigned long long ts2 = VF_TS_NOW();
     conv_epilogue<G, EPI, MREP>(p, acc, bx, by, bz, red);
+#ifdef VF_TILE_STATS
+    if constexpr (EPI == EPI_LSTM) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts3 = VF_TS_NOW();
+        VF_TS_ADD(ts_key, 0, ts1 - ts0); VF_TS_ADD(ts_key, 1, ts2 - ts1); VF_TS_ADD(ts_key, 2, ts3 - ts2);
+        VF_TS_ADD(ts_key, 3, 1); VF_TS_ADD(ts_key, 4, ts_stage);
+    }
+#endif
 }
 
 template <int G, int EPI, int MREP>

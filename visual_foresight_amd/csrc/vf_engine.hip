@@ -1324,6 +1324,18 @@ int vf_debug_phase_stats(vf_handle *h, int32_t max_phases, int32_t *types, int32
     return n;
 }
 
+#ifdef VF_TILE_STATS
+int vf_debug_tile_clocks(uint64_t *out /*[16][8]*/, int32_t reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return fail(VF_ERR_HIP, "sync failed");
+    VF_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(vf::g_tile_clk), sizeof(uint64_t) * 128));
+    if (reset) {
+        static const uint64_t zeros[128] = {0};
+        VF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(vf::g_tile_clk), zeros, sizeof(zeros)));
+    }
+    return VF_OK;
+}
+#endif
+
 int vf_set_dedup(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->dedup = enable != 0;

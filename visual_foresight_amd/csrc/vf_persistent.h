@@ -144,6 +144,7 @@ __global__ __launch_bounds__(kConvThreads, WPS) void rollout_persistent_kernel(
     int ph = 0;
 
     for (;;) {
+        [[maybe_unused]] const unsigned long long ts_top = VF_TS_NOW();
         __syncthreads();                    // previous item fully retired (LDS reusable)
         if (tid == 0) s_ctl[0] = atomicAdd(sched.ticket, 1);
         __syncthreads();
@@ -156,6 +157,8 @@ __global__ __launch_bounds__(kConvThreads, WPS) void rollout_persistent_kernel(
         int b0, b1;
         item_samples(P, local, b0, b1);
         const unsigned long long t_start = sched.stats ? wall_clock64() : 0ull;
+        VF_TS_ADD(15, 5, VF_TS_NOW() - ts_top);         // ticket fetch + phase lookup
+        VF_TS_ADD(15, 7, 1);
 
         // ---- wait for the producers (wave 0 polls: lane i watches sample b0 + i, strided)
         if (wave == 0 && P.ndep > 0) {
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(kConvThreads, WPS) void rollout_persistent_kernel(
         }
 
         // ---- publish: drain this wave's stores, barrier, one release, then the counters
+        [[maybe_unused]] const unsigned long long ts_pub = VF_TS_NOW();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (sched.stats && tid == 0) {
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(kConvThreads, WPS) void rollout_persistent_kernel(
                                                __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        VF_TS_ADD(15, 6, VF_TS_NOW() - ts_pub);         // drain + barrier + release fence + counters (tid 0's view)
     }
 }
 
