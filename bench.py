@@ -212,8 +212,25 @@ class Bench(object):
         return dict(ctrl=ctrl, prof_pred=prof_pred, elapsed=elapsed,
                     call_ms=[float(np.percentile(per_call, q)) for q in (50, 10, 90)], kernel_ms=kernel_ms, launches=launches,
                     flops=flops, busy_ms=busy_ms, host_ms=1e3 * (elapsed - score_time[0]) / a.steps,
+                    rollouts=self.args.samples_per_gpu * max(a.latent_draws, 1) * a.iterations * a.steps,
                     elites=[int(i) for i in ctrl._best_indices],
                     best=float(np.min(out['plan_stat']['scores_itr%d' % (a.iterations - 1)])))
+
+    def survey_rate(self, m):
+        """SURVEY.md 8(d) accounting: every sample charged with all seq_len - 1 cell evaluations at the layer
+        table's MAC count, including the context step the engine runs once and shares (so >= `achieved`)."""
+        from visual_foresight_amd.video_prediction.cdna_arch import macs_per_sample_step
+        pred = m['prof_pred']
+        steps = pred.sequence_length - 1
+        if not m['launches'] or m['kernel_ms'] <= 0:
+            return None
+        rollouts_per_launch = m['rollouts'] / m['launches']
+        macs = float(sum(macs_per_sample_step(pred.cfg).values()))
+        flops = 2.0 * macs * steps * rollouts_per_launch
+        tf = flops / (1e-3 * m['kernel_ms'] / m['launches']) / 1e12
+        return {'flops_per_launch': flops, 'tflops': tf, 'frac_of_fp32_mfma_peak': tf / PEAK_FP32_MFMA_TFLOPS,
+                'what': '2 x %.3f GMAC per sample-step x %d steps x %d rollouts per launch / avg launch duration'
+                        % (macs / 1e9, steps, rollouts_per_launch)}
 
     def roofline(self, m, precision):
         persistent = getattr(m['prof_pred'], 'persistent', False)
@@ -226,6 +243,7 @@ class Bench(object):
              'achieved': tf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
              'frac': tf / PEAK_FP32_MFMA_TFLOPS if tf else None, 'traffic': None,
              'launches': m['launches'], 'avg_launch_us': 1e3 * m['kernel_ms'] / max(m['launches'], 1),
+             'survey_8d': self.survey_rate(m),
              'kernel_time_share': m['busy_ms'] * 1e-3 / m['elapsed']}
         if precision == 'bf16x6':
             # the same algorithmic (fp32-equivalent) FLOPs cost six bf16 MFMA FLOPs each in the
