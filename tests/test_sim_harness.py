@@ -53,3 +53,25 @@ def test_sim_with_hip_predictor_and_propagation(tmp_path):
     chosen = sim.policy._chosen_distrib
     assert chosen.shape == (4, 1, 32, 32, 1)
     np.testing.assert_allclose(chosen.sum(axis=(2, 3)), 1.0, atol=1e-5)
+
+
+def test_stochastic_predictor_host_logic():
+    """Latent draws fold into the sample axis draw-minor; context actions get zero latents (no GPU needed)."""
+    from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
+    cls = StochasticHipPredictor.with_options(n_latent=3, zdim=2, latent_seed=7)
+    assert cls.options == {'n_latent': 3, 'zdim': 2, 'latent_seed': 7} and StochasticHipPredictor.options == {}
+    p = cls.__new__(cls)            # host-side helpers only: the engine needs a GPU
+    p.n_latent, p.zdim, p.adim, p.latent_seed, p._calls = 3, 2, 4, 7, 0
+    z = p.draw_latents(5)
+    assert z.shape == (3, 5, 2)
+    np.testing.assert_array_equal(z, p.draw_latents(5))         # same planning call -> same draws
+    p._calls = 1
+    assert not np.array_equal(z, p.draw_latents(5))             # next planning call -> new draws
+    actions = np.arange(2 * 5 * 4, dtype=np.float64).reshape(2, 5, 4)
+    ctx, aug = p._augment({'context_actions': np.ones((1, 4))}, actions, z)
+    assert aug.shape == (6, 5, 6) and ctx['context_actions'].shape == (1, 6)
+    np.testing.assert_array_equal(ctx['context_actions'][0], [1, 1, 1, 1, 0, 0])
+    for m in range(2):
+        for d in range(3):
+            np.testing.assert_array_equal(aug[m * 3 + d, :, :4], actions[m])
+            np.testing.assert_array_equal(aug[m * 3 + d, :, 4:], z[d])
