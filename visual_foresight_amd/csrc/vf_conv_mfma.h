@@ -360,7 +360,11 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
                                    ((long long)iy * p.Win + ix) * sg.C + c;
                 const int nvalid = min(4, sg.C - c);
                 if (vec_ok) {
+#ifdef VF_EXP_STAGE_NOLOAD
+                    v = f32x4{(float)(it & 7), 1.f, 2.f, 3.f};
+#else
                     v = *reinterpret_cast<const f32x4 *>(src);
+#endif
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = (j < nvalid) ? src[j] : 0.f;
@@ -381,6 +385,9 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = (j < nvalid) ? v[j] : 0.f;
             }
+#ifdef VF_EXP_STAGE_NOWRITE
+            if (ci == ch_begin || v[0] == 12345.678f)
+#endif
             *reinterpret_cast<f32x4 *>(&smem[pix * KCpad + 4 * q]) = v;
         }
         if constexpr (kBLds) {
