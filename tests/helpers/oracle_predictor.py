@@ -3,7 +3,7 @@ import numpy as np
 import torch
 
 from oracle.cdna_predictor import OracleCdna
-from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights
+from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig
 
 
 def make_oracle_predictor_class(weights_factory, dtype=torch.float32):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """GPU box: accuracy of the two precision modes against the float64 oracle + elite agreement."""
-import os, sys, contextlib, io
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights

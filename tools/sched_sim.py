@@ -9,7 +9,6 @@ run times (tools/persist_stats.py, B=200, 128-row tiles).  Used to compare ticke
     python tools/sched_sim.py
 """
 import heapq
-import sys
 
 import numpy as np
 
