@@ -1,31 +1,44 @@
 #!/usr/bin/env python
 """Headline benchmark: visual-MPC CEM planning throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c4|c5] [--scaling strong|weak]
+
+With ``--gpus N > 1`` and no ``WORLD_SIZE`` in the environment the script launches its N ranks
+itself (child processes started BEFORE this process touches a GPU; RCCL when the box has N GPUs,
+gloo with the ranks sharing the GPUs it has otherwise) and rank 0 prints the line; under
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
 
 One "step" = one planning call ``policy.act()`` = one full CEM (reference
 ``cem_base_controller.py:85-116``): sample -> upload -> roll every candidate through the CDNA
 predictor -> pixel-distance cost on the device -> (all-gather) -> argsort -> refit, for
-``iterations=3`` CEM iterations.  Workload = BASELINE.json configs[1]: 200 samples x horizon 13
-x 64x64, pixel-distance cost, random-init CDNA predictor, synthetic context frames.  With
-``--gpus N`` each rank rolls 200 samples (weak scaling: 200*N candidates per CEM iteration,
-sharded by sample, one RCCL all-gather of the score rows per iteration).
+``iterations=3`` CEM iterations.  Every timed call sees a NEW context frame (a growing history, as
+in a real MPC loop), so the first rollout of each call pays for the context-only part of the
+network.  Workloads are BASELINE.json's configs:
+
+    c2 (default)  200 samples x horizon 13 x 64x64, pixel-distance cost           configs[1]
+    c1            32 samples x horizon 5, 1 CEM iteration (plumbing)               configs[0]
+    c3            2 views x 600 samples x horizon 13, flow-registration controller configs[2]
+    c4            1000 samples x horizon 15                                        configs[3]
+    c5            5 latent draws x 1000 actions x horizon 15 x 128x128             configs[4]
+
+``--scaling strong`` (default) keeps the workload's candidate count and shards it over the ranks
+(c2 on 8 GPUs = 25 samples per rank, the north-star target; c4 = 125 per rank); ``weak`` gives
+every rank the full count.  One all-gather of ``[M, 1 + tasks]`` score rows per CEM iteration.
 
 Prints ONE JSON line on rank 0: ``value`` = predicted frames / second over the whole job
-(M * T * views * iterations * K / wall) in the PRIMARY precision mode - exact fp32 MFMA - plus CEM
-iterations / second, the roofline of the dominant kernel measured with HIP events on the launch
-stream, and the CPU baseline (the oracle restatement timed on the host cores on a bounded sample;
-rank 0, N=1 only).  ``alt_precision`` repeats the timed loop with the conv-LSTM GEMMs in the
-split-bf16 mode (six bf16 MFMA products per multiply, fp32 accumulate, fp32-class accuracy; see
-csrc/vf_conv_bf16x6.h) and says whether it selected the same elites.
+(M * T * views * draws * iterations * K / wall, max over ranks) in exact fp32, CEM iterations /
+second, the roofline of the dominant kernel measured with HIP events on the launch stream, and the
+CPU baseline (the oracle restatement timed on the host cores, rank 0 at N=1 only).
+``alt_precision`` repeats the timed loop with the conv-LSTM GEMMs in the split-bf16 mode.
 """
 import argparse
 import contextlib
+import hashlib
 import io
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,51 +51,129 @@ if REPO not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: dense bf16 MFMA
 
+WORKLOADS = {
+    #      M     T  iters ncam ndesig size draws selection_frac  BASELINE.json config
+    'c1': (32, 5, 1, 1, 1, 64, 0, 0.0, 'configs[0]: sim cartgripper pixel-distance CEM plumbing case'),
+    'c2': (200, 13, 3, 1, 1, 64, 0, 0.0, 'configs[1]: CDNA predictor, pixel-distance cost'),
+    'c3': (600, 13, 3, 2, 2, 64, 0, 0.05, 'configs[2]: 2-view, flow-registration controller'),
+    'c4': (1000, 15, 3, 1, 1, 64, 0, 0.0, 'configs[3]: samples sharded across the GPUs, RCCL cost all-gather'),
+    'c5': (1000, 15, 3, 1, 1, 128, 5, 0.0, 'configs[4]: stochastic predictor, latent draws'),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--samples-per-gpu', type=int, default=200)
-    ap.add_argument('--horizon', type=int, default=13)
-    ap.add_argument('--iterations', type=int, default=3)
-    ap.add_argument('--ncam', type=int, default=1, help='views (BASELINE configs[2] uses 2)')
-    ap.add_argument('--ndesig', type=int, default=1, help='designated pixels per view')
-    ap.add_argument('--selection-frac', type=float, default=0.0)
-    ap.add_argument('--image-size', type=int, default=64, help='square frame size (BASELINE configs[4] uses 128)')
-    ap.add_argument('--latent-draws', type=int, default=0,
-                    help='stochastic predictor: z-draws per action (BASELINE configs[4] uses 5)')
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c2')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='strong')
+    ap.add_argument('--samples', type=int, default=0, help='override the workload\'s candidate count')
     ap.add_argument('--precision', choices=('fp32', 'bf16x6'), default=os.environ.get('VF_PRECISION', 'fp32'),
                     help='primary precision mode (the other one is reported as alt_precision)')
     ap.add_argument('--no-alt', action='store_true', help='skip the alt_precision measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-samples', type=int, default=128)
     return ap.parse_args()
 
 
-def cpu_baseline(weights, ctx, actions, goal):
-    """Time the oracle (CPU restatement, PyTorch-CPU fp32) on a bounded sample of the workload."""
+# ----------------------------------------------------------------------------- self-launch
+def spawn_ranks(args):
+    """Start one child per rank (this process has not initialised any GPU and never will)."""
+    import socket
     import torch
-    from oracle.cdna_predictor import OracleCdna
-    from oracle import pixel_cost
-    # oneDNN convs on many tiny images stop scaling (and oversubscribe badly) beyond a few dozen
-    # threads, so the baseline uses at most 32 host cores and says so
-    cores = min(os.cpu_count() or 1, 32)
-    ora = OracleCdna(weights, torch.float32, threads=cores)
-    T = actions.shape[1]
-    ora.rollout(ctx['context_frames'], ctx['context_actions'], ctx['context_pixel_distributions'],
-                ctx['context_states'], actions[:1, :2])                                   # warm-up
-    t0 = time.perf_counter()
-    _, d, _ = ora.rollout(ctx['context_frames'], ctx['context_actions'],
-                          ctx['context_pixel_distributions'], ctx['context_states'], actions)
-    pixel_cost.eval_pixel_cost(d, goal, 10.)
-    dt = time.perf_counter() - t0
-    return {'value': actions.shape[0] * T / dt, 'unit': 'predicted frames/s', 'cores': cores,
-            'kind': 'port',
-            'sample': '%d of the workload\'s samples x %d steps, one rollout + cost, %.1f s'
-                      % (actions.shape[0], T, dt)}
+    have = torch.cuda.device_count()            # counting devices does not initialise the runtime
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if have < args.gpus:
+        # fewer GPUs than ranks (a 1-GPU box): the ranks share them and talk over gloo - a dry run of the
+        # sharding and the collective, not a scaling measurement; the line says so
+        env['VF_BENCH_BACKEND'] = 'gloo'
+    procs = []
+    for r in range(args.gpus):
+        renv = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=renv,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+def physical_cores():
+    try:
+        import psutil
+        return psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except ImportError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline():
+    """The CPU restatement (oracle, PyTorch-CPU fp32) behind the SAME controller on the host cores
+    (BASELINE.md section 3): one full C1 planning call, and one full CEM iteration of C2 with all 200
+    candidates (sample -> rollout -> cost -> argsort -> refit).  A bounded sample: the other two C2
+    iterations repeat the same work."""
+    import torch
+    from tests.helpers.oracle_predictor import make_oracle_predictor_class
+    from visual_foresight_amd.policy.cem_controllers import PixelCostController
+    from visual_foresight_amd.video_prediction.cdna_arch import CdnaWeights
+    cores = physical_cores()
+    torch.set_num_threads(cores)
+    factory = lambda cfg: CdnaWeights.random(cfg, seed=0)
+    frames = np.random.RandomState(1).randint(0, 256, (2, 1, 64, 64, 3)).astype(np.uint8)
+    states = np.random.RandomState(2).normal(0, .1, (2, 5))
+
+    def plan(M, T, iters):
+        pol = {'predictor_class': make_oracle_predictor_class(factory), 'repeat': 1, 'rejection_sampling': False,
+               'verbose': False}
+        if T != 5:                                      # an override equal to the default raises
+            pol['nactions'] = T
+        if M != 200:
+            pol['num_samples'] = M
+        if iters != 3:
+            pol['iterations'] = iters
+        with contextlib.redirect_stdout(io.StringIO()):
+            ctrl = PixelCostController({'adim': 4, 'sdim': 5, 'image_height': 64, 'image_width': 64}, pol, 0, 1)
+            ctrl.reset()
+            np.random.seed(0)
+            ctrl.act(t=0, i_tr=0, desig_pix=[[32, 32]], goal_pix=[[16, 48]], images=frames[:1], state=states[:1])
+            t0 = time.perf_counter()
+            ctrl.act(t=1, i_tr=0, desig_pix=[[32, 32]], goal_pix=[[16, 48]], images=frames, state=states)
+            return time.perf_counter() - t0
+
+    plan(12, 2, 1)                                          # warm-up (thread pool, oneDNN primitives)
+    t_c1 = plan(32, 5, 1)
+    t_c2 = plan(200, 13, 1)
+    return {'value': 200 * 13 / t_c2, 'unit': 'predicted frames/s', 'cores': cores, 'kind': 'port',
+            'sample': 'C2: one full CEM iteration of the workload (all 200 samples x 13 steps: sample, rollout, '
+                      'cost, argsort, refit) through the controller, %.1f s; torch threads = physical cores' % t_c2,
+            'cem_iters_per_sec': 1.0 / t_c2,
+            'c1': {'value': 32 * 5 / t_c1, 'unit': 'predicted frames/s', 'cem_iters_per_sec': 1.0 / t_c1,
+                   'sample': 'C1: the whole planning call (32 samples x horizon 5, 1 iteration), %.2f s' % t_c1},
+            'note': 'CPU restatement baseline (oracle/), reported, not the optimisation target; the literal '
+                    'TF1-CPU reference cannot run anywhere in this project (no TF, no video_prediction)'}
+
+
+# ----------------------------------------------------------------------------- the benchmark
+def library_hash():
+    """sha256 over the kernel sources: ties an offline PMC profile to the library it was taken from."""
+    from visual_foresight_amd import _lib
+    h = hashlib.sha256()
+    for path in _lib.SOURCES:
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def identity_warper(current, reference):
+    """Plug-in for the registration controller in the c3 workload: zero flow (the registration network is
+    not part of the reference snapshot; the device side - warp, window medians, warp error - still runs)."""
+    ncam, H, W = current.shape[:3]
+    return None, np.zeros((ncam, H, W, 2), np.float32), None
 
 
 class Bench(object):
@@ -107,21 +198,29 @@ class Bench(object):
         if self.world != args.gpus and self.rank == 0:
             print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, self.world), file=sys.stderr)
         self.dev = torch.device('cuda', dev_index)
-        self.H = self.W = args.image_size
-        self.M = args.samples_per_gpu * (self.world if args.scaling == 'weak' else 1)
-        # synthetic inputs: identical on every rank
-        self.frames = np.random.RandomState(1).randint(0, 256, (2, args.ncam, self.H, self.W, 3)).astype(np.uint8)
-        self.states = np.random.RandomState(2).normal(0, .1, (2, 5))
-        npix = args.ncam * args.ndesig
+        self.dev_index = dev_index
+        (M, self.T, self.iters, self.ncam, self.ndesig, size, self.draws, self.sel_frac,
+         self.workload_name) = WORKLOADS[args.workload]
+        if args.samples:
+            M = args.samples
+        self.H = self.W = size
+        self.M = M * (self.world if args.scaling == 'weak' else 1)
+        self.per_rank = -(-self.M // self.world)
+        # synthetic inputs, identical on every rank; the history grows by one frame per call
+        n_calls = 1 + args.warmup + args.steps
+        self.frames = np.random.RandomState(1).randint(0, 256, (1 + n_calls, self.ncam, self.H, self.W, 3)
+                                                       ).astype(np.uint8)
+        self.states = np.random.RandomState(2).normal(0, .1, (1 + n_calls, 5))
         k = self.H // 64 or 1
-        self.desig = [[k * (32 - 3 * i), k * (32 + 2 * i)] for i in range(npix)]
-        self.goal = [[k * (16 + 2 * i), k * (48 - 3 * i)] for i in range(npix)]
-        # The sampler's 52x52 SVD / covariance refits are tiny: BLAS worker threads only add wake-up
-        # latency there (several ms per CEM iteration on a 256-core host), so host math runs on 1 thread.
-        # (a fresh guard per measurement: a threadpool_limits object restores the old limits on exit)
+        ntask = self.ndesig // 2 if args.workload == 'c3' else self.ndesig      # c3: 1 task x (start, goal)
+        self.desig = [[k * (32 - 3 * i), k * (32 + 2 * i)] for i in range(self.ncam * ntask)]
+        self.goal = [[k * (16 + 2 * i), k * (48 - 3 * i)] for i in range(self.ncam * ntask)]
+        self.goal_image = np.random.RandomState(3).uniform(0, 1, (1, self.ncam, self.H, self.W, 3)).astype(np.float32)
 
     @staticmethod
     def blas_guard():
+        # The sampler's 52x52 SVD / covariance refits are tiny: BLAS worker threads only add wake-up latency
+        # there (several ms per CEM iteration on a 256-core host), so host math runs on 1 thread.
         try:
             from threadpoolctl import threadpool_limits
             return threadpool_limits(limits=1, user_api='blas')
@@ -135,34 +234,35 @@ class Bench(object):
         self.torch.cuda.synchronize(self.dev)
 
     def build_controller(self, precision):
-        from visual_foresight_amd.policy.cem_controllers import PixelCostController
+        from visual_foresight_amd.policy.cem_controllers import PixelCostController, RegisterGtruthController
         from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
-        a = self.args
         ag_params = {'adim': 4, 'sdim': 5, 'image_height': self.H, 'image_width': self.W}
-        if a.ncam != 1:
-            ag_params['ncam'] = a.ncam
+        if self.ncam != 1:
+            ag_params['ncam'] = self.ncam
         # overrides equal to a default raise (reference policy.py:57-58), hence the conditionals
-        policy = {'type': PixelCostController, 'repeat': 1, 'rejection_sampling': False, 'verbose': False}
-        if a.latent_draws:
+        cls = RegisterGtruthController if self.args.workload == 'c3' else PixelCostController
+        policy = {'type': cls, 'repeat': 1, 'rejection_sampling': False, 'verbose': False,
+                  'predictor_class': HipVPredEvaluation}
+        if self.args.workload == 'c3':
+            policy.update(registration_warper=identity_warper, register_region=True)
+        if self.draws:
             from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
-            policy['predictor_class'] = StochasticHipPredictor.with_options(n_latent=a.latent_draws)
-        elif a.ncam == 1:
-            policy['predictor_class'] = HipVPredEvaluation      # (ncam > 1: the multi-view default)
-        if a.samples_per_gpu != 200:
-            policy['vpred_batch_size'] = max(a.samples_per_gpu, 1)
-        if a.ndesig != 1:
-            policy['designated_pixel_count'] = a.ndesig
-        if a.selection_frac:
-            policy['selection_frac'] = a.selection_frac
-        if a.horizon != 5:
-            policy['nactions'] = a.horizon
+            policy['predictor_class'] = StochasticHipPredictor.with_options(n_latent=self.draws)
+        if self.per_rank != 200:
+            policy['vpred_batch_size'] = self.per_rank      # engine buffers sized for one rank's shard
+        if self.ndesig != 1:
+            policy['designated_pixel_count'] = self.ndesig
+        if self.sel_frac:
+            policy['selection_frac'] = self.sel_frac
+        if self.T != 5:
+            policy['nactions'] = self.T
         if self.M != 200:
             policy['num_samples'] = self.M
-        if a.iterations != 3:
-            policy['iterations'] = a.iterations
-        os.environ['VF_PRECISION'] = precision      # read by HipVPredEvaluation (also inside multi-view)
+        if self.iters != 3:
+            policy['iterations'] = self.iters
+        os.environ['VF_PRECISION'] = precision      # read by HipVPredEvaluation
         with contextlib.redirect_stdout(io.StringIO()):
-            ctrl = PixelCostController(ag_params, policy, 0, 1)
+            ctrl = cls(ag_params, policy, 0, 1)      # the predictor adds LOCAL_RANK itself
             ctrl.reset()
         return ctrl
 
@@ -170,57 +270,62 @@ class Bench(object):
         """Warm up, then time exactly --steps planning calls.  Returns the raw measurements."""
         a, torch = self.args, self.torch
         ctrl = self.build_controller(precision)
-        prof_pred = ctrl.predictor.views[0] if hasattr(ctrl.predictor, 'views') else ctrl.predictor
-        prof_pred = getattr(prof_pred, 'engine', prof_pred)     # stochastic wrapper -> its engine
+        pred = ctrl.predictor
         score_time = [0.0]
-        inner_score = ctrl.predictor.score
+        inner_score = pred.score
 
         def timed_score(*args_, **kw):
             t = time.perf_counter()
             out = inner_score(*args_, **kw)
             score_time[0] += time.perf_counter() - t
             return out
-        ctrl.predictor.score = timed_score
+        pred.score = timed_score
+        extra = {'goal_image': self.goal_image} if a.workload == 'c3' else {}
 
-        def plan():
-            return ctrl.act(t=1, i_tr=0, desig_pix=self.desig, goal_pix=self.goal, images=self.frames,
-                            state=self.states)
+        def plan(i):
+            # call i sees frames[0 .. i+1]: a new last frame (and state) every call, like a real MPC loop
+            return ctrl.act(t=i, i_tr=0, desig_pix=self.desig, goal_pix=self.goal, images=self.frames[:i + 1],
+                            state=self.states[:i + 1], **extra)
 
         np.random.seed(0)       # same candidate stream for every rank and every precision mode
         with contextlib.redirect_stdout(io.StringIO()), self.blas_guard():
-            ctrl.act(t=0, i_tr=0, desig_pix=self.desig, goal_pix=self.goal, images=self.frames[:1],
-                     state=self.states[:1])
-            for _ in range(a.warmup):
-                plan()
+            plan(0)                             # t = 0 < start_planning: no rollout (one context frame only)
+            for i in range(a.warmup):
+                plan(1 + i)
             score_time[0] = 0.0
-            prof_pred.set_profiling(True)
+            pred.set_profiling(True)
             self.sync()
             t0 = time.perf_counter()
             marks = [t0]
-            for _ in range(a.steps):
-                out = plan()                    # synchronous: returns after the scores are back on the host
+            for i in range(a.steps):
+                out = plan(1 + a.warmup + i)    # synchronous: returns after the scores are back on the host
                 marks.append(time.perf_counter())
             self.sync()
             elapsed = time.perf_counter() - t0
-            kernel_ms, launches, flops, busy_ms = prof_pred.get_profile()
-            prof_pred.set_profiling(False)
+            kernel_ms, launches, flops, busy_ms = pred.get_profile()
+            pred.set_profiling(False)
         if self.world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == 'nccl' else 'cpu')
             self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         per_call = 1e3 * np.diff(marks)
-        return dict(ctrl=ctrl, prof_pred=prof_pred, elapsed=elapsed,
-                    call_ms=[float(np.percentile(per_call, q)) for q in (50, 10, 90)], kernel_ms=kernel_ms, launches=launches,
-                    flops=flops, busy_ms=busy_ms, host_ms=1e3 * (elapsed - score_time[0]) / a.steps,
-                    rollouts=self.args.samples_per_gpu * max(a.latent_draws, 1) * a.iterations * a.steps,
+        lo, hi = 0, self.M
+        if self.world > 1:
+            from visual_foresight_amd.video_prediction.sharding import shard_bounds
+            lo, hi = shard_bounds(self.M, self.rank, self.world)
+        return dict(ctrl=ctrl, pred=pred, elapsed=elapsed,
+                    call_ms=[float(np.percentile(per_call, q)) for q in (50, 10, 90)], kernel_ms=kernel_ms,
+                    launches=launches, flops=flops, busy_ms=busy_ms,
+                    host_ms=1e3 * (elapsed - score_time[0]) / a.steps,
+                    rollouts=(hi - lo) * max(self.draws, 1) * self.ncam * self.iters * a.steps,
                     elites=[int(i) for i in ctrl._best_indices],
-                    best=float(np.min(out['plan_stat']['scores_itr%d' % (a.iterations - 1)])))
+                    best=float(np.min(out['plan_stat']['scores_itr%d' % (self.iters - 1)])))
 
     def survey_rate(self, m):
         """SURVEY.md 8(d) accounting: every sample charged with all seq_len - 1 cell evaluations at the layer
         table's MAC count, including the context step the engine runs once and shares (so >= `achieved`)."""
         from visual_foresight_amd.video_prediction.cdna_arch import macs_per_sample_step
-        pred = m['prof_pred']
+        pred = m['pred']
         steps = pred.sequence_length - 1
         if not m['launches'] or m['kernel_ms'] <= 0:
             return None
@@ -229,19 +334,18 @@ class Bench(object):
         flops = 2.0 * macs * steps * rollouts_per_launch
         tf = flops / (1e-3 * m['kernel_ms'] / m['launches']) / 1e12
         return {'flops_per_launch': flops, 'tflops': tf, 'frac_of_fp32_mfma_peak': tf / PEAK_FP32_MFMA_TFLOPS,
-                'what': '2 x %.3f GMAC per sample-step x %d steps x %d rollouts per launch / avg launch duration'
-                        % (macs / 1e9, steps, rollouts_per_launch)}
+                'what': '2 x %.3f GMAC per sample-step x %d steps x %d single-view rollouts per launch / avg launch '
+                        'duration' % (macs / 1e9, steps, rollouts_per_launch)}
 
     def roofline(self, m, precision):
-        persistent = getattr(m['prof_pred'], 'persistent', False)
         tf = m['flops'] / (m['kernel_ms'] * 1e-3) / 1e12 if m['kernel_ms'] > 0 else None
         r = {'bound': 'mfma',
-             'kernel': ('rollout_persistent_kernel (one launch per rollout: every conv-LSTM / conv / '
-                        'transposed-conv / FC tile of all steps; FLOPs = algorithmic MFMA work of the launch)'
-                        if persistent else
-                        'conv_mfma_kernel<4,EPI_LSTM> (fused conv-LSTM gate GEMM, one launch per layer per step)'),
+             'kernel': 'rollout_persistent_kernel (one launch per rollout of one rank\'s shard: every conv-LSTM / '
+                       'conv / transposed-conv / FC tile of all steps and views; FLOPs = the MFMA work the launch '
+                       'executes, context step counted once)',
              'achieved': tf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
              'frac': tf / PEAK_FP32_MFMA_TFLOPS if tf else None, 'traffic': None,
+             'traffic_measured_in_run': False,
              'launches': m['launches'], 'avg_launch_us': 1e3 * m['kernel_ms'] / max(m['launches'], 1),
              'survey_8d': self.survey_rate(m),
              'kernel_time_share': m['busy_ms'] * 1e-3 / m['elapsed']}
@@ -254,12 +358,28 @@ class Bench(object):
             r['bf16_mfma_frac_of_peak'] = 6.0 * tf / PEAK_BF16_MFMA_TFLOPS if tf else None
         return r
 
+    def attach_traffic(self, roof, precision):
+        """HBM bytes per launch cannot be counted from inside the process: they come from the committed
+        rocprofv3 PMC passes of this same command (tools/pmc_hbm.sh) and are only quoted when that profile
+        was taken from this very library (source hash) on this workload."""
+        path = os.path.join(REPO, 'profiles', 'r02_hbm_traffic.json')
+        if not os.path.exists(path):
+            return
+        with open(path) as f:
+            prof = json.load(f)
+        if (prof.get('lib_sources_sha16') == library_hash() and prof.get('workload') == self.args.workload
+                and prof.get('precision') == precision and self.world == 1 and not self.args.samples):
+            roof['traffic'] = prof['hbm_bytes_per_launch']
+            roof['traffic_source'] = 'profiles/r02_hbm_traffic.json (rocprofv3 PMC passes of this library, offline)'
+            roof['traffic_vs_algorithmic'] = prof.get('ratio_to_algorithmic')
+
     def run(self):
         a = self.args
-        T, iters = a.horizon, a.iterations
+        T, iters = self.T, self.iters
         primary = a.precision
         m = self.measure(primary)
-        frames_total = self.M * max(a.latent_draws, 1) * T * a.ncam * iters * a.steps
+        frames_total = self.M * max(self.draws, 1) * T * self.ncam * iters * a.steps
+        shared_gpus = self.world > 1 and self.backend != 'nccl'
         result = {
             'metric': 'predicted frames/sec (whole node), 200-sample x 13-step x 64x64 CEM',
             'value': frames_total / m['elapsed'], 'unit': 'frames/s', 'n_gpus': self.world, 'steps': a.steps,
@@ -269,26 +389,21 @@ class Bench(object):
             'dtype': 'f32' if primary == 'fp32' else 'f32 emulated by 6 bf16 MFMA products (fp32 accumulate)',
             'data': 'synthetic',
             'cem_iters_per_sec': iters * a.steps / m['elapsed'],
-            'config': {'workload': 'BASELINE configs[1]: CDNA predictor, %d samples/GPU x horizon %d x %dx%d, '
-                                   '%d CEM iters, pixel-distance cost, random-init weights' %
-                                   (a.samples_per_gpu, T, self.H, self.W, iters),
-                       'num_samples': self.M, 'horizon': T, 'iterations': iters, 'views': a.ncam,
-                       'designated_pixels_per_view': a.ndesig, 'precision': primary,
-                       'latent_draws_per_action': a.latent_draws,
-                       'sharding': 'samples over %d rank(s)' % self.world},
+            'config': {'workload': 'BASELINE %s: %d samples (%d per rank) x horizon %d x %dx%d, %d CEM iters, '
+                                   'random-init weights, a new context frame per planning call' %
+                                   (self.workload_name, self.M, self.per_rank, T, self.H, self.W, iters),
+                       'workload_id': a.workload, 'num_samples': self.M, 'samples_per_rank': self.per_rank,
+                       'horizon': T, 'iterations': iters, 'views': self.ncam,
+                       'designated_pixels_per_view': self.ndesig, 'precision': primary,
+                       'latent_draws_per_action': self.draws,
+                       'sharding': 'samples over %d rank(s), one all-gather of score rows per CEM iteration%s' %
+                                   (self.world, ' (gloo dry run: ranks share a GPU, not a scaling measurement)'
+                                    if shared_gpus else ' over RCCL' if self.world > 1 else '')},
             'roofline': self.roofline(m, primary),
             'host_ms_per_step_outside_predictor': m['host_ms'],
             'best_score_last_plan': m['best'],
         }
-        # HBM traffic cannot be counted from inside the process; it is taken from the committed rocprofv3
-        # PMC run of this same command (tools/pmc_hbm.sh), when one exists for the default workload
-        traffic_file = os.path.join(REPO, 'profiles', 'r01_h_hbm_traffic.json')
-        if (os.path.exists(traffic_file) and getattr(m['prof_pred'], 'persistent', False) and self.M == 200
-                and T == 13 and iters == 3 and a.ncam * a.ndesig == 1 and primary == 'fp32'
-                and self.H == 64 and not a.latent_draws):
-            with open(traffic_file) as f:
-                result['roofline']['traffic'] = json.load(f)['hbm_bytes_per_launch']
-            result['roofline']['traffic_source'] = 'profiles/r01_h_hbm_traffic.json (rocprofv3 PMC, offline)'
+        self.attach_traffic(result['roofline'], primary)
 
         if not a.no_alt:
             other = 'bf16x6' if primary == 'fp32' else 'fp32'
@@ -307,22 +422,17 @@ class Bench(object):
             }
 
         if self.rank == 0 and self.world == 1 and not a.no_cpu_baseline:
-            ctrl = m['ctrl']
-            adim = m['prof_pred'].cfg.adim          # 4 (+ zdim for the stochastic predictor)
-            ctx = {'context_frames': self.frames[:, :1], 'context_actions': np.zeros((1, adim)),
-                   'context_states': self.states,
-                   'context_pixel_distributions': ctrl._switch_on_pix(
-                       np.array(self.desig).reshape(a.ncam, a.ndesig, 2))[:, :1]}
-            acts = np.random.RandomState(3).normal(0, 0.05, (a.cpu_samples, T, adim))
-            result['cpu_baseline'] = cpu_baseline(m['prof_pred'].weights, ctx, acts,
-                                                  np.array(self.goal[:a.ndesig]).reshape(1, -1, 2))
+            result['cpu_baseline'] = cpu_baseline()
         elif self.rank == 0:
             result['cpu_baseline'] = None
         if self.rank == 0:
-            print(json.dumps(result))
+            print(json.dumps(result), flush=True)
         if self.world > 1:
             self.dist.destroy_process_group()
 
 
 if __name__ == '__main__':
-    Bench(parse()).run()
+    _args = parse()
+    if _args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(_args))
+    Bench(_args).run()

@@ -57,3 +57,39 @@ def tradeoff_loops(warperrs):
             for r in range(nreg):
                 out[c, p, r] = (1.0 / warperrs[c, p, r]) / total
     return out
+
+
+def bilinear_warp_loops(current, flow):
+    """warped[c, r, col] = bilinear sample of current[c] at pts[c, r, col] = (col + dx, row + dy), border-clamped.
+
+    The reference obtains ``warped`` and ``warp_pts`` from its registration network
+    (``register_gtruth_controller.py:64-66``, module absent from the snapshot); the network's
+    OUTPUT convention assumed here - a flow field in pixels, sampled bilinearly with clamped
+    coordinates - is this repo's definition (parity unpinned).  float32 arithmetic in the same
+    operation order as ``csrc/vf_small_kernels.h`` (``bilinear_clamped``), so the warp points and
+    hence the tracked pixels agree bit for bit.
+    """
+    cur = np.asarray(current, dtype=np.float32)
+    fl = np.asarray(flow, dtype=np.float32)
+    ncam, H, W = cur.shape[:3]
+    warped = np.zeros_like(cur)
+    pts = np.zeros((ncam, H, W, 2), np.float32)
+    f32 = np.float32
+    for c in range(ncam):
+        for r in range(H):
+            for col in range(W):
+                x = f32(col) + fl[c, r, col, 0]
+                y = f32(r) + fl[c, r, col, 1]
+                pts[c, r, col] = (x, y)
+                xc = min(max(x, f32(0)), f32(W - 1))
+                yc = min(max(y, f32(0)), f32(H - 1))
+                x0, y0 = int(np.floor(xc)), int(np.floor(yc))
+                x1, y1 = min(x0 + 1, W - 1), min(y0 + 1, H - 1)
+                fx, fy = f32(xc - f32(x0)), f32(yc - f32(y0))
+                a, b = cur[c, y0, x0].astype(np.float64), cur[c, y0, x1].astype(np.float64)
+                cc, d = cur[c, y1, x0].astype(np.float64), cur[c, y1, x1].astype(np.float64)
+                # fmaf(fx, b - a, a): the difference is rounded to float32, the fma is exact then rounded
+                top = (np.float64(fx) * np.float32(b - a).astype(np.float64) + a).astype(np.float32).astype(np.float64)
+                bot = (np.float64(fx) * np.float32(d - cc).astype(np.float64) + cc).astype(np.float32).astype(np.float64)
+                warped[c, r, col] = (np.float64(fy) * (bot - top).astype(np.float32).astype(np.float64) + top).astype(np.float32)
+    return warped, pts

@@ -1,0 +1,157 @@
+"""GPU tests of the C-ABI contract of include/vf_hip.h: in-band failure status, no allocation after
+vf_create, the RCCL all-gather entry point, and the product's multi-rank path on real hardware."""
+import ctypes
+import os
+import pickle
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+from oracle import pixel_cost                                           # noqa: E402
+from visual_foresight_amd import _lib                                   # noqa: E402
+from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights   # noqa: E402
+from visual_foresight_amd.video_prediction.sharding import shard_bounds              # noqa: E402
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(REPO, 'tests', 'helpers', 'gpu_rank_worker.py')
+
+
+def _small(bs=6, T=2, precision='fp32'):
+    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+    hp = dict(designated_pixel_count=1, run_batch_size=bs, adim=4, sdim=5, image_height=32, image_width=32,
+              sequence_length=T + 2, precision=precision)
+    pred = HipVPredEvaluation('', hp).restore()
+    rs = np.random.RandomState(1)
+    ctx = {'context_frames': rs.randint(0, 256, (2, 1, 32, 32, 3)).astype(np.uint8),
+           'context_actions': rs.normal(0, 0.05, (1, 4)), 'context_states': rs.normal(0, 0.1, (2, 5)),
+           'context_pixel_distributions': pixel_cost.one_hot_distrib([[[16, 16]]], 2, 1, 32, 32, 1)}
+    return pred, ctx, rs.normal(0, 0.1, (bs, T, 4))
+
+
+def test_device_failure_is_reported_in_band():
+    """A raised device status word (a tile gave up waiting) must turn every score into NaN and the Python
+    wrapper into an exception - never into elite candidates; reading the status re-arms the engine."""
+    pred, ctx, actions = _small()
+    good, _ = pred.score(ctx, {'actions': actions}, [[[3, 20]]])
+    _lib.check(pred._libh.vf_debug_poison_status(pred._handle))
+    with pytest.raises(_lib.VfError, match='device status 1'):
+        pred.score(ctx, {'actions': actions}, [[[3, 20]]])
+    # the raw C entry point: scores come back as NaN, the status stays raised until it is read
+    _lib.check(pred._libh.vf_debug_poison_status(pred._handle))
+    with torch.cuda.device(pred.device):
+        a = torch.from_numpy(actions.astype(np.float32)).to(pred.device)
+        sc = torch.zeros(len(actions), device=pred.device)
+        pt = torch.zeros((len(actions), 1), device=pred.device)
+        for _ in range(2):
+            pred._rollout_chunk(a, [[[3, 20]]], 10., sc, pt)
+            assert torch.isnan(sc).all() and torch.isnan(pt).all()
+    assert pred.device_status() == 1
+    assert pred.device_status() == 0
+    again, _ = pred.score(ctx, {'actions': actions}, [[[3, 20]]])
+    np.testing.assert_array_equal(again, good)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x6'])
+def test_nothing_is_allocated_after_create(precision):
+    """vf_hip.h: every device buffer is allocated in vf_create.  Repeated restore() (weight hot-swap), context
+    changes, ragged batches (schedule rebuilds) and exports leave the device's free memory untouched."""
+    pred, ctx, actions = _small(bs=8, precision=precision)
+    cfg = pred.cfg
+    pred(ctx, {'actions': actions[:3]})
+    free0 = None
+    for i in range(4):          # round 0 warms PyTorch's own caching allocator (tensor sizes of this loop)
+        pred.restore(CdnaWeights.random(cfg, seed=40 + i))
+        for n in (8, 5, 8, 1):
+            pred.score(ctx, {'actions': actions[:n]}, [[[3 + i, 20]]])
+        pred.fetch_pixel_distributions(0)
+        if i == 0:
+            torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info(pred.device)[0]
+    pred.restore(CdnaWeights.random(cfg, seed=40))
+    s, _ = pred.score(ctx, {'actions': actions}, [[[3, 20]]])
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(pred.device)[0] == free0
+    # a hot-swapped weight set is really in use: same scores as a fresh engine restored from it
+    fresh, _, _ = _small(bs=8, precision=precision)
+    fresh.restore(CdnaWeights.random(cfg, seed=40))
+    np.testing.assert_array_equal(fresh.score(ctx, {'actions': actions}, [[[3, 20]]])[0], s)
+
+
+def test_allgather_scores_entry_point():
+    """vf_allgather_scores with a caller-owned RCCL communicator (world size 1 on the one-GPU box: the
+    collective degenerates to a copy, which still exercises the dlopen binding and the call)."""
+    pred, ctx, actions = _small()
+    rccl = None
+    for cand in ('librccl.so.1', 'librccl.so', '/opt/rocm/lib/librccl.so'):
+        try:
+            rccl = ctypes.CDLL(cand)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip('no RCCL library to build a communicator with')
+    class NcclUniqueId(ctypes.Structure):           # nccl.h: struct { char internal[128]; }, passed by value
+        _fields_ = [('internal', ctypes.c_char * 128)]
+
+    uid = NcclUniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, NcclUniqueId, ctypes.c_int]
+    with torch.cuda.device(pred.device):
+        assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+        local = torch.arange(14, dtype=torch.float32, device=pred.device) * 0.5
+        out = torch.zeros(14, dtype=torch.float32, device=pred.device)
+        _lib.check(pred._libh.vf_allgather_scores(pred._handle, comm, local.data_ptr(), 14, out.data_ptr(),
+                                                  pred._stream()))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), local.cpu().numpy())
+        assert pred._libh.vf_allgather_scores(pred._handle, None, local.data_ptr(), 14, out.data_ptr(), None) == -1
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _launch(world, out_dir, num_samples, stochastic):
+    port = _free_port()
+    env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), str(out_dir),
+                               str(num_samples), '1' if stochastic else '0'], env=env)
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    return [pickle.load(open(os.path.join(out_dir, 'gpu_rank%d_of%d.pkl' % (r, world)), 'rb')) for r in range(world)]
+
+
+@pytest.mark.parametrize('num_samples,stochastic', [(23, False), (14, True)])
+def test_two_ranks_of_the_real_predictor_match_one(tmp_path, num_samples, stochastic):
+    """2 ranks x the real HIP predictor (deterministic and latent-draw) with predictor_propagation on: every
+    rank sees the single-process scores, elites, actions and propagated distributions bit for bit."""
+    single = _launch(1, tmp_path, num_samples, stochastic)[0]
+    ranks = _launch(2, tmp_path, num_samples, stochastic)
+    for r, res in enumerate(ranks):
+        lo, hi = shard_bounds(num_samples, r, 2)
+        assert res['rolled'] == hi - lo                     # each rank rolled only its own shard
+        for a, b in zip(res['log'], single['log']):
+            np.testing.assert_array_equal(a['action'], b['action'])
+            for k in b['plan_stat']:
+                np.testing.assert_array_equal(a['plan_stat'][k], b['plan_stat'][k])
+            for k in ('best', 'chosen'):
+                if b[k] is None:
+                    assert a[k] is None
+                else:
+                    np.testing.assert_array_equal(a[k], b[k])
+    assert single['log'][-1]['chosen'] is not None

@@ -177,7 +177,7 @@ def test_errors_are_loud():
     acts = torch.zeros((2, 3, 4), device='cuda')
     sc = torch.zeros(2, device='cuda')
     goal = (ctypes.c_int32 * 2)(0, 0)
-    assert lib.vf_rollout(h, acts.data_ptr(), 2, goal, ctypes.c_float(1.), sc.data_ptr(), None, None) == -4
+    assert lib.vf_rollout(h, acts.data_ptr(), 2, goal, ctypes.c_float(1.), None, sc.data_ptr(), None, None) == -4
     assert b'vf_load_weights' in lib.vf_last_error()
     bad = _lib.VfConfig(60, 64, 4, 5, 1, 2, 5, 10, 4, 0)
     h2 = ctypes.c_void_p()
@@ -213,7 +213,8 @@ def test_launch_strategies_are_bit_identical():
 
 
 def test_two_view_predictor_matches_per_view_oracle():
-    """BASELINE configs[2] shape in miniature: 2 views x 2 designated pixels, one engine per view."""
+    """BASELINE configs[2] shape in miniature: 2 views x 2 designated pixels, both views in one launch,
+    every launch strategy."""
     from visual_foresight_amd.video_prediction.multiview_predictor import MultiViewHipPredictor
     H = W = 32
     T, M, nd, ncam = 2, 6, 2, 2
@@ -230,21 +231,37 @@ def test_two_view_predictor_matches_per_view_oracle():
            'context_pixel_distributions': pixel_cost.one_hot_distrib(desig, 2, ncam, H, W, nd)}
     actions = rs.normal(0, 0.1, (M, T, 4))
     goal = rs.randint(0, H, (ncam, nd, 2))
-    scores, per_task = pred.score(ctx, {'actions': actions}, goal)
-    got = pred(ctx, {'actions': actions})
-    assert got['predicted_frames'].shape == (M, T, ncam, H, W, 3)
     want_d = []
+    oracle_frames = []
     for c in range(ncam):
-        view_ctx = MultiViewHipPredictor._view_context(ctx, c)
-        f, d, s = _oracle(weights[c], view_ctx, actions)
-        assert np.abs(got['predicted_frames'][:, :, c] - f[:, :, 0]).max() <= 1e-5
+        f, d, s = _oracle(weights[c], MultiViewHipPredictor.view_context(ctx, c), actions)
+        oracle_frames.append(f)
         want_d.append(d)
     want_d = np.concatenate(want_d, axis=2)
     want, want_pt = pixel_cost.eval_pixel_cost(want_d, goal, 10.)
-    np.testing.assert_allclose(per_task, want_pt, rtol=1e-5)        # camera-major task order
-    np.testing.assert_allclose(scores, want, rtol=1e-5)
-    best = pred.fetch_pixel_distributions(int(np.argmin(scores)))
-    assert best.shape == (T, ncam, H, W, nd)
+    first = None
+    for persistent, nsub in ((1, 1), (0, 1), (0, 2)):
+        pred.set_persistent(persistent)
+        pred.set_substreams(nsub)
+        scores, per_task = pred.score(ctx, {'actions': actions}, goal)
+        got = pred(ctx, {'actions': actions})
+        assert got['predicted_frames'].shape == (M, T, ncam, H, W, 3)
+        for c in range(ncam):
+            assert np.abs(got['predicted_frames'][:, :, c] - oracle_frames[c][:, :, 0]).max() <= 1e-5
+        dmax = want_d.max(axis=(3, 4), keepdims=True)
+        assert (np.abs(got['predicted_pixel_distributions'] - want_d) / dmax).max() <= 2e-5
+        np.testing.assert_allclose(per_task, want_pt, rtol=1e-5)        # camera-major task order
+        np.testing.assert_allclose(scores, want, rtol=1e-5)
+        best = pred.fetch_pixel_distributions(int(np.argmin(scores)))
+        assert best.shape == (T, ncam, H, W, nd)
+        np.testing.assert_array_equal(best, got['predicted_pixel_distributions'][int(np.argmin(scores))])
+        if first is None:
+            first = (scores, per_task, got['predicted_frames'])
+        else:       # the launch strategies agree bit for bit
+            np.testing.assert_array_equal(scores, first[0])
+            np.testing.assert_array_equal(per_task, first[1])
+            np.testing.assert_array_equal(got['predicted_frames'], first[2])
+        assert pred.device_status() == 0
 
 
 def test_shared_unit_cache_across_rollouts():
@@ -361,6 +378,9 @@ def test_config2_planning_call_elites_match_oracle():
         for itr in range(3):
             key = 'scores_itr%d' % itr
             np.testing.assert_allclose(hip['plan_stat'][key], ora['plan_stat'][key], rtol=1e-5)
+            gap = np.diff(np.sort(ora['plan_stat'][key]))[9]            # margin at the K / K+1 boundary (K = 10)
+            assert gap > 4 * np.abs(hip['plan_stat'][key] - ora['plan_stat'][key]).max(), \
+                'fixture seeds give an ambiguous elite boundary in iteration %d' % itr
         np.testing.assert_array_equal(hip_idx, ora_idx)
         np.testing.assert_array_equal(hip['actions'], ora['actions'])
 
@@ -382,6 +402,7 @@ def test_stochastic_predictor_mean_over_latent_draws():
     goal = np.array([[[4, 20]]])
     z = pred.draw_latents(T)
     scores, _ = pred.score(ctx, {'actions': actions}, goal)
+    assert scores.shape == (M,)
     # oracle: the same network with z appended to every action, mean over the draws
     ctx_o = dict(ctx, context_actions=np.concatenate([ctx['context_actions'], np.zeros((2, zd))], axis=1))
     aug = np.concatenate([np.repeat(actions, nl, axis=0), np.tile(z, (M, 1, 1))], axis=2)

@@ -68,7 +68,8 @@ def test_stochastic_predictor_host_logic():
     p._calls = 1
     assert not np.array_equal(z, p.draw_latents(5))             # next planning call -> new draws
     actions = np.arange(2 * 5 * 4, dtype=np.float64).reshape(2, 5, 4)
-    ctx, aug = p._augment({'context_actions': np.ones((1, 4))}, actions, z)
+    p._z = z
+    ctx, aug = p._prepare({'context_actions': np.ones((1, 4))}, actions)
     assert aug.shape == (6, 5, 6) and ctx['context_actions'].shape == (1, 6)
     np.testing.assert_array_equal(ctx['context_actions'][0], [1, 1, 1, 1, 0, 0])
     for m in range(2):

@@ -2,7 +2,6 @@
 """GPU box diagnostic: per-phase wait/run time of one persistent rollout (VF_PERSIST_STATS=1)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ['VF_PERSIST_STATS'] = '1'
 os.environ['VF_PERSISTENT'] = '1'
 import numpy as np, torch
 from visual_foresight_amd import _lib
@@ -11,14 +10,14 @@ from oracle import pixel_cost
 
 M, T = int(sys.argv[1]) if len(sys.argv) > 1 else 200, 13
 pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2)).restore()
+lib = _lib.load_library()
+_lib.check(lib.vf_set_phase_stats(pred._handle, 1))
 rs = np.random.RandomState(0)
 ctx = {'context_frames': rs.randint(0, 256, (2, 1, 64, 64, 3)).astype(np.uint8), 'context_actions': np.zeros((1, 4)),
        'context_states': np.zeros((2, 5)), 'context_pixel_distributions': pixel_cost.one_hot_distrib([[[32, 32]]], 2, 1, 64, 64, 1)}
 acts = rs.normal(0, 0.05, (M, T, 4))
 for _ in range(2):
     pred.score(ctx, {'actions': acts}, [[[16, 48]]])
-lib = _lib.load_library()
-lib.vf_debug_phase_stats.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]
 N = 400
 types, items, wr = (ctypes.c_int32 * N)(), (ctypes.c_int32 * N)(), (ctypes.c_uint64 * (2 * N))()
 n = lib.vf_debug_phase_stats(pred._handle, N, types, items, wr)

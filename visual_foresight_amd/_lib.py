@@ -17,10 +17,13 @@ SOURCES = [os.path.join(_HERE, 'csrc', f) for f in
            ('vf_engine.hip', 'vf_conv_mfma.h', 'vf_small_kernels.h', 'vf_persistent.h', 'vf_conv_bf16x6.h')] + \
           [os.path.join(REPO, 'include', 'vf_hip.h')]
 
+# every symbol include/vf_hip.h declares
 EXPORTS = ('vf_abi_version', 'vf_last_error', 'vf_weight_count', 'vf_create', 'vf_destroy',
-           'vf_load_weights', 'vf_set_context', 'vf_rollout', 'vf_export',
-           'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile', 'vf_set_substreams', 'vf_set_dedup', 'vf_set_persistent',
-           'vf_device_status')
+           'vf_load_weights', 'vf_set_context', 'vf_rollout', 'vf_export', 'vf_register',
+           'vf_allgather_scores', 'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile',
+           'vf_set_substreams', 'vf_set_dedup', 'vf_set_persistent', 'vf_device_status',
+           'vf_set_phase_stats', 'vf_debug_phase_stats', 'vf_debug_poison_status')
+ABI_VERSION = 3
 
 
 class VfError(RuntimeError):
@@ -30,7 +33,7 @@ class VfError(RuntimeError):
 class VfConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ('height', 'width', 'adim', 'sdim', 'ndesig', 'n_context', 'sequence_length',
-                 'num_masks', 'max_batch', 'device', 'precision')]
+                 'num_masks', 'max_batch', 'device', 'precision', 'ncam', 'n_draws')]
 
 
 def _hipcc():
@@ -89,7 +92,13 @@ def load_library():
     lib.vf_load_weights.argtypes = [P, P, ctypes.c_size_t]
     lib.vf_set_context.argtypes = [P, P, P, P, P, P]
     lib.vf_rollout.argtypes = [P, P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_float,
-                               P, P, P]
+                               ctypes.POINTER(ctypes.c_float), P, P, P]
+    lib.vf_register.argtypes = [P, P, P, P, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, P, P, P, P, P]
+    lib.vf_allgather_scores.argtypes = [P, P, P, ctypes.c_int32, P, P]
+    lib.vf_set_phase_stats.argtypes = [P, ctypes.c_int32]
+    lib.vf_debug_phase_stats.argtypes = [P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                         ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]
+    lib.vf_debug_poison_status.argtypes = [P]
     lib.vf_export.argtypes = [P, ctypes.c_int32, ctypes.c_int32, P, P, P, P]
     lib.vf_set_profiling.argtypes = [P, ctypes.c_int32]
     lib.vf_get_profile.argtypes = [P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
@@ -102,10 +111,12 @@ def load_library():
     lib.vf_set_persistent.restype = lib.vf_device_status.restype = ctypes.c_int
     lib.vf_set_profiling.restype = lib.vf_get_profile.restype = lib.vf_set_substreams.restype = ctypes.c_int
     for name in ('vf_create', 'vf_destroy', 'vf_load_weights', 'vf_set_context', 'vf_rollout',
-                 'vf_export'):
+                 'vf_export', 'vf_register', 'vf_allgather_scores', 'vf_set_phase_stats',
+                 'vf_debug_phase_stats', 'vf_debug_poison_status'):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.vf_abi_version() != 2:
-        raise VfError('libvf_hip.so ABI version %d, expected 2' % lib.vf_abi_version())
+    if lib.vf_abi_version() != ABI_VERSION:
+        raise VfError('libvf_hip.so ABI version %d, expected %d (stale build? run __graft_entry__.build())'
+                      % (lib.vf_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -178,7 +178,7 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx,
                 const int buf = gt & 1;
                 const int ao = (ky * LW + kx) * kBfRowUnits;
                 const bool more = gt + 1 < gtN;
-                if (more) { VF_LOADB16(VF_EXP_B(gt + 1)) }
+                if (more) { VF_LOADB16(gt + 1) }
                 bf16x8 a[3][MREP], bw[3][G];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
@@ -197,9 +197,7 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx,
                 VF_T(2, 0) VF_T(0, 2) VF_T(1, 1) VF_T(1, 0) VF_T(0, 1) VF_T(0, 0)
 #undef VF_T
                 if (more) { VF_WRITEB16(buf ^ 1) }
-#ifndef VF_EXP_NO_TAP_BARRIER
                 __syncthreads();
-#endif
             }
         }
     }

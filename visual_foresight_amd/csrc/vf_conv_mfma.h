@@ -23,18 +23,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-// Timing experiments only (tools/ubench/build_variants.sh): results are WRONG with any of these.
-#ifdef VF_EXP_NO_A
-#define VF_EXP_A(x) 0
-#else
-#define VF_EXP_A(x) (x)
-#endif
-#ifdef VF_EXP_NO_B
-#define VF_EXP_B(x) 0
-#else
-#define VF_EXP_B(x) (x)
-#endif
-
 namespace vf {
 
 #ifdef VF_TILE_STATS
@@ -344,9 +332,6 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 
         __syncthreads();        // previous chunk fully consumed (and lnTab visible on entry)
         [[maybe_unused]] const unsigned long long ts_s0 = VF_TS_NOW();
-#ifdef VF_EXP_NO_STAGE
-        if (ci == ch_begin)
-#endif
         for (int it = tid; it < items; it += kConvThreads) {
             const int pix = it / q4, q = it - pix * q4;
             const int img = pix / tile_px, r = pix - img * tile_px;
@@ -360,11 +345,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
                                    ((long long)iy * p.Win + ix) * sg.C + c;
                 const int nvalid = min(4, sg.C - c);
                 if (vec_ok) {
-#ifdef VF_EXP_STAGE_NOLOAD
-                    v = f32x4{(float)(it & 7), 1.f, 2.f, 3.f};
-#else
                     v = *reinterpret_cast<const f32x4 *>(src);
-#endif
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = (j < nvalid) ? src[j] : 0.f;
@@ -385,9 +366,6 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = (j < nvalid) ? v[j] : 0.f;
             }
-#ifdef VF_EXP_STAGE_NOWRITE
-            if (ci == ch_begin || v[0] == 12345.678f)
-#endif
             *reinterpret_cast<f32x4 *>(&smem[pix * KCpad + 4 * q]) = v;
         }
         if constexpr (kBLds) {
@@ -417,7 +395,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #define VF_FETCH_L(A_, B_, Q_)                                                                  \
             {                                                                                   \
                 _Pragma("unroll") for (int m = 0; m < MREP; ++m)                                \
-                    A_[m] = smem4[ab4[m] + VF_EXP_A(ao + (Q_) * 2)];                            \
+                    A_[m] = smem4[ab4[m] + ao + (Q_) * 2];                            \
                 _Pragma("unroll") for (int g = 0; g < G; ++g)                                   \
                     B_[g] = bsm[((buf * K8 + (Q_)) * 4 + g) * 64 + lane];                       \
             }
@@ -427,7 +405,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
                     const int buf = (gt - gt0) & 1;
                     const int ao = (ky * LW + kx) * kcp4;
                     const bool more = gt + 1 < gtN;
-                    if (more) { VF_LOADB(VF_EXP_B(gt + 1)) }
+                    if (more) { VF_LOADB(gt + 1) }
                     VF_FETCH_L(aP, bP, 0)
                     int q = 0;
                     for (; q + 2 <= K8; q += 2) {
@@ -451,8 +429,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #define VF_FETCH(A_, B_, IT_)                                                                   \
             {                                                                                   \
                 const int ao_ = (ky * LW + kx) * kcp4 + k8 * 2;                                 \
-                _Pragma("unroll") for (int m = 0; m < MREP; ++m) A_[m] = smem4[ab4[m] + VF_EXP_A(ao_)]; \
-                const float *wp_ = wchunk + (long long)VF_EXP_B(IT_) * wstep;                   \
+                _Pragma("unroll") for (int m = 0; m < MREP; ++m) A_[m] = smem4[ab4[m] + ao_]; \
+                const float *wp_ = wchunk + (long long)(IT_) * wstep;                             \
                 _Pragma("unroll") for (int g = 0; g < G; ++g)                                   \
                     B_[g] = *reinterpret_cast<const f32x4 *>(wp_ + g * 128);                    \
                 if (++k8 == K8) { k8 = 0; if (++kx == p.KW) { kx = 0; ++ky; } }                 \

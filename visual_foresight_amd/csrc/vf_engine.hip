@@ -4,7 +4,19 @@
 // Layer table and semantics: visual_foresight_amd/video_prediction/cdna_arch.py (the reference
 // repo holds no network code).  Boundary semantics replaced here:
 // visual_mpc/video_prediction/setup_predictor.py:98-114,164-200 and pred_util.py:4-48 of the
-// reference (context slicing, /255, batch-1 context broadcast, per-sample action batch).
+// reference (context slicing, /255, batch-1 context broadcast, per-sample action batch), the
+// per-view networks of vpred_model_interface.py:60-88 (one weight set per camera, outputs stacked
+// on a camera axis) and the registration arithmetic of
+// visual_mpc/policy/cem_controllers/register_gtruth_controller.py:54-173.
+//
+// Memory contract (include/vf_hip.h): every device buffer - packed weights included - is sized
+// from the config and allocated in vf_create(); later calls only fill them.  vf_rollout() never
+// synchronises the caller's stream: a changed schedule is staged in a ring of pinned host
+// buffers and uploaded with hipMemcpyAsync on that stream.
+//
+// -DVF_HOST_SELFTEST builds the same file for the host only (tools/host_selftest.cc, ASan/UBSan):
+// device allocations become address reservations and uploads become checksums, so the packer
+// and the schedule builder run - and are bounds-checked - without a GPU.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -14,6 +26,11 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
+
+#include <dlfcn.h>
+#ifdef VF_HOST_SELFTEST
+#include <sys/mman.h>
+#endif
 
 #include "../../include/vf_hip.h"
 #include "vf_conv_mfma.h"
@@ -39,6 +56,7 @@ static int fail(int code, const std::string &msg) {
 
 static const int kLstmSizes[7] = {32, 32, 64, 64, 128, 64, 32};
 static const int kMaxSubBatches = 8;
+static const int kSchedRing = 4;            // pinned staging buffers for schedule uploads
 
 // ------------------------------------------------------------------ canonical tensor table
 struct TensorDesc {
@@ -107,9 +125,11 @@ static const TensorDesc *find_tensor(const std::vector<TensorDesc> &t, const std
 
 // ------------------------------------------------------------------ one dense layer
 enum PackMode { PACK_PLAIN, PACK_LSTM, PACK_CONVT };
+static const int kNumConvLayers = 15;
 
-struct ConvLayer {
+struct ConvLayer {          // geometry only: shared by every view; the packed weights are per view
     std::string name;
+    int id = -1;                    // slot in ViewData::lw
     PackMode mode;
     int G;
     int Hin, Win, Hout, Wout;       // Hout/Wout: GEMM row grid
@@ -118,13 +138,18 @@ struct ConvLayer {
     int KC, nchunk[2];
     int mrep;                       // MFMA row blocks per wave: the workgroup covers 128 * mrep rows
     int prec = 0;                   // 1: split-bf16 tile (conv-LSTM only)
-    unsigned short *d_w16 = nullptr;
     int NI, TH, TW, RPI, tilesY, tilesX;
     int ncg, Cout;
     int nsplit, chunks_per_split, n_valid;
     int stats_nparts;               // partial sums this layer's epilogue writes per sample
     size_t lds_bytes;
-    float *d_w = nullptr, *d_b = nullptr;
+    size_t packed_w() const {       // floats of the packed fp32 weights (pack_weights)
+        return (size_t)(nchunk[0] + nchunk[1]) * KH * KW * (KC / 8) * 2 * ((size_t)ncg * G * 32) * 4;
+    }
+    size_t packed_w16() const {     // bf16 values of the 3-plane split weights (pack_weights_bf16x3)
+        return prec == 1 ? (size_t)(nchunk[0] + nchunk[1]) * KH * KW * ncg * 4 * 3 * 64 * 8 : 0;
+    }
+    size_t packed_b() const { return (size_t)ncg * G * 32; }
 };
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -161,8 +186,6 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
     while (KC > 8 && (KC > round_up(maxC, 8) || conv_lds_bytes(l, KC) > 78 * 1024 ||
                       l.segC[0] % KC || (l.nseg > 1 && l.segC[1] % KC)))
         KC >>= 1;
-    if (l.mode == PACK_LSTM)
-        if (const char *e = getenv("VF_LSTM_KC")) KC = std::min(KC, std::max(8, atoi(e)));   // tuning knob
     if (l.prec == 1) KC = kBfKC;        // the split-bf16 tile stages 16-channel chunks
     l.KC = KC;
     for (int s = 0; s < 2; ++s) l.nchunk[s] = s < l.nseg ? (l.segC[s] + KC - 1) / KC : 0;
@@ -282,9 +305,9 @@ static std::vector<float> pack_bias(const ConvLayer &l, const float *b) {
 
 using namespace vf;
 
-// Views of the engine's working buffers: one per sub-batch (offset to its first sample) and
-// one "shared" set of batch-1 buffers per sub-batch for tensors that are identical for every
-// sample (see run_steps).
+// Views of the engine's working buffers: one per (camera view, sub-batch) - offset to its first
+// sample - and one "shared" set of batch-1 buffers per (view, sub-batch) for tensors that are
+// identical for every sample (see emit_rollout).
 struct BatchView {
     float *enc0_o, *enc1_o, *enc2_o, *enc3_o, *enc4_o, *enc5_o, *enc6_o;
     float *c_state[7], *h_state[7][2];
@@ -295,42 +318,55 @@ struct BatchView {
     const float *actions;
 };
 
+// Device-resident parameters and context of one camera view (the reference's multi-view models
+// are one network per view sharing actions and states, vpred_model_interface.py:60-88).
+struct LayerW { float *w = nullptr, *b = nullptr; unsigned short *w16 = nullptr; };
+struct ViewData {
+    LayerW lw[kNumConvLayers];
+    float *ln_g[9] = {nullptr}, *ln_b[9] = {nullptr};
+    float *w_rgb = nullptr, *b_rgb = nullptr, *w_mask = nullptr, *b_mask = nullptr;
+    float *w_state = nullptr, *b_state = nullptr, *w_sa = nullptr, *b_fc = nullptr;
+    float *ctx_frames = nullptr, *ctx_distrib = nullptr;
+};
+
+struct AllocRec { void *p; size_t bytes; };
+
 // ------------------------------------------------------------------ the engine
 struct vf_handle {
     vf_config cfg;
     int H, W, T, S, ND, K;              // S = steps per rollout = T + n_context - 1
+    int ncam = 1, n_draws = 1;
     int ntiles;                         // composite tiles per image
     std::vector<TensorDesc> table;
+    size_t blob_floats = 0;             // canonical floats per view
     bool have_weights = false, have_context = false;
     int last_B = 0;
 
-    // layers
+    // layers (geometry)
     ConvLayer enc0, lstm[7], enc1, enc2, enc3, convt1, convt2, convt3, fc;
+    std::vector<ConvLayer *> layers;    // in slot order
+    std::vector<ViewData> views;
 
-    // small dense parameters on the device
-    float *d_ln_g[9] = {nullptr}, *d_ln_b[9] = {nullptr};
-    float *d_w_rgb = nullptr, *d_b_rgb = nullptr, *d_w_mask = nullptr, *d_b_mask = nullptr;
-    float *d_w_state = nullptr, *d_b_state = nullptr, *d_w_sa = nullptr, *d_b_fc = nullptr;
+    // context: frames / distributions [ncam][n_context][..] (views[v] points into them), states and
+    // executed actions shared by the views
+    float *ctx_frames_all = nullptr, *ctx_distrib_all = nullptr;
+    float *ctx_states = nullptr, *ctx_actions = nullptr;
 
-    // context
-    float *ctx_frames = nullptr, *ctx_distrib = nullptr, *ctx_states = nullptr, *ctx_actions = nullptr;
-
-    // activations
+    // activations, [ncam][max_batch] samples each
     float *enc0_o = nullptr, *enc1_o = nullptr, *enc2_o = nullptr, *enc3_o = nullptr;
     float *enc4_o = nullptr, *enc5_o = nullptr, *enc6_o = nullptr;
     float *c_state[7] = {nullptr}, *h_state[7][2] = {{nullptr}};
     double *st_enc0 = nullptr, *st_h[7] = {nullptr}, *st_enc6 = nullptr;
     float *sbias = nullptr, *fc_part = nullptr, *kern = nullptr;
-    size_t lstm_elems[7] = {0};
 
     // predictions of the last rollout
     float *frames_all = nullptr, *distrib_all = nullptr, *states_all = nullptr;
     double *sums = nullptr;
-    long long sums_step_stride = 0;
+    long long sums_step_stride = 0, sums_view_stride = 0;
 
-    std::vector<void *> allocs;
+    std::vector<AllocRec> allocs;
 
-    // batch-1 buffers for tensors shared by all samples of a sub-batch (context de-duplication)
+    // batch-1 buffers for tensors shared by all samples (context de-duplication): [view][sub-batch]
     bool dedup = true;
     std::vector<BatchView> shared_views;
 
@@ -340,19 +376,24 @@ struct vf_handle {
     float *actions_buf = nullptr;
     struct SchedCache {                 // device copy of one schedule + the key it was built for
         PhaseDesc *d_phases = nullptr;
-        int B = -1, groups = 0, offset = 0, items = 0, counters = 0, phases = 0;
+        int B = -1, items = 0, counters = 0, phases = 0;
         bool dedup = true;
-        int32_t goal[2 * kMaxDesig] = {0};
         double flops = 0.0;
         size_t lds = 0;
         std::vector<int> types, nitems;
     } sched[2];                         // [0]: full rollout, [1]: shared units skipped (cached)
     int last_sched = 0;
     size_t sched_capacity = 0, counter_capacity = 0;
-    int *d_sync = nullptr;              // [ticket, status, counters...]
-    unsigned long long *d_stats = nullptr;  // debugging aid (VF_PERSIST_STATS): per-phase wait/run ticks
-    int n_groups = 1, group_offset = 9;
+    PhaseDesc *stage[kSchedRing] = {nullptr};   // pinned host staging of schedule uploads
+    hipEvent_t stage_done[kSchedRing] = {nullptr};
+    bool stage_used[kSchedRing] = {false};
+    int stage_next = 0;
+    int *d_sync = nullptr;              // [ticket, counters...]
+    int *d_status = nullptr;            // sticky failure word of the persistent kernel
+    unsigned long long *d_stats = nullptr;  // per-phase wait/run ticks (vf_set_phase_stats)
+    bool phase_stats = false;
     int persist_wgs_per_cu = 2;
+    size_t max_lds = 0;                 // largest dynamic LDS any tile of this engine needs
 
     // cross-rollout cache of the shared (batch-1, context-only) units
     bool cache_shared = true, shared_valid = false;
@@ -364,22 +405,56 @@ struct vf_handle {
     std::vector<hipEvent_t> ev_join;
     hipEvent_t ev_fork = nullptr;
 
-    // optional per-launch timing of the conv-LSTM kernel (HIP events on the launch stream)
+    // optional per-launch timing of the dominant kernel (HIP events on the launch stream)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     double prof_flops = 0.0;        // algorithmic FLOPs of the launches bracketed so far
+
+    // RCCL, bound lazily by vf_allgather_scores
+    void *rccl_lib = nullptr;
+    int (*nccl_all_gather)(const void *, void *, size_t, int, void *, void *) = nullptr;
+
+#ifdef VF_HOST_SELFTEST
+    char *fake_base = nullptr;
+    size_t fake_used = 0, fake_size = 0;
+    unsigned long long upload_checksum = 0;
+#endif
 };
 
 namespace vf {
 
 template <typename T>
 static int dev_alloc(vf_handle *h, T **p, size_t n) {
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
     void *q = nullptr;
-    if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess)
-        return fail(VF_ERR_NOMEM, "hipMalloc of " + std::to_string(n * sizeof(T)) + " bytes failed");
-    h->allocs.push_back(q);
+#ifdef VF_HOST_SELFTEST
+    // address reservation only: the self-test never dereferences a "device" pointer
+    const size_t aligned = (bytes + 255) & ~(size_t)255;
+    if (h->fake_used + aligned > h->fake_size) return fail(VF_ERR_NOMEM, "self-test address space exhausted");
+    q = h->fake_base + h->fake_used;
+    h->fake_used += aligned;
+#else
+    if (hipMalloc(&q, bytes) != hipSuccess)
+        return fail(VF_ERR_NOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
+#endif
+    h->allocs.push_back({q, bytes});
     *p = reinterpret_cast<T *>(q);
+    return VF_OK;
+}
+
+// host -> device copy of freshly packed parameters (blocking; vf_load_weights only)
+static int dev_write(vf_handle *h, void *dst, const void *src, size_t bytes) {
+#ifdef VF_HOST_SELFTEST
+    const unsigned char *s = static_cast<const unsigned char *>(src);
+    unsigned long long acc = h->upload_checksum;
+    for (size_t i = 0; i < bytes; ++i) acc = acc * 1099511628211ull + s[i];
+    h->upload_checksum = acc;
+    (void)dst;
+#else
+    (void)h;
+    VF_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+#endif
     return VF_OK;
 }
 
@@ -395,6 +470,10 @@ static int validate(const vf_config *c) {
     if (c->num_masks != 10) return fail(VF_ERR_INVALID, "num_masks must be 10 in this build");
     if (c->max_batch < 1) return fail(VF_ERR_INVALID, "max_batch must be >= 1");
     if (c->precision != 0 && c->precision != 1) return fail(VF_ERR_INVALID, "precision must be 0 (fp32) or 1 (split bf16)");
+    if (c->ncam < 0 || c->ncam > kMaxCam) return fail(VF_ERR_INVALID, "ncam must be 1..4 (0 = 1)");
+    if (c->n_draws < 0) return fail(VF_ERR_INVALID, "n_draws must be >= 1 (0 = 1)");
+    if (c->n_draws > 1 && c->max_batch % c->n_draws)
+        return fail(VF_ERR_INVALID, "max_batch must be a multiple of n_draws");
     return VF_OK;
 }
 
@@ -411,21 +490,44 @@ static void init_layer(ConvLayer &l, const char *name, PackMode mode, int Hin, i
     l.chunks_per_split = l.nchunk[0] + l.nchunk[1];
 }
 
-static int upload(vf_handle *h, float **dst, const float *src, size_t n) {
-    int rc = dev_alloc(h, dst, n);
-    if (rc) return rc;
-    VF_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+// every kernel instance may be asked for up to h->max_lds bytes of dynamic LDS; the attribute is
+// per device, so it is (re)applied by every vf_create on that handle's device
+template <class K>
+static int allow_lds(K kernel, size_t bytes) {
+#ifndef VF_HOST_SELFTEST
+    VF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+#else
+    (void)kernel; (void)bytes;
+#endif
+    return VF_OK;
+}
+
+static int configure_kernels(vf_handle *h) {
+    const size_t n = h->max_lds;
+    int rc;
+    if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_LSTM, 1>, n))) return rc;
+    if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_LSTM, 2>, n))) return rc;
+    if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_BIAS_RELU, 1>, n))) return rc;
+    if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_RAW_STATS, 1>, n))) return rc;
+    if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_CONVT_RELU, 1>, n))) return rc;
+    if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_CONVT_RAW_STATS, 1>, n))) return rc;
+    if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_PARTIAL, 2>, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_bf16x6_kernel<1>, n))) return rc;
+    const size_t np = n + kCtlWords * sizeof(int);
+    if ((rc = allow_lds(&rollout_persistent_kernel<1, 2>, np))) return rc;
+    if ((rc = allow_lds(&rollout_persistent_kernel<2, 2>, np))) return rc;
+    if ((rc = allow_lds(&rollout_persistent_kernel<3, 2>, np))) return rc;
+    if ((rc = allow_lds(&rollout_persistent_kernel<4, 2>, np))) return rc;
+    if ((rc = allow_lds(&rollout_persistent_kernel<1, 3>, np))) return rc;
+    if ((rc = allow_lds(&rollout_persistent_kernel<2, 3>, np))) return rc;
+    if ((rc = allow_lds(&rollout_persistent_kernel<3, 3>, np))) return rc;
+    if ((rc = allow_lds(&rollout_persistent_kernel<4, 3>, np))) return rc;
     return VF_OK;
 }
 
 template <int G, int EPI, int MREP>
 static int launch_conv_m(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
-    static size_t configured = 0;
-    if (l.lds_bytes > configured) {
-        VF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<G, EPI, MREP>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes));
-        configured = l.lds_bytes;
-    }
     const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
     dim3 grid(tiles, l.ncg, l.nsplit);
     hipLaunchKernelGGL((conv_mfma_kernel<G, EPI, MREP>), grid, dim3(kConvThreads), l.lds_bytes, st, p);
@@ -433,22 +535,16 @@ static int launch_conv_m(const ConvLayer &l, const ConvParams &p, hipStream_t st
     return VF_OK;
 }
 
-// which (G, EPI, MREP) instances exist: LSTM in both tile heights, the FC with 256 rows (it has
-// few rows and a long K), every other layer with 128-row tiles
 template <int MREP>
 static int launch_lstm_bf16x6(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
-    static size_t configured = 0;
-    if (l.lds_bytes > configured) {
-        VF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_lstm_bf16x6_kernel<MREP>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes));
-        configured = l.lds_bytes;
-    }
     const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
     hipLaunchKernelGGL((conv_lstm_bf16x6_kernel<MREP>), dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     VF_HIP_CHECK(hipGetLastError());
     return VF_OK;
 }
 
+// which (G, EPI, MREP) instances exist: LSTM in both tile heights, the FC with 256 rows (it has
+// few rows and a long K), every other layer with 128-row tiles
 template <int G, int EPI>
 static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     if constexpr (EPI == EPI_LSTM) {
@@ -466,7 +562,7 @@ struct SegArg {
     const float *gamma, *beta; int gamma_mod; int relu;
 };
 
-static ConvParams make_params(const ConvLayer &l, int B, const SegArg &s0, const SegArg *s1) {
+static ConvParams make_params(const ConvLayer &l, const LayerW &w, int B, const SegArg &s0, const SegArg *s1) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
     const SegArg *sa[2] = {&s0, s1};
@@ -484,7 +580,7 @@ static ConvParams make_params(const ConvLayer &l, int B, const SegArg &s0, const
     p.Hin = l.Hin; p.Win = l.Win; p.Hout = l.Hout; p.Wout = l.Wout;
     p.KH = l.KH; p.KW = l.KW; p.stride = l.stride; p.pad = l.pad; p.KC = l.KC;
     p.NI = l.NI; p.TH = l.TH; p.TW = l.TW; p.RPI = l.RPI; p.tilesY = l.tilesY; p.tilesX = l.tilesX;
-    p.ncg = l.ncg; p.Cout = l.Cout; p.Wp = l.d_w; p.Wp16 = l.d_w16; p.bias = l.d_b;
+    p.ncg = l.ncg; p.Cout = l.Cout; p.Wp = w.w; p.Wp16 = w.w16; p.bias = w.b;
     p.chunks_per_split = l.chunks_per_split; p.n_valid = l.n_valid;
     p.stats_nparts = l.stats_nparts;
     return p;
@@ -530,23 +626,38 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     *out = nullptr;
     int rc = validate(cfg);
     if (rc) return rc;
+#ifndef VF_HOST_SELFTEST
     VF_HIP_CHECK(hipSetDevice(cfg->device));
+#endif
     vf_handle *h = new vf_handle();
     h->cfg = *cfg;
+    h->ncam = std::max(1, cfg->ncam);
+    h->n_draws = std::max(1, cfg->n_draws);
+    h->cfg.ncam = h->ncam; h->cfg.n_draws = h->n_draws;
     h->H = cfg->height; h->W = cfg->width; h->ND = cfg->ndesig; h->K = cfg->num_masks;
     h->T = cfg->sequence_length - cfg->n_context;
     h->S = h->T + cfg->n_context - 1;
     h->table = tensor_table(*cfg);
-    const int H = h->H, W = h->W, Bc = cfg->max_batch, ND = h->ND;
+    h->blob_floats = h->table.back().offset + h->table.back().size();
+    const int H = h->H, W = h->W, Bc = cfg->max_batch, ND = h->ND, NV = h->ncam;
+    const size_t BV = (size_t)Bc * NV;          // samples x views: rows of every per-sample buffer
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
     const int *L = kLstmSizes;
     h->ntiles = ((H + kCompTile - 1) / kCompTile) * ((W + kCompTile - 1) / kCompTile);
+#ifdef VF_HOST_SELFTEST
+    h->fake_size = (size_t)1 << 40;
+    void *base = mmap(nullptr, h->fake_size, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (base == MAP_FAILED) { delete h; return fail(VF_ERR_NOMEM, "self-test address reservation failed"); }
+    h->fake_base = static_cast<char *>(base);
+#endif
 
     // rows per LSTM workgroup: 128 (mrep 1) keeps items short - the per-sample dependency chain,
-    // not the MFMA rate, bounds a 200-sample rollout; VF_LSTM_MREP=2222222 selects 256-row tiles
+    // not the MFMA rate, bounds a 200-sample rollout
     int lstm_mrep[7] = {1, 1, 1, 1, 1, 1, 1};
+#ifdef VF_DEBUG_KNOBS
     if (const char *e = getenv("VF_LSTM_MREP"))
         for (int k = 0; k < 7 && e[k]; ++k) lstm_mrep[k] = e[k] == '2' ? 2 : 1;
+#endif
     init_layer(h->enc0, "enc0", PACK_PLAIN, H, W, H2, W2, 5, 5, 2, 1, 3, 0, 32, true);
     init_layer(h->lstm[0], "lstm1", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, 32, L[0], L[0], true, false, lstm_mrep[0], cfg->precision);
     init_layer(h->lstm[1], "lstm2", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[0], L[1], L[1], true, false, lstm_mrep[1], cfg->precision);
@@ -571,6 +682,14 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         f.nsplit = (total + f.chunks_per_split - 1) / f.chunks_per_split;
         f.n_valid = kTaps * h->K;
     }
+    h->layers = {&h->enc0, &h->lstm[0], &h->lstm[1], &h->enc1, &h->lstm[2], &h->lstm[3], &h->enc2, &h->enc3,
+                 &h->lstm[4], &h->convt1, &h->lstm[5], &h->convt2, &h->lstm[6], &h->convt3, &h->fc};
+    h->max_lds = (size_t)composite_lds_floats<kMaxDesig, 10>() * 4;
+    for (size_t i = 0; i < h->layers.size(); ++i) {
+        h->layers[i]->id = (int)i;
+        h->max_lds = std::max(h->max_lds, h->layers[i]->lds_bytes);
+    }
+    h->max_lds += 16;
 
 #define VF_ALLOC(ptr, n)                           \
     do {                                           \
@@ -578,53 +697,70 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         if (rc) { vf_destroy(h); return rc; }      \
     } while (0)
 
+    // ---- per-view parameters and context: sized from the layer plans, filled by vf_load_weights
     const int nc = cfg->n_context;
-    VF_ALLOC(h->ctx_frames, (size_t)nc * H * W * 3);
-    VF_ALLOC(h->ctx_distrib, (size_t)nc * H * W * ND);
+    const int nsa = cfg->adim + cfg->sdim;
+    h->views.resize(NV);
+    for (ViewData &vd : h->views) {
+        for (const ConvLayer *l : h->layers) {
+            VF_ALLOC(vd.lw[l->id].w, l->packed_w());
+            VF_ALLOC(vd.lw[l->id].b, l->packed_b());
+            if (l->prec == 1) VF_ALLOC(vd.lw[l->id].w16, l->packed_w16());
+        }
+        for (int i = 0; i < 9; ++i) {
+            const TensorDesc *g = find_tensor(h->table, "ln" + std::to_string(i + 1) + "/g");
+            VF_ALLOC(vd.ln_g[i], g->size());
+            VF_ALLOC(vd.ln_b[i], g->size());
+        }
+        VF_ALLOC(vd.w_rgb, 32 * 3); VF_ALLOC(vd.b_rgb, 3);
+        VF_ALLOC(vd.w_mask, 32 * (h->K + 1)); VF_ALLOC(vd.b_mask, h->K + 1);
+        VF_ALLOC(vd.w_state, (size_t)nsa * cfg->sdim); VF_ALLOC(vd.b_state, cfg->sdim);
+        VF_ALLOC(vd.w_sa, (size_t)nsa * L[3]); VF_ALLOC(vd.b_fc, kTaps * h->K);
+    }
+    VF_ALLOC(h->ctx_frames_all, (size_t)NV * nc * H * W * 3);
+    VF_ALLOC(h->ctx_distrib_all, (size_t)NV * nc * H * W * ND);
+    for (int v = 0; v < NV; ++v) {
+        h->views[v].ctx_frames = h->ctx_frames_all + (size_t)v * nc * H * W * 3;
+        h->views[v].ctx_distrib = h->ctx_distrib_all + (size_t)v * nc * H * W * ND;
+    }
     VF_ALLOC(h->ctx_states, (size_t)nc * cfg->sdim);
     VF_ALLOC(h->ctx_actions, (size_t)std::max(nc - 1, 1) * cfg->adim);
 
-    VF_ALLOC(h->enc0_o, (size_t)Bc * H2 * W2 * 32);
-    VF_ALLOC(h->enc1_o, (size_t)Bc * H4 * W4 * L[1]);
-    VF_ALLOC(h->enc2_o, (size_t)Bc * H8 * W8 * L[3]);
-    VF_ALLOC(h->enc3_o, (size_t)Bc * H8 * W8 * L[3]);
-    VF_ALLOC(h->enc4_o, (size_t)Bc * H4 * W4 * L[4]);
-    VF_ALLOC(h->enc5_o, (size_t)Bc * H2 * W2 * L[5]);
-    VF_ALLOC(h->enc6_o, (size_t)Bc * H * W * 32);
+    VF_ALLOC(h->enc0_o, BV * H2 * W2 * 32);
+    VF_ALLOC(h->enc1_o, BV * H4 * W4 * L[1]);
+    VF_ALLOC(h->enc2_o, BV * H8 * W8 * L[3]);
+    VF_ALLOC(h->enc3_o, BV * H8 * W8 * L[3]);
+    VF_ALLOC(h->enc4_o, BV * H4 * W4 * L[4]);
+    VF_ALLOC(h->enc5_o, BV * H2 * W2 * L[5]);
+    VF_ALLOC(h->enc6_o, BV * H * W * 32);
     const int lh[7] = {H2, H2, H4, H4, H8, H4, H2}, lw[7] = {W2, W2, W4, W4, W8, W4, W2};
     for (int k = 0; k < 7; ++k) {
-        h->lstm_elems[k] = (size_t)Bc * lh[k] * lw[k] * L[k];
-        VF_ALLOC(h->c_state[k], h->lstm_elems[k]);
-        VF_ALLOC(h->h_state[k][0], h->lstm_elems[k]);
-        VF_ALLOC(h->h_state[k][1], h->lstm_elems[k]);
-        VF_ALLOC(h->st_h[k], (size_t)Bc * h->lstm[k].stats_nparts * 2);
+        const size_t elems = BV * lh[k] * lw[k] * L[k];
+        VF_ALLOC(h->c_state[k], elems);
+        VF_ALLOC(h->h_state[k][0], elems);
+        VF_ALLOC(h->h_state[k][1], elems);
+        VF_ALLOC(h->st_h[k], BV * h->lstm[k].stats_nparts * 2);
     }
-    VF_ALLOC(h->st_enc0, (size_t)Bc * h->enc0.stats_nparts * 2);
-    VF_ALLOC(h->st_enc6, (size_t)Bc * h->convt3.stats_nparts * 2);
-    VF_ALLOC(h->sbias, (size_t)Bc * L[3]);
-    VF_ALLOC(h->fc_part, (size_t)h->fc.nsplit * Bc * kTaps * h->K);
-    VF_ALLOC(h->kern, (size_t)Bc * kTaps * h->K);
-    VF_ALLOC(h->frames_all, (size_t)Bc * h->T * H * W * 3);
-    VF_ALLOC(h->distrib_all, (size_t)Bc * h->T * H * W * ND);
-    VF_ALLOC(h->states_all, (size_t)Bc * h->T * cfg->sdim);
-    h->sums_step_stride = (long long)Bc * ND * h->ntiles * 2;
+    VF_ALLOC(h->st_enc0, BV * h->enc0.stats_nparts * 2);
+    VF_ALLOC(h->st_enc6, BV * h->convt3.stats_nparts * 2);
+    VF_ALLOC(h->sbias, BV * L[3]);
+    VF_ALLOC(h->fc_part, BV * h->fc.nsplit * kTaps * h->K);
+    VF_ALLOC(h->kern, BV * kTaps * h->K);
+    VF_ALLOC(h->frames_all, BV * h->T * H * W * 3);
+    VF_ALLOC(h->distrib_all, BV * h->T * H * W * ND);
+    VF_ALLOC(h->states_all, BV * h->T * cfg->sdim);
+    h->sums_view_stride = (long long)Bc * ND * h->ntiles * 2;
+    h->sums_step_stride = h->sums_view_stride * NV;
     VF_ALLOC(h->sums, (size_t)h->T * h->sums_step_stride);
     VF_ALLOC(h->actions_buf, (size_t)Bc * h->T * cfg->adim);
-    h->sched_capacity = ((size_t)h->S * 20 + 8) * kMaxSubBatches;
-    h->counter_capacity = ((size_t)h->S * 20 + 8) * ((size_t)Bc + kMaxSubBatches);
+    h->sched_capacity = ((size_t)h->S * 20 + 8) * NV;
+    h->counter_capacity = ((size_t)h->S * 20 + 8) * ((size_t)Bc + 1) * NV;
     VF_ALLOC(h->sched[0].d_phases, h->sched_capacity);
     VF_ALLOC(h->sched[1].d_phases, h->sched_capacity);
-    VF_ALLOC(h->d_sync, 2 + h->counter_capacity);
-    if (hipMemset(h->d_sync, 0, 2 * sizeof(int)) != hipSuccess) {
-        vf_destroy(h);
-        return fail(VF_ERR_HIP, "hipMemset of the scheduler words failed");
-    }
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
-            h->n_cu = prop.multiProcessorCount;
-    }
-    for (int i = 0; i < kMaxSubBatches; ++i) {
+    VF_ALLOC(h->d_sync, 1 + h->counter_capacity);
+    VF_ALLOC(h->d_status, 1);
+    VF_ALLOC(h->d_stats, h->sched_capacity * 2);
+    for (int i = 0; i < NV * kMaxSubBatches; ++i) {
         BatchView sv;
         memset(&sv, 0, sizeof(sv));
         VF_ALLOC(sv.enc0_o, (size_t)H2 * W2 * 32);
@@ -645,85 +781,125 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         h->shared_views.push_back(sv);
     }
 #undef VF_ALLOC
+#ifndef VF_HOST_SELFTEST
+    if (hipMemset(h->d_sync, 0, sizeof(int)) != hipSuccess || hipMemset(h->d_status, 0, sizeof(int)) != hipSuccess) {
+        vf_destroy(h);
+        return fail(VF_ERR_HIP, "hipMemset of the scheduler words failed");
+    }
+    for (int i = 0; i < kSchedRing; ++i) {
+        void *q = nullptr;
+        if (hipHostMalloc(&q, h->sched_capacity * sizeof(PhaseDesc), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&h->stage_done[i], hipEventDisableTiming) != hipSuccess) {
+            vf_destroy(h);
+            return fail(VF_ERR_NOMEM, "pinned staging buffer for the schedule failed");
+        }
+        h->stage[i] = static_cast<PhaseDesc *>(q);
+    }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+            h->n_cu = prop.multiProcessorCount;
+    }
+    if ((rc = configure_kernels(h))) { vf_destroy(h); return rc; }
+#endif
     *out = h;
     return VF_OK;
 }
 
 int vf_destroy(vf_handle *h) {
     if (!h) return VF_OK;
-    for (void *p : h->allocs) (void)hipFree(p);
+#ifdef VF_HOST_SELFTEST
+    if (h->fake_base) munmap(h->fake_base, h->fake_size);
+#else
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (const AllocRec &a : h->allocs) (void)hipFree(a.p);
+    for (int i = 0; i < kSchedRing; ++i) {
+        if (h->stage[i]) (void)hipHostFree(h->stage[i]);
+        if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
+    }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_join) (void)hipEventDestroy(e);
     for (hipStream_t s : h->sub_streams) (void)hipStreamDestroy(s);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->rccl_lib) dlclose(h->rccl_lib);
+#endif
     delete h;
     return VF_OK;
 }
 
-int vf_load_weights(vf_handle *h, const float *blob, size_t n_floats) {
-    if (!h || !blob) return fail(VF_ERR_INVALID, "null handle or blob");
-    const size_t want = h->table.back().offset + h->table.back().size();
+int vf_load_weights(vf_handle *h, const float *blob_all, size_t n_floats) {
+    if (!h || !blob_all) return fail(VF_ERR_INVALID, "null handle or blob");
+    const size_t want = h->blob_floats * h->ncam;
     if (n_floats != want)
         return fail(VF_ERR_INVALID, "weight blob has " + std::to_string(n_floats) + " floats, expected " +
-                                        std::to_string(want));
+                                        std::to_string(want) + " (" + std::to_string(h->ncam) + " view(s))");
+#ifndef VF_HOST_SELFTEST
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
+    // the previous weights may still be in use by a rollout in flight
+    VF_HIP_CHECK(hipDeviceSynchronize());
+#endif
     int rc;
     auto T = [&](const std::string &name) { return find_tensor(h->table, name); };
-    auto pack_layer = [&](ConvLayer &l) -> int {
-        const TensorDesc *w = T(l.name + "/w"), *b = T(l.name + "/b");
-        std::vector<float> wp, bp;
-        if (l.name == "cdna") {
-            wp = pack_weights(l, blob + w->offset, 1, 1, w->shape[0], w->shape[1]);
-            bp.assign((size_t)l.ncg * 32, 0.f);     // bias is added by cdna_finalize
-        } else if (l.name == "enc3") {
-            // only the enc2 rows go through the GEMM; the action/state rows become a per-sample bias
-            wp = pack_weights(l, blob + w->offset, 1, 1, w->shape[2], w->shape[3]);
-            bp = pack_bias(l, blob + b->offset);
-        } else {
-            wp = pack_weights(l, blob + w->offset, w->shape[0], w->shape[1], w->shape[2], w->shape[3]);
-            bp = pack_bias(l, blob + b->offset);
+    for (int view = 0; view < h->ncam; ++view) {
+        const float *blob = blob_all + (size_t)view * h->blob_floats;
+        ViewData &vd = h->views[view];
+        for (const ConvLayer *lp : h->layers) {
+            const ConvLayer &l = *lp;
+            const TensorDesc *w = T(l.name + "/w"), *b = T(l.name + "/b");
+            std::vector<float> wp, bp;
+            if (l.name == "cdna") {
+                wp = pack_weights(l, blob + w->offset, 1, 1, w->shape[0], w->shape[1]);
+                bp.assign(l.packed_b(), 0.f);       // bias is added by cdna_finalize
+            } else if (l.name == "enc3") {
+                // only the enc2 rows go through the GEMM; the action/state rows become a per-sample bias
+                wp = pack_weights(l, blob + w->offset, 1, 1, w->shape[2], w->shape[3]);
+                bp = pack_bias(l, blob + b->offset);
+            } else {
+                wp = pack_weights(l, blob + w->offset, w->shape[0], w->shape[1], w->shape[2], w->shape[3]);
+                bp = pack_bias(l, blob + b->offset);
+            }
+            if (wp.size() != l.packed_w() || bp.size() != l.packed_b())
+                return fail(VF_ERR_INVALID, "internal: packed size of " + l.name + " differs from its plan");
+            if ((rc = dev_write(h, vd.lw[l.id].w, wp.data(), wp.size() * sizeof(float)))) return rc;
+            if ((rc = dev_write(h, vd.lw[l.id].b, bp.data(), bp.size() * sizeof(float)))) return rc;
+            if (l.prec == 1) {
+                std::vector<unsigned short> w16 = pack_weights_bf16x3(l, blob + w->offset, w->shape[2], w->shape[3]);
+                if (w16.size() != l.packed_w16())
+                    return fail(VF_ERR_INVALID, "internal: split-bf16 size of " + l.name + " differs from its plan");
+                if ((rc = dev_write(h, vd.lw[l.id].w16, w16.data(), w16.size() * sizeof(unsigned short)))) return rc;
+            }
         }
-        int r = upload(h, &l.d_w, wp.data(), wp.size());
-        if (r) return r;
-        if (l.prec == 1) {
-            std::vector<unsigned short> w16 = pack_weights_bf16x3(l, blob + w->offset, w->shape[2], w->shape[3]);
-            if ((r = dev_alloc(h, &l.d_w16, w16.size()))) return r;
-            VF_HIP_CHECK(hipMemcpy(l.d_w16, w16.data(), w16.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        for (int i = 0; i < 9; ++i) {
+            const std::string n = "ln" + std::to_string(i + 1);
+            const TensorDesc *g = T(n + "/g"), *b = T(n + "/b");
+            if ((rc = dev_write(h, vd.ln_g[i], blob + g->offset, g->size() * sizeof(float)))) return rc;
+            if ((rc = dev_write(h, vd.ln_b[i], blob + b->offset, b->size() * sizeof(float)))) return rc;
         }
-        return upload(h, &l.d_b, bp.data(), bp.size());
-    };
-    ConvLayer *layers[] = {&h->enc0, &h->lstm[0], &h->lstm[1], &h->enc1, &h->lstm[2], &h->lstm[3], &h->enc2,
-                           &h->enc3, &h->lstm[4], &h->convt1, &h->lstm[5], &h->convt2, &h->lstm[6],
-                           &h->convt3, &h->fc};
-    for (ConvLayer *l : layers)
-        if ((rc = pack_layer(*l))) return rc;
-
-    for (int i = 0; i < 9; ++i) {
-        const std::string n = "ln" + std::to_string(i + 1);
-        const TensorDesc *g = T(n + "/g"), *b = T(n + "/b");
-        if ((rc = upload(h, &h->d_ln_g[i], blob + g->offset, g->size()))) return rc;
-        if ((rc = upload(h, &h->d_ln_b[i], blob + b->offset, b->size()))) return rc;
+        const TensorDesc *d;
+        d = T("rgb/w");   if ((rc = dev_write(h, vd.w_rgb, blob + d->offset, d->size() * sizeof(float)))) return rc;
+        d = T("rgb/b");   if ((rc = dev_write(h, vd.b_rgb, blob + d->offset, d->size() * sizeof(float)))) return rc;
+        d = T("masks/w"); if ((rc = dev_write(h, vd.w_mask, blob + d->offset, d->size() * sizeof(float)))) return rc;
+        d = T("masks/b"); if ((rc = dev_write(h, vd.b_mask, blob + d->offset, d->size() * sizeof(float)))) return rc;
+        d = T("state/w"); if ((rc = dev_write(h, vd.w_state, blob + d->offset, d->size() * sizeof(float)))) return rc;
+        d = T("state/b"); if ((rc = dev_write(h, vd.b_state, blob + d->offset, d->size() * sizeof(float)))) return rc;
+        d = T("cdna/b");  if ((rc = dev_write(h, vd.b_fc, blob + d->offset, d->size() * sizeof(float)))) return rc;
+        // enc3 rows [L3 .. L3+adim+sdim) x 64: the smeared action/state inputs
+        d = T("enc3/w");
+        const int L3 = kLstmSizes[3];
+        if ((rc = dev_write(h, vd.w_sa, blob + d->offset + (size_t)L3 * d->shape[3],
+                            (size_t)(h->cfg.adim + h->cfg.sdim) * d->shape[3] * sizeof(float))))
+            return rc;
     }
-    const TensorDesc *d;
-    d = T("rgb/w");   if ((rc = upload(h, &h->d_w_rgb, blob + d->offset, d->size()))) return rc;
-    d = T("rgb/b");   if ((rc = upload(h, &h->d_b_rgb, blob + d->offset, d->size()))) return rc;
-    d = T("masks/w"); if ((rc = upload(h, &h->d_w_mask, blob + d->offset, d->size()))) return rc;
-    d = T("masks/b"); if ((rc = upload(h, &h->d_b_mask, blob + d->offset, d->size()))) return rc;
-    d = T("state/w"); if ((rc = upload(h, &h->d_w_state, blob + d->offset, d->size()))) return rc;
-    d = T("state/b"); if ((rc = upload(h, &h->d_b_state, blob + d->offset, d->size()))) return rc;
-    d = T("cdna/b");  if ((rc = upload(h, &h->d_b_fc, blob + d->offset, d->size()))) return rc;
-    // enc3 rows [L3 .. L3+adim+sdim) x 64: the smeared action/state inputs
-    d = T("enc3/w");
-    const int L3 = kLstmSizes[3];
-    if ((rc = upload(h, &h->d_w_sa, blob + d->offset + (size_t)L3 * d->shape[3],
-                     (size_t)(h->cfg.adim + h->cfg.sdim) * d->shape[3])))
-        return rc;
+#ifndef VF_HOST_SELFTEST
     VF_HIP_CHECK(hipDeviceSynchronize());
+#endif
     h->have_weights = true;
     h->shared_valid = false;
     return VF_OK;
 }
 
+#ifndef VF_HOST_SELFTEST
 int vf_set_context(vf_handle *h, const uint8_t *d_frames, const float *d_states, const float *d_ctx_actions,
                    const float *d_ctx_distrib, void *stream) {
     if (!h || !d_frames || !d_states || !d_ctx_distrib) return fail(VF_ERR_INVALID, "null argument");
@@ -731,27 +907,29 @@ int vf_set_context(vf_handle *h, const uint8_t *d_frames, const float *d_states,
     if (nc > 1 && !d_ctx_actions) return fail(VF_ERR_INVALID, "context actions required when n_context > 1");
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int n_frames = nc * h->H * h->W * 3, n_d = nc * h->H * h->W * h->ND;
+    const int hw3 = h->H * h->W * 3, hwd = h->H * h->W * h->ND;
     const int n_s = nc * h->cfg.sdim, n_a = (nc - 1) * h->cfg.adim;
-    const int n = std::max(std::max(n_frames, n_d), std::max(n_s, n_a));
-    hipLaunchKernelGGL(set_context_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_frames, h->ctx_frames,
-                       n_frames, d_states, h->ctx_states, n_s, d_ctx_actions, h->ctx_actions, n_a,
-                       d_ctx_distrib, h->ctx_distrib, n_d);
+    const int n = std::max(std::max(nc * h->ncam * hw3, nc * h->ncam * hwd), std::max(n_s, n_a));
+    // [nc][ncam][..] of the caller -> [ncam][nc][..] (the views' context buffers are one allocation)
+    hipLaunchKernelGGL(set_context_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_frames, h->ctx_frames_all, nc,
+                       h->ncam, hw3, d_ctx_distrib, h->ctx_distrib_all, hwd, d_states, h->ctx_states, n_s,
+                       d_ctx_actions, h->ctx_actions, n_a);
     VF_HIP_CHECK(hipGetLastError());
     h->have_context = true;
     h->shared_valid = false;        // the shared units are functions of the context
     return VF_OK;
 }
+#endif
 
 }  // extern "C"
 
-static BatchView make_view(vf_handle *h, const float *d_actions, int b0) {
+static BatchView make_view(vf_handle *h, int view, const float *d_actions, int b0) {
     const vf_config &c = h->cfg;
     const int H = h->H, W = h->W, T = h->T, ND = h->ND;
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
     const int *L = kLstmSizes;
     const int lh[7] = {H2, H2, H4, H4, H8, H4, H2}, lw[7] = {W2, W2, W4, W4, W8, W4, W2};
-    const size_t b = (size_t)b0;
+    const size_t b = (size_t)view * c.max_batch + (size_t)b0;      // row of every [ncam][max_batch] buffer
     BatchView v;
     v.enc0_o = h->enc0_o + b * H2 * W2 * 32;
     v.enc1_o = h->enc1_o + b * H4 * W4 * L[1];
@@ -775,18 +953,19 @@ static BatchView make_view(vf_handle *h, const float *d_actions, int b0) {
     v.frames_all = h->frames_all + b * T * H * W * 3;
     v.distrib_all = h->distrib_all + b * T * H * W * ND;
     v.states_all = h->states_all + b * T * c.sdim;
-    v.sums = h->sums + b * ND * h->ntiles * 2;
-    v.actions = d_actions + b * T * c.adim;
+    v.sums = h->sums + (long long)view * h->sums_view_stride + (size_t)b0 * ND * h->ntiles * 2;
+    v.actions = d_actions + (size_t)b0 * T * c.adim;       // the views share the action sequences
     return v;
 }
 
 // ------------------------------------------------------------------ rollout emission
-// emit_rollout() walks the S steps of the predictor once and hands every unit of device work
-// to a sink, together with the units it depends on.  LaunchSink enqueues one kernel per unit
-// (stream order makes the dependencies implicit); ScheduleSink records the units as phases of
-// the persistent launch (vf_persistent.h) with explicit per-sample dependencies.
+// emit_rollout() walks the S steps of the predictor once for one view and hands every unit of
+// device work to a sink, together with the units it depends on.  LaunchSink enqueues one kernel
+// per unit (stream order makes the dependencies implicit); ScheduleSink records the units as
+// phases of the persistent launch (vf_persistent.h) with explicit per-sample dependencies.
 static const int kSkipped = 1 << 30;      // id of a unit whose cached result is reused
 
+#ifndef VF_HOST_SELFTEST
 struct LaunchSink {
     vf_handle *h;
     hipStream_t st;
@@ -823,7 +1002,7 @@ struct LaunchSink {
         hipLaunchKernelGGL(cdna_finalize_kernel, dim3(p.B), dim3(256), 0, st, p);
         return VF_OK;
     }
-    int composite(const CompositeParams &p, int ntiles, std::initializer_list<int>) {
+    int composite(const CompositeParams &p, int ntiles, int /*view*/, std::initializer_list<int>) {
         dim3 grid(ntiles, p.B);
         switch (p.ND) {
             case 1: hipLaunchKernelGGL((composite_kernel<1, 10>), grid, dim3(256), 0, st, p); break;
@@ -836,10 +1015,11 @@ struct LaunchSink {
     }
     static bool failed(int rc) { return rc != VF_OK; }
 };
+#endif
 
 struct ScheduleSink {
     std::vector<PhaseDesc> phases;
-    int next_ticket = 0, next_counter = 0;      // tickets are re-assigned when groups are merged
+    int next_ticket = 0, next_counter = 0;      // tickets are re-assigned when the views are merged
     double flops = 0.0;         // algorithmic FLOPs of all MFMA (conv / FC) phases
     size_t max_lds = 0;
 
@@ -895,10 +1075,10 @@ struct ScheduleSink {
         P.type = PH_CDNA_FIN; P.fin = p; P.B = p.B;
         return add(P, p.B, p.B, deps);
     }
-    int composite(const CompositeParams &p, int ntiles, std::initializer_list<int> deps) {
+    int composite(const CompositeParams &p, int ntiles, int view, std::initializer_list<int> deps) {
         PhaseDesc P;
         memset(&P, 0, sizeof(P));
-        P.type = PH_COMPOSITE; P.comp = p; P.B = p.B; P.gx = ntiles;
+        P.type = PH_COMPOSITE; P.comp = p; P.B = p.B; P.gx = ntiles; P.view = view;
         return add(P, ntiles * p.B, p.B, deps);
     }
     static bool failed(int rc) { return rc < 0; }
@@ -915,14 +1095,21 @@ struct ScheduleSink {
 // The shared units depend only on the context and the weights, so they are also cached ACROSS
 // rollouts: the CEM iterations of one planning call keep the same context, and every rollout
 // after the first skips them (`skip_shared`) and reads the shared buffers of the first.
+//
+// goal_pix: this view's [ND][2] goal pixels (only the per-layer composite kernel reads them from
+// its parameters; the persistent kernel receives all goals as launch arguments).
 template <class Sink>
-static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, int B, const int32_t *goal_pix,
-                        Sink &sink, bool skip_shared) {
+static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchView &sh, int B,
+                        const int32_t *goal_pix, Sink &sink, bool skip_shared) {
     const vf_config &c = h->cfg;
+    const ViewData &vd = h->views[view];
     const int H = h->H, W = h->W, T = h->T, ND = h->ND, nc = c.n_context;
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
     const int *L = kLstmSizes;
     const int lh[7] = {H2, H2, H4, H4, H8, H4, H2}, lw[7] = {W2, W2, W4, W4, W8, W4, W2};
+    auto params = [&](const ConvLayer &l, int Bp, const SegArg &s0, const SegArg *s1) {
+        return make_params(l, vd.lw[l.id], Bp, s0, s1);
+    };
 
     auto all_shared = [&](int s) { return h->dedup && s < nc - 1; };
     auto enc_shared = [&](int s) { return h->dedup && s < nc; };
@@ -963,7 +1150,7 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
         if (s < nc) { sp.state = h->ctx_states + (size_t)s * c.sdim; sp.state_bstride = 0; }
         else { sp.state = v.states_all + (size_t)(s - nc) * c.sdim; sp.state_bstride = (long long)T * c.sdim; }
         sp.adim = c.adim; sp.sdim = c.sdim; sp.B = BD;
-        sp.w_state = h->d_w_state; sp.b_state = h->d_b_state; sp.w_sa = h->d_w_sa; sp.n_out = L[3];
+        sp.w_state = vd.w_state; sp.b_state = vd.b_state; sp.w_sa = vd.w_sa; sp.n_out = L[3];
         sp.state_out = produce ? v.states_all + (size_t)t_out * c.sdim : nullptr;
         sp.state_out_bstride = (long long)T * c.sdim;
         sp.sbias = D.sbias;
@@ -971,29 +1158,29 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
 
         // ---- encoder
         const float *frame_in; long long frame_bs;
-        if (s < nc) { frame_in = h->ctx_frames + (size_t)s * H * W * 3; frame_bs = 0; }
+        if (s < nc) { frame_in = vd.ctx_frames + (size_t)s * H * W * 3; frame_bs = 0; }
         else { frame_in = v.frames_all + (size_t)(s - nc) * H * W * 3; frame_bs = (long long)T * H * W * 3; }
 
-        ConvParams p = make_params(h->enc0, BE, plain(frame_in, frame_bs), nullptr);
+        ConvParams p = params(h->enc0, BE, plain(frame_in, frame_bs), nullptr);
         p.out = E.enc0_o; p.stats = E.st_enc0;
         VF_EMIT_SH(u_enc0, enc_sh, sink.conv(PH_CONV_RAW, h->enc0, p, {last}))
 
         SegArg enc0_n = normed(E.enc0_o, bs(enc_sh, (long long)H2 * W2 * 32), E.st_enc0, h->enc0.stats_nparts,
-                               enc_sh, (long long)H2 * W2 * 32, h->d_ln_g[0], h->d_ln_b[0], 32, 1);
+                               enc_sh, (long long)H2 * W2 * 32, vd.ln_g[0], vd.ln_b[0], 32, 1);
         // LayerNorm index: ln1 = enc0, ln2..ln8 = lstm1..7, ln9 = convt3
         auto h_normed = [&](int k) {        // normalised new hidden state of lstm k at this step
             const bool shd = lstm_shared(k, s);
             const BatchView &O = shd ? sh : v;
             const long long per = (long long)lh[k] * lw[k] * L[k];
             return normed(O.h_state[k][nxt], bs(shd, per), O.st_h[k], h->lstm[k].stats_nparts, shd, per,
-                          h->d_ln_g[k + 1], h->d_ln_b[k + 1], L[k], 0);
+                          vd.ln_g[k + 1], vd.ln_b[k + 1], L[k], 0);
         };
         auto lstm_params = [&](int k, const SegArg &x) {
             const bool out_sh = lstm_shared(k, s), in_sh = lstm_shared(k, s - 1);
             const BatchView &O = out_sh ? sh : v, &I = in_sh ? sh : v;
             const long long per = (long long)lh[k] * lw[k] * L[k];
             SegArg hs = plain(I.h_state[k][cur], bs(in_sh, per));
-            ConvParams q = make_params(h->lstm[k], out_sh ? 1 : B, x, &hs);
+            ConvParams q = params(h->lstm[k], out_sh ? 1 : B, x, &hs);
             q.out = O.h_state[k][nxt]; q.cstate = O.c_state[k]; q.stats = O.st_h[k];
             q.cstate_in = I.c_state[k]; q.cin_bstride = bs(in_sh, per);
             return q;
@@ -1001,7 +1188,7 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
         VF_EMIT_SH(u_l1, lstm_shared(0, s), sink.conv(PH_LSTM, h->lstm[0], lstm_params(0, enc0_n), {u_enc0}))
         VF_EMIT_SH(u_l2, lstm_shared(1, s), sink.conv(PH_LSTM, h->lstm[1], lstm_params(1, h_normed(0)), {u_l1}))
 
-        p = make_params(h->enc1, BE, h_normed(1), nullptr);
+        p = params(h->enc1, BE, h_normed(1), nullptr);
         p.out = E.enc1_o;
         VF_EMIT_SH(u_enc1, enc_sh, sink.conv(PH_CONV_RELU, h->enc1, p, {u_l2}))
 
@@ -1009,11 +1196,11 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
                                 lstm_params(2, plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]))), {u_enc1}))
         VF_EMIT_SH(u_l4, lstm_shared(3, s), sink.conv(PH_LSTM, h->lstm[3], lstm_params(3, h_normed(2)), {u_l3}))
 
-        p = make_params(h->enc2, BE, h_normed(3), nullptr);
+        p = params(h->enc2, BE, h_normed(3), nullptr);
         p.out = E.enc2_o;
         VF_EMIT_SH(u_enc2, enc_sh, sink.conv(PH_CONV_RELU, h->enc2, p, {u_l4}))
 
-        p = make_params(h->enc3, BD, plain(E.enc2_o, bs(enc_sh, (long long)H8 * W8 * L[3])), nullptr);
+        p = params(h->enc3, BD, plain(E.enc2_o, bs(enc_sh, (long long)H8 * W8 * L[3])), nullptr);
         p.out = D.enc3_o; p.sbias = D.sbias; p.sbias_ld = L[3];
         VF_EMIT_SH(u_enc3, all_sh, sink.conv(PH_CONV_RELU, h->enc3, p, {u_enc2, u_sa}))
 
@@ -1022,14 +1209,14 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
         SegArg h5n = h_normed(4);
 
         // ---- decoder
-        p = make_params(h->convt1, BD, h5n, nullptr);
+        p = params(h->convt1, BD, h5n, nullptr);
         p.out = D.enc4_o;
         VF_EMIT_SH(u_t1, all_sh, sink.conv(PH_CONVT_RELU, h->convt1, p, {u_l5}))
         VF_EMIT_SH(u_l6, lstm_shared(5, s), sink.conv(PH_LSTM, h->lstm[5],
                                 lstm_params(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))), {u_t1}))
 
         SegArg enc1_s = plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]));
-        p = make_params(h->convt2, BD, h_normed(5), &enc1_s);
+        p = params(h->convt2, BD, h_normed(5), &enc1_s);
         p.out = D.enc5_o;
         VF_EMIT_SH(u_t2, all_sh, sink.conv(PH_CONVT_RELU, h->convt2, p, {u_l6}))
         VF_EMIT_SH(u_l7, lstm_shared(6, s), sink.conv(PH_LSTM, h->lstm[6],
@@ -1041,18 +1228,18 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
         int u_fin = -1;
         if (produce) {
             SegArg flat = h5n;      // same LayerNorm, viewed as [B][1][1][H8*W8*128]
-            p = make_params(h->fc, B, flat, nullptr);
+            p = params(h->fc, B, flat, nullptr);
             p.out = v.fc_part;
             VF_EMIT(u_fc, sink.conv(PH_FC_PARTIAL, h->fc, p, {u_l5}))
             FinParams fp;
             fp.partial = v.fc_part; fp.nsplit = h->fc.nsplit; fp.B = B; fp.K = h->K;
-            fp.bias = h->d_b_fc; fp.kern = v.kern;
+            fp.bias = vd.b_fc; fp.kern = v.kern;
             u_fin = sink.fin(fp, {u_fc});
             if (Sink::failed(u_fin)) return u_fin;
         }
 
         if (produce) {      // never an all-shared step
-            p = make_params(h->convt3, B, h_normed(6), &enc0_n);
+            p = params(h->convt3, B, h_normed(6), &enc0_n);
             p.out = v.enc6_o; p.stats = v.st_enc6;
             VF_EMIT(u_t3, sink.conv(PH_CONVT_RAW, h->convt3, p, {u_l7}))
 
@@ -1060,12 +1247,12 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
             cp.B = B; cp.H = H; cp.W = W; cp.ND = ND; cp.K = h->K;
             cp.enc6 = v.enc6_o; cp.ln_part = v.st_enc6; cp.ln_nparts = h->convt3.stats_nparts;
             cp.ln_inv_n = (float)(1.0 / ((double)H * W * 32));
-            cp.gamma = h->d_ln_g[8]; cp.beta = h->d_ln_b[8];
-            cp.w_rgb = h->d_w_rgb; cp.b_rgb = h->d_b_rgb; cp.w_mask = h->d_w_mask; cp.b_mask = h->d_b_mask;
+            cp.gamma = vd.ln_g[8]; cp.beta = vd.ln_b[8];
+            cp.w_rgb = vd.w_rgb; cp.b_rgb = vd.b_rgb; cp.w_mask = vd.w_mask; cp.b_mask = vd.b_mask;
             cp.kern = v.kern;
             cp.prev_frame = frame_in; cp.prev_frame_bstride = frame_bs;
             if (s < nc) {
-                cp.prev_distrib = h->ctx_distrib + (size_t)s * H * W * ND; cp.prev_distrib_bstride = 0;
+                cp.prev_distrib = vd.ctx_distrib + (size_t)s * H * W * ND; cp.prev_distrib_bstride = 0;
                 cp.prev_sums = nullptr;
             } else {
                 cp.prev_distrib = v.distrib_all + (size_t)(s - nc) * H * W * ND;
@@ -1076,8 +1263,9 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
             cp.out_distrib = v.distrib_all + (size_t)t_out * H * W * ND;
             cp.out_distrib_bstride = (long long)T * H * W * ND;
             cp.out_sums = v.sums + (long long)t_out * h->sums_step_stride;
-            for (int d = 0; d < ND; ++d) { cp.goal[d][0] = goal_pix[2 * d]; cp.goal[d][1] = goal_pix[2 * d + 1]; }
-            VF_EMIT(u_comp, sink.composite(cp, h->ntiles, {u_t3, u_fin}))
+            if (goal_pix)
+                for (int d = 0; d < ND; ++d) { cp.goal[d][0] = goal_pix[2 * d]; cp.goal[d][1] = goal_pix[2 * d + 1]; }
+            VF_EMIT(u_comp, sink.composite(cp, h->ntiles, view, {u_t3, u_fin}))
             last = u_comp;
         }
     }
@@ -1085,6 +1273,115 @@ static int emit_rollout(vf_handle *h, const BatchView &v, const BatchView &sh, i
 #undef VF_EMIT
     return VF_OK;
 }
+
+// ------------------------------------------------------------------ persistent schedule (host part)
+struct BuiltSchedule {
+    std::vector<PhaseDesc> phases;
+    int items = 0, counters = 0;
+    double flops = 0.0;
+    size_t lds = 0;
+};
+
+// One phase list per view (own weights, own buffers, own counters), merged phase by phase so that
+// the views advance together and a phase's items of both views are neighbours in ticket order.
+static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &out) {
+    std::vector<ScheduleSink> sinks(h->ncam);
+    int counters = 0, rc;
+    out.flops = 0.0;
+    size_t max_lds = 0;
+    for (int v = 0; v < h->ncam; ++v) {
+        sinks[v].next_counter = counters;
+        if ((rc = emit_rollout(h, v, make_view(h, v, h->actions_buf, 0), h->shared_views[(size_t)v * kMaxSubBatches],
+                               B, nullptr, sinks[v], skip_shared)) < 0)
+            return rc;
+        counters = sinks[v].next_counter;
+        out.flops += sinks[v].flops;
+        max_lds = std::max(max_lds, sinks[v].max_lds);
+    }
+    out.phases.clear();
+    const size_t n = sinks[0].phases.size();
+    for (size_t i = 0; i < n; ++i)
+        for (int v = 0; v < h->ncam; ++v) out.phases.push_back(sinks[v].phases[i]);
+    int ticket = 0;
+    for (PhaseDesc &P : out.phases) { P.first_ticket = ticket; ticket += P.n_items; }
+    out.items = ticket;
+    out.counters = counters;
+    out.lds = std::max(max_lds, (size_t)composite_lds_floats<kMaxDesig, 10>() * 4) + 16;
+    if (out.phases.size() > h->sched_capacity || (size_t)counters > h->counter_capacity)
+        return fail(VF_ERR_INVALID, "persistent schedule exceeds its preallocated capacity");
+    return VF_OK;
+}
+
+#ifdef VF_HOST_SELFTEST
+// ------------------------------------------------------------------ host self-test hooks
+// (tools/host_selftest.cc; ASan/UBSan build).  Checks the invariants the device relies on.
+static bool in_allocs(const vf_handle *h, const void *p, size_t bytes) {
+    if (!p) return true;
+    const char *q = static_cast<const char *>(p);
+    for (const AllocRec &a : h->allocs) {
+        const char *lo = static_cast<const char *>(a.p);
+        if (q >= lo && q + bytes <= lo + a.bytes) return true;
+    }
+    return false;
+}
+
+extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared, int64_t *out_items,
+                                    uint64_t *out_upload_checksum) {
+    if (!h) return fail(VF_ERR_INVALID, "null handle");
+    BuiltSchedule bs;
+    int rc = build_schedule(h, B, skip_shared != 0, bs);
+    if (rc) return rc;
+    int ticket = 0;
+    for (size_t i = 0; i < bs.phases.size(); ++i) {
+        const PhaseDesc &P = bs.phases[i];
+        if (P.first_ticket != ticket || P.n_items <= 0) return fail(VF_ERR_INVALID, "tickets are not contiguous");
+        ticket += P.n_items;
+        if (P.ndep < 0 || P.ndep > kMaxDeps) return fail(VF_ERR_INVALID, "bad dependency count");
+        for (int d = 0; d < P.ndep; ++d) {
+            // a dependency must point at the counters of a phase with smaller tickets
+            bool found = false;
+            for (size_t j = 0; j < i && !found; ++j) found = bs.phases[j].cnt_base == P.dep[d].cnt_base;
+            if (!found) return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + " depends on a later phase");
+            if (P.dep[d].expect <= 0) return fail(VF_ERR_INVALID, "non-positive expected count");
+        }
+        const int ncnt = P.whole ? 1 : P.B;
+        if (P.cnt_base < 0 || P.cnt_base + ncnt > bs.counters) return fail(VF_ERR_INVALID, "counter out of range");
+        // every pointer a tile dereferences must lie inside an allocation of this handle
+        bool ok = true;
+        if (P.type <= PH_FC_PARTIAL) {
+            const ConvParams &c = P.conv;
+            for (int s = 0; s < c.nseg; ++s) {
+                const long long span = (long long)(P.B - 1) * c.seg[s].bstride + (long long)c.Hin * c.Win * c.seg[s].C;
+                ok = ok && in_allocs(h, c.seg[s].ptr, (size_t)span * 4);
+                ok = ok && in_allocs(h, c.seg[s].ln_part, c.seg[s].ln_part ? (size_t)((P.B - 1) * c.seg[s].ln_bstride + c.seg[s].ln_nparts * 2) * 8 : 0);
+            }
+            ok = ok && in_allocs(h, c.Wp, 16) && in_allocs(h, c.bias, 4) && in_allocs(h, c.out, 4);
+            ok = ok && in_allocs(h, c.cstate, 4) && in_allocs(h, c.cstate_in, 4) && in_allocs(h, c.stats, 8);
+        } else if (P.type == PH_COMPOSITE) {
+            const CompositeParams &c = P.comp;
+            const size_t hw = (size_t)c.H * c.W;
+            ok = ok && in_allocs(h, c.enc6, (size_t)P.B * hw * 32 * 4);
+            ok = ok && in_allocs(h, c.prev_frame, ((size_t)(P.B - 1) * c.prev_frame_bstride + hw * 3) * 4);
+            ok = ok && in_allocs(h, c.prev_distrib, ((size_t)(P.B - 1) * c.prev_distrib_bstride + hw * c.ND) * 4);
+            ok = ok && in_allocs(h, c.out_frame, ((size_t)(P.B - 1) * c.out_frame_bstride + hw * 3) * 4);
+            ok = ok && in_allocs(h, c.out_distrib, ((size_t)(P.B - 1) * c.out_distrib_bstride + hw * c.ND) * 4);
+            ok = ok && in_allocs(h, c.out_sums, (size_t)P.B * c.ND * h->ntiles * 2 * 8);
+            ok = ok && in_allocs(h, c.kern, (size_t)P.B * kTaps * c.K * 4);
+        } else if (P.type == PH_SA) {
+            ok = ok && in_allocs(h, P.sa.sbias, (size_t)P.B * P.sa.n_out * 4) && in_allocs(h, P.sa.action, 4) &&
+                 in_allocs(h, P.sa.state, 4);
+        } else {
+            ok = ok && in_allocs(h, P.fin.partial, (size_t)P.fin.nsplit * P.B * kTaps * P.fin.K * 4) &&
+                 in_allocs(h, P.fin.kern, (size_t)P.B * kTaps * P.fin.K * 4);
+        }
+        if (!ok) return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + " points outside the handle's buffers");
+    }
+    if (ticket != bs.items) return fail(VF_ERR_INVALID, "item count mismatch");
+    if (out_items) *out_items = bs.items;
+    if (out_upload_checksum) *out_upload_checksum = h->upload_checksum;
+    return VF_OK;
+}
+#else   // ------------------------------------------------------------------ device execution
 
 // the zero initial LSTM state is one shared image per layer
 static int zero_shared_state(vf_handle *h, const BatchView &sh, hipStream_t st) {
@@ -1100,14 +1397,14 @@ static int zero_shared_state(vf_handle *h, const BatchView &sh, hipStream_t st) 
     return VF_OK;
 }
 
-static int run_steps(vf_handle *h, const BatchView &v, const BatchView &sh, int B, const int32_t *goal_pix,
-                     hipStream_t st, bool skip_shared) {
+static int run_steps(vf_handle *h, int view, const BatchView &v, const BatchView &sh, int B,
+                     const int32_t *goal_pix, hipStream_t st, bool skip_shared) {
     if (!skip_shared) {
         int rc = zero_shared_state(h, sh, st);
         if (rc) return rc;
     }
     LaunchSink sink{h, st};
-    return emit_rollout(h, v, sh, B, goal_pix, sink, skip_shared);
+    return emit_rollout(h, view, v, sh, B, goal_pix + (size_t)view * h->ND * 2, sink, skip_shared);
 }
 
 // Are the shared buffers of configuration `cfg` (launch mode and split) still valid?
@@ -1116,13 +1413,7 @@ static bool shared_cache_hit(vf_handle *h, int cfg) {
 }
 
 template <int ND, int WPS>
-static int launch_persistent_w(vf_handle *h, const Schedule &sc, int grid, size_t lds, hipStream_t st) {
-    static size_t configured = 0;
-    if (lds > configured) {
-        VF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_persistent_kernel<ND, WPS>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+static int launch_persistent_w(const Schedule &sc, int grid, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL((rollout_persistent_kernel<ND, WPS>), dim3(grid), dim3(kConvThreads), lds, st, sc.phases,
                        sc);
     VF_HIP_CHECK(hipGetLastError());
@@ -1134,92 +1425,63 @@ static int launch_persistent_t(vf_handle *h, const Schedule &sc, int grid, size_
     // 3 resident workgroups per CU need the 168-VGPR build, which has no 256-row LSTM tile
     bool any_mrep2 = false;
     for (int k = 0; k < 7; ++k) any_mrep2 = any_mrep2 || h->lstm[k].mrep == 2;
-    if (h->persist_wgs_per_cu >= 3 && !any_mrep2) return launch_persistent_w<ND, 3>(h, sc, grid, lds, st);
-    return launch_persistent_w<ND, 2>(h, sc, grid, lds, st);
+    if (h->persist_wgs_per_cu >= 3 && !any_mrep2) return launch_persistent_w<ND, 3>(sc, grid, lds, st);
+    return launch_persistent_w<ND, 2>(sc, grid, lds, st);
 }
 
-// the whole rollout as one persistent launch (vf_persistent.h)
+// the whole rollout (every view) as one persistent launch (vf_persistent.h)
 static int run_persistent(vf_handle *h, const float *d_actions, int B, const int32_t *goal_pix, hipStream_t st) {
     int rc;
-    // the schedule holds pointers into the handle's own action buffer, so it only depends on
-    // (B, goal pixels, options) and is rebuilt when those change
+    // the schedule holds pointers into the handle's own buffers (the action sequences are copied
+    // into actions_buf, the goal pixels travel as launch arguments), so it only depends on
+    // (B, options) and is rebuilt when those change - typically for a ragged last chunk
     const size_t act_bytes = (size_t)B * h->T * h->cfg.adim * sizeof(float);
     VF_HIP_CHECK(hipMemcpyAsync(h->actions_buf, d_actions, act_bytes, hipMemcpyDeviceToDevice, st));
-    const int ngroups = std::max(1, std::min({h->n_groups, kMaxSubBatches, B / 8}));
-    const int cfg = 1000 + ngroups;
+    const int cfg = 1000;
     const bool skip_shared = shared_cache_hit(h, cfg);
     vf_handle::SchedCache &sc_host = h->sched[skip_shared ? 1 : 0];
-    bool rebuild = sc_host.B != B || sc_host.dedup != h->dedup || sc_host.groups != ngroups ||
-                   sc_host.offset != h->group_offset;
-    for (int d = 0; d < 2 * h->ND; ++d) rebuild = rebuild || sc_host.goal[d] != goal_pix[d];
-    if (rebuild) {
-        // Sample groups: each group of samples gets its own phase list (own shared buffers, own
-        // counters); the lists are merged with a phase offset (tuning knob; 1 group by default).
-        std::vector<ScheduleSink> sinks(ngroups);
-        int counters = 0;
-        double flops = 0.0;
-        size_t max_lds = 0;
-        for (int g = 0; g < ngroups; ++g) {
-            const int b0 = (int)((long long)B * g / ngroups), b1 = (int)((long long)B * (g + 1) / ngroups);
-            sinks[g].next_counter = counters;
-            if ((rc = emit_rollout(h, make_view(h, h->actions_buf, b0), h->shared_views[g], b1 - b0, goal_pix,
-                                   sinks[g], skip_shared)) < 0)
-                return rc;
-            counters = sinks[g].next_counter;
-            flops += sinks[g].flops;
-            max_lds = std::max(max_lds, sinks[g].max_lds);
-        }
-        std::vector<PhaseDesc> merged;
-        std::vector<size_t> pos(ngroups, 0);
-        for (long long vt = 0;; ++vt) {     // virtual time: group g runs its phase i at vt = i + g * offset
-            bool any_left = false;
-            for (int g = 0; g < ngroups; ++g) {
-                const long long i = vt - (long long)g * h->group_offset;
-                if (pos[g] < sinks[g].phases.size()) any_left = true;
-                if (i >= 0 && (size_t)i == pos[g] && pos[g] < sinks[g].phases.size())
-                    merged.push_back(sinks[g].phases[pos[g]++]);
-            }
-            if (!any_left) break;
-        }
-        int ticket = 0;
-        for (PhaseDesc &P : merged) { P.first_ticket = ticket; ticket += P.n_items; }
-        if (merged.size() > h->sched_capacity || (size_t)counters > h->counter_capacity)
-            return fail(VF_ERR_INVALID, "persistent schedule exceeds its preallocated capacity");
-        // an earlier rollout may still be reading the device copy
-        VF_HIP_CHECK(hipStreamSynchronize(st));
-        VF_HIP_CHECK(hipMemcpy(sc_host.d_phases, merged.data(), merged.size() * sizeof(PhaseDesc),
-                               hipMemcpyHostToDevice));
-        sc_host.B = B; sc_host.dedup = h->dedup; sc_host.groups = ngroups; sc_host.offset = h->group_offset;
-        for (int d = 0; d < 2 * h->ND; ++d) sc_host.goal[d] = goal_pix[d];
-        sc_host.items = ticket; sc_host.counters = counters;
-        sc_host.phases = (int)merged.size();
+    if (sc_host.B != B || sc_host.dedup != h->dedup) {
+        BuiltSchedule bs;
+        if ((rc = build_schedule(h, B, skip_shared, bs))) return rc;
+        // Upload without synchronising the caller's stream: the copy is stream-ordered behind the
+        // rollouts still reading the device schedule, and the pinned staging buffer is only reused
+        // once its own copy has completed (ring of kSchedRing; waits only if that many rebuilds are
+        // in flight at once).
+        const int slot = h->stage_next;
+        h->stage_next = (slot + 1) % kSchedRing;
+        if (h->stage_used[slot]) VF_HIP_CHECK(hipEventSynchronize(h->stage_done[slot]));
+        memcpy(h->stage[slot], bs.phases.data(), bs.phases.size() * sizeof(PhaseDesc));
+        VF_HIP_CHECK(hipMemcpyAsync(sc_host.d_phases, h->stage[slot], bs.phases.size() * sizeof(PhaseDesc),
+                                    hipMemcpyHostToDevice, st));
+        VF_HIP_CHECK(hipEventRecord(h->stage_done[slot], st));
+        h->stage_used[slot] = true;
+        sc_host.B = B; sc_host.dedup = h->dedup;
+        sc_host.items = bs.items; sc_host.counters = bs.counters;
+        sc_host.phases = (int)bs.phases.size();
         sc_host.types.clear(); sc_host.nitems.clear();
-        for (const PhaseDesc &P : merged) { sc_host.types.push_back(P.type); sc_host.nitems.push_back(P.n_items); }
-        sc_host.flops = flops;
-        sc_host.lds = std::max(max_lds, (size_t)composite_lds_floats<kMaxDesig, 10>() * 4) + 16;
+        for (const PhaseDesc &P : bs.phases) { sc_host.types.push_back(P.type); sc_host.nitems.push_back(P.n_items); }
+        sc_host.flops = bs.flops;
+        sc_host.lds = bs.lds;
     }
     h->last_sched = skip_shared ? 1 : 0;
     if (!skip_shared)
-        for (int g = 0; g < ngroups; ++g)
-            if ((rc = zero_shared_state(h, h->shared_views[g], st))) return rc;
-    VF_HIP_CHECK(hipMemsetAsync(h->d_sync, 0, (2 + (size_t)sc_host.counters) * sizeof(int), st));
+        for (int v = 0; v < h->ncam; ++v)
+            if ((rc = zero_shared_state(h, h->shared_views[(size_t)v * kMaxSubBatches], st))) return rc;
+    VF_HIP_CHECK(hipMemsetAsync(h->d_sync, 0, (1 + (size_t)sc_host.counters) * sizeof(int), st));
     Schedule sc;
+    memset(&sc, 0, sizeof(sc));
     sc.phases = sc_host.d_phases; sc.n_phases = sc_host.phases; sc.total_items = sc_host.items;
-    sc.ticket = h->d_sync; sc.status = h->d_sync + 1; sc.counters = h->d_sync + 2;
+    sc.ticket = h->d_sync; sc.counters = h->d_sync + 1; sc.status = h->d_status;
     sc.stats = nullptr;
-    sc.debug_no_fence = getenv("VF_DEBUG_NO_FENCE") ? 1 : 0;
-    if (getenv("VF_PERSIST_STATS")) {
-        if (!h->d_stats) {
-            void *q = nullptr;
-            VF_HIP_CHECK(hipMalloc(&q, h->sched_capacity * 2 * sizeof(unsigned long long)));
-            h->allocs.push_back(q);
-            h->d_stats = reinterpret_cast<unsigned long long *>(q);
-        }
+    sc.nd = h->ND;
+    for (int i = 0; i < h->ncam * h->ND * 2; ++i) sc.goal[i] = goal_pix[i];
+    if (h->phase_stats) {
         VF_HIP_CHECK(hipMemsetAsync(h->d_stats, 0, h->sched_capacity * 2 * sizeof(unsigned long long), st));
         sc.stats = h->d_stats;
     }
     // resident workgroups per CU: bounded by the LDS a workgroup needs (160 KiB per CU)
-    const int by_lds = (int)std::max<size_t>(1, (160 * 1024) / sc_host.lds);
+    const size_t lds = sc_host.lds + kCtlWords * sizeof(int);
+    const int by_lds = (int)std::max<size_t>(1, (160 * 1024) / lds);
     const int grid = std::min(sc_host.items, h->n_cu * std::min(h->persist_wgs_per_cu, by_lds));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) {
@@ -1232,10 +1494,10 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         VF_HIP_CHECK(hipEventRecord(e0, st));
     }
     switch (h->ND) {
-        case 1: rc = launch_persistent_t<1>(h, sc, grid, sc_host.lds, st); break;
-        case 2: rc = launch_persistent_t<2>(h, sc, grid, sc_host.lds, st); break;
-        case 3: rc = launch_persistent_t<3>(h, sc, grid, sc_host.lds, st); break;
-        default: rc = launch_persistent_t<4>(h, sc, grid, sc_host.lds, st); break;
+        case 1: rc = launch_persistent_t<1>(h, sc, grid, lds, st); break;
+        case 2: rc = launch_persistent_t<2>(h, sc, grid, lds, st); break;
+        case 3: rc = launch_persistent_t<3>(h, sc, grid, lds, st); break;
+        default: rc = launch_persistent_t<4>(h, sc, grid, lds, st); break;
     }
     if (rc) return rc;
     if (h->profiling) {
@@ -1251,25 +1513,31 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
 extern "C" {
 
 int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *goal_pix, float finalweight,
-               float *d_scores, float *d_scores_per_task, void *stream) {
+               const float *task_weights, float *d_scores, float *d_scores_per_task, void *stream) {
     if (!h || !d_actions || !goal_pix || !d_scores) return fail(VF_ERR_INVALID, "null argument");
     if (!h->have_weights) return fail(VF_ERR_NOWEIGHTS, "vf_load_weights has not been called");
     if (!h->have_context) return fail(VF_ERR_NOCONTEXT, "vf_set_context has not been called");
     if (B < 1 || B > h->cfg.max_batch)
         return fail(VF_ERR_INVALID, "batch " + std::to_string(B) + " outside 1.." + std::to_string(h->cfg.max_batch));
+    if (B % h->n_draws)
+        return fail(VF_ERR_INVALID, "batch " + std::to_string(B) + " is not a multiple of n_draws = " +
+                                        std::to_string(h->n_draws));
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
 
-    // Samples never interact before the scores are compared, so the batch is cut into
-    // sub-batches that advance on forked streams: while one sub-batch drains the tail of a
-    // layer, the other's workgroups fill the idle CUs.  Results are bit-identical for any split.
+    // Samples never interact before the scores are compared, so the per-layer path may cut the
+    // batch into sub-batches that advance on forked streams: while one sub-batch drains the tail of
+    // a layer, the other's workgroups fill the idle CUs.  Results are bit-identical for any split.
     const int nsub = std::max(1, std::min({h->n_sub, B / 16, (int)h->sub_streams.size() + 1}));
     if (h->persistent) {
         if ((rc = run_persistent(h, d_actions, B, goal_pix, st))) return rc;
     } else if (nsub == 1) {
         const bool skip = shared_cache_hit(h, 1);
-        if ((rc = run_steps(h, make_view(h, d_actions, 0), h->shared_views[0], B, goal_pix, st, skip))) return rc;
+        for (int v = 0; v < h->ncam; ++v)
+            if ((rc = run_steps(h, v, make_view(h, v, d_actions, 0), h->shared_views[(size_t)v * kMaxSubBatches], B,
+                                goal_pix, st, skip)))
+                return rc;
         h->shared_valid = h->dedup; h->shared_cfg = 1;
     } else {
         const bool skip = shared_cache_hit(h, 100 + nsub);
@@ -1278,8 +1546,10 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
             const int b0 = (int)((long long)B * i / nsub), b1 = (int)((long long)B * (i + 1) / nsub);
             hipStream_t ss = i == 0 ? st : h->sub_streams[i - 1];
             if (i > 0) VF_HIP_CHECK(hipStreamWaitEvent(ss, h->ev_fork, 0));
-            if ((rc = run_steps(h, make_view(h, d_actions, b0), h->shared_views[i], b1 - b0, goal_pix, ss, skip)))
-                return rc;
+            for (int v = 0; v < h->ncam; ++v)
+                if ((rc = run_steps(h, v, make_view(h, v, d_actions, b0),
+                                    h->shared_views[(size_t)v * kMaxSubBatches + i], b1 - b0, goal_pix, ss, skip)))
+                    return rc;
             if (i > 0) {
                 VF_HIP_CHECK(hipEventRecord(h->ev_join[i - 1], ss));
                 VF_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join[i - 1], 0));
@@ -1287,8 +1557,16 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
         }
         h->shared_valid = h->dedup; h->shared_cfg = 100 + nsub;
     }
-    hipLaunchKernelGGL(scores_kernel, dim3((B + 63) / 64), dim3(64), 0, st, h->sums, h->sums_step_stride, B,
-                       h->T, h->ND, h->ntiles, finalweight, d_scores, d_scores_per_task);
+    TaskWeights tw;
+    memset(&tw, 0, sizeof(tw));
+    if (task_weights) {
+        tw.use = 1;
+        for (int i = 0; i < h->ncam * h->ND; ++i) tw.w[i] = task_weights[i];
+    }
+    const int n_actions = B / h->n_draws;
+    hipLaunchKernelGGL(scores_kernel, dim3((n_actions + 63) / 64), dim3(64), 0, st, h->sums, h->sums_step_stride,
+                       h->sums_view_stride, n_actions, h->n_draws, h->T, h->ND, h->ncam, h->ntiles, finalweight, tw,
+                       h->d_status, d_scores, d_scores_per_task);
     VF_HIP_CHECK(hipGetLastError());
     h->last_B = B;
     return VF_OK;
@@ -1297,24 +1575,41 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
 int vf_set_persistent(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->persistent = enable != 0;
-    // tuning knobs of the persistent schedule (sample groups, their phase offset, resident
-    // workgroups per CU); read once per switch so A/B runs need no rebuild
-    if (const char *e = getenv("VF_GROUPS")) h->n_groups = std::max(1, atoi(e));
-    if (const char *e = getenv("VF_GROUP_OFFSET")) h->group_offset = std::max(0, atoi(e));
+#ifdef VF_DEBUG_KNOBS
     if (const char *e = getenv("VF_PERSIST_WGS_PER_CU")) h->persist_wgs_per_cu = std::max(1, std::min(4, atoi(e)));
+#endif
     return VF_OK;
 }
 
 int vf_device_status(vf_handle *h, int32_t *status) {
     if (!h || !status) return fail(VF_ERR_INVALID, "null argument");
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
-    VF_HIP_CHECK(hipMemcpy(status, h->d_sync + 1, sizeof(int), hipMemcpyDeviceToHost));
+    VF_HIP_CHECK(hipDeviceSynchronize());
+    VF_HIP_CHECK(hipMemcpy(status, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (*status != 0) VF_HIP_CHECK(hipMemset(h->d_status, 0, sizeof(int)));    // observed: re-arm
+    return VF_OK;
+}
+
+// debugging aid: make the next rollouts fail as if a producer never arrived (tests of the in-band
+// failure path); the word is cleared again by vf_device_status
+int vf_debug_poison_status(vf_handle *h) {
+    if (!h) return fail(VF_ERR_INVALID, "null handle");
+    VF_HIP_CHECK(hipSetDevice(h->cfg.device));
+    VF_HIP_CHECK(hipDeviceSynchronize());
+    const int one = 1;
+    VF_HIP_CHECK(hipMemcpy(h->d_status, &one, sizeof(int), hipMemcpyHostToDevice));
     return VF_OK;
 }
 
 // debugging aid: per-phase (type, items, wait ticks, run ticks) of the last persistent rollout
+int vf_set_phase_stats(vf_handle *h, int32_t enable) {
+    if (!h) return fail(VF_ERR_INVALID, "null handle");
+    h->phase_stats = enable != 0;
+    return VF_OK;
+}
+
 int vf_debug_phase_stats(vf_handle *h, int32_t max_phases, int32_t *types, int32_t *items, uint64_t *wait_run) {
-    if (!h || !h->d_stats) return fail(VF_ERR_INVALID, "no phase statistics (set VF_PERSIST_STATS)");
+    if (!h || !h->phase_stats) return fail(VF_ERR_INVALID, "no phase statistics (vf_set_phase_stats)");
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
     VF_HIP_CHECK(hipDeviceSynchronize());
     const vf_handle::SchedCache &sc = h->sched[h->last_sched];
@@ -1340,7 +1635,6 @@ int vf_set_dedup(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->dedup = enable != 0;
     h->shared_valid = false;
-    if (const char *e = getenv("VF_CACHE_SHARED")) h->cache_shared = atoi(e) != 0;
     return VF_OK;
 }
 
@@ -1368,20 +1662,72 @@ int vf_export(vf_handle *h, int32_t first, int32_t count, float *d_frames, float
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t HW = (size_t)h->H * h->W;
-    if (d_frames)
-        VF_HIP_CHECK(hipMemcpyAsync(d_frames, h->frames_all + (size_t)first * h->T * HW * 3,
-                                    (size_t)count * h->T * HW * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (d_states)
+    const long long view_rows = (long long)h->cfg.max_batch * h->T;
+    if (d_frames) {
+        if (h->ncam == 1) {
+            VF_HIP_CHECK(hipMemcpyAsync(d_frames, h->frames_all + (size_t)first * h->T * HW * 3,
+                                        (size_t)count * h->T * HW * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        } else {
+            const long long n = (long long)count * h->T * h->ncam * HW * 3;
+            hipLaunchKernelGGL(export_frames_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               h->frames_all, view_rows * (long long)HW * 3, first, count, h->T, h->ncam,
+                               (int)(HW * 3), d_frames);
+            VF_HIP_CHECK(hipGetLastError());
+        }
+    }
+    if (d_states)       // the views share the state trajectory's inputs; view 0's prediction is reported
         VF_HIP_CHECK(hipMemcpyAsync(d_states, h->states_all + (size_t)first * h->T * h->cfg.sdim,
                                     (size_t)count * h->T * h->cfg.sdim * sizeof(float), hipMemcpyDeviceToDevice,
                                     st));
     if (d_distrib) {
-        const long long n = (long long)count * h->T * HW * h->ND;
+        const long long n = (long long)count * h->T * h->ncam * HW * h->ND;
         hipLaunchKernelGGL(export_distrib_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           h->distrib_all, h->sums, h->sums_step_stride, first, count, h->T, (int)HW, h->ND,
-                           h->ntiles, d_distrib);
+                           h->distrib_all, view_rows * (long long)HW * h->ND, h->sums, h->sums_step_stride,
+                           h->sums_view_stride, first, count, h->T, h->ncam, (int)HW, h->ND, h->ntiles, d_distrib);
         VF_HIP_CHECK(hipGetLastError());
     }
+    return VF_OK;
+}
+
+int vf_register(vf_handle *h, const float *d_current, const float *d_reference, const float *d_flow,
+                const int32_t *d_pix, int32_t ntask, int32_t region, int32_t clip_sub, float *d_warped,
+                float *d_warp_pts, float *d_desig, float *d_err, void *stream) {
+    if (!h || !d_current || !d_reference || !d_flow || !d_pix || !d_desig || !d_err)
+        return fail(VF_ERR_INVALID, "null argument");
+    if (ntask < 1 || region < 0 || (2 * region + 1) * (2 * region + 1) > kRegMaxWin || (clip_sub != 0 && clip_sub != 1))
+        return fail(VF_ERR_INVALID, "need ntask >= 1, 0 <= region <= 5 and clip_sub in {0, 1}");
+    VF_HIP_CHECK(hipSetDevice(h->cfg.device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d_warped || d_warp_pts) {
+        const int n = h->ncam * h->H * h->W;
+        hipLaunchKernelGGL(warp_image_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_current, d_flow, h->ncam,
+                           h->H, h->W, d_warped, d_warp_pts);
+        VF_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(register_kernel, dim3(h->ncam * ntask), dim3(128), 0, st, d_current, d_reference, d_flow,
+                       d_pix, h->ncam, ntask, h->H, h->W, region, clip_sub, d_desig, d_err);
+    VF_HIP_CHECK(hipGetLastError());
+    return VF_OK;
+}
+
+// RCCL is bound at first use (dlopen of the library the process already carries - PyTorch ships
+// its own librccl.so - or the system one), so libvf_hip.so itself has no link dependency on it.
+int vf_allgather_scores(vf_handle *h, void *nccl_comm, const float *d_local, int32_t n_local, float *d_all,
+                        void *stream) {
+    if (!h || !nccl_comm || !d_local || !d_all || n_local < 1) return fail(VF_ERR_INVALID, "null or empty argument");
+    if (!h->nccl_all_gather) {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names)
+            if ((h->rccl_lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h->rccl_lib) return fail(VF_ERR_HIP, std::string("cannot load RCCL: ") + dlerror());
+        h->nccl_all_gather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, void *)>(
+            dlsym(h->rccl_lib, "ncclAllGather"));
+        if (!h->nccl_all_gather) return fail(VF_ERR_HIP, "ncclAllGather not found in the RCCL library");
+    }
+    VF_HIP_CHECK(hipSetDevice(h->cfg.device));
+    const int nccl_float32 = 7;     // ncclFloat32 in nccl.h
+    const int rc = h->nccl_all_gather(d_local, d_all, (size_t)n_local, nccl_float32, nccl_comm, stream);
+    if (rc != 0) return fail(VF_ERR_HIP, "ncclAllGather failed with ncclResult_t " + std::to_string(rc));
     return VF_OK;
 }
 
@@ -1428,3 +1774,4 @@ int vf_get_profile(vf_handle *h, double *kernel_ms, int64_t *launches, double *f
 }
 
 }  // extern "C"
+#endif  // VF_HOST_SELFTEST

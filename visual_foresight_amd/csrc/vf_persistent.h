@@ -47,6 +47,7 @@ struct PhaseDesc {
     int whole;              // 1: completion is counted once per item on counter 0
     int mrep;               // MFMA row blocks per wave of this conv phase (1 or 2)
     int prec;               // 0: fp32 MFMA tile, 1: split-bf16 conv-LSTM tile
+    int view;               // camera view this phase belongs to (selects the goal pixels of PH_COMPOSITE)
     int cnt_base;
     int ndep;
     PhaseDep dep[kMaxDeps];
@@ -56,15 +57,21 @@ struct PhaseDesc {
     CompositeParams comp;
 };
 
+constexpr int kCtlWords = 64;               // LDS control block: [0..3] scheduler, [8..8+32) goal pixels
+constexpr int kCtlGoal = 8;
+
 struct Schedule {
     const PhaseDesc *phases;
     int n_phases;
     int total_items;
     int *ticket;            // [1]
     int *counters;          // completion counters
-    int *status;            // [1] set non-zero when an item gave up waiting
-    int debug_no_fence;     // timing experiments only: skip the agent-scope fences (results invalid)
+    int *status;            // [1] sticky: set non-zero when an item gave up waiting; cleared by the host
+                            //     only after it has been read (vf_device_status)
     unsigned long long *stats;  // optional [n_phases][2]: summed wait / run time per phase (wall clock ticks)
+    int goal[kMaxCam * kMaxDesig * 2];      // goal pixels [view][desig][row, col]: launch arguments, so
+                                            // the device schedule does not depend on them
+    int nd;                 // designated pixels per view
 };
 
 __device__ __forceinline__ int ld_relaxed(const int *p) {
@@ -107,7 +114,7 @@ __device__ __forceinline__ const VF_CONST_AS T &const_params(const T *generic_pt
 
 __device__ __forceinline__ float *tile_lds() {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
-    return smem_all + 4;    // 4 control words of the scheduler come first
+    return smem_all + kCtlWords;    // the control block comes first
 }
 
 template <int G, int EPI, int MREP>
@@ -119,8 +126,10 @@ __device__ __noinline__ void lstm_bf16x6_tile_call(const ConvParams *p, int bx, 
     conv_lstm_bf16x6_tile<MREP>(const_params(p), bx, by, tile_lds());
 }
 template <int ND>
-__device__ __noinline__ void composite_tile_call(const CompositeParams *p, int tile, int b) {
-    composite_tile<ND, 10>(const_params(p), tile, b, tile_lds());
+__device__ __noinline__ void composite_tile_call(const CompositeParams *p, int tile, int b, int view) {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
+    composite_tile<ND, 10>(const_params(p), tile, b, goal, tile_lds());
 }
 __device__ __noinline__ void small_item_call(const PhaseDesc *P, int type, int b0, int b1) {
     float *smem = tile_lds();
@@ -138,10 +147,11 @@ template <int ND, int WPS>
 __global__ __launch_bounds__(kConvThreads, WPS) void rollout_persistent_kernel(
     const PhaseDesc *__restrict__ phases, const Schedule sched) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
-    // all LDS in one dynamic array: 4 control words first, the tile workspace after them
+    // all LDS in one dynamic array: the control block first, the tile workspace after it
     int *s_ctl = reinterpret_cast<int *>(smem_all);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ph = 0;
+    if (tid < kMaxCam * kMaxDesig * 2) s_ctl[kCtlGoal + tid] = sched.goal[tid];    // visible after the first barrier
 
     for (;;) {
         [[maybe_unused]] const unsigned long long ts_top = VF_TS_NOW();
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(kConvThreads, WPS) void rollout_persistent_kernel(
             } while (!ok);
             if (lane == 0) {
                 s_ctl[1] = ok ? 1 : 0;
-                if (!sched.debug_no_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         } else if (tid == 0) {
             s_ctl[1] = 1;
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(kConvThreads, WPS) void rollout_persistent_kernel(
                 case PH_FC_PARTIAL:
                     conv_tile_call<1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx);
                     break;
-                case PH_COMPOSITE: composite_tile_call<ND>(&P.comp, local % P.gx, b0); break;
+                case PH_COMPOSITE: composite_tile_call<ND>(&P.comp, local % P.gx, b0, P.view); break;
                 default: small_item_call(&P, P.type, b0, b1); break;
             }
         }
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(kConvThreads, WPS) void rollout_persistent_kernel(
             atomicAdd(sched.stats + 2 * ph + 1, t_end - t_run);
         }
         if (wave == 0) {
-            if (lane == 0 && !sched.debug_no_fence) {
+            if (lane == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }

@@ -4,7 +4,9 @@
 //   cdna_finalize    sum K-split partials of the CDNA FC, relu-shift, L1-normalise each 5x5 kernel
 //   composite        LN9+relu -> rgb/mask heads -> softmax -> CDNA warp -> compositing of the next
 //                    frame and designated-pixel distributions + expected-distance partial sums
-//   scores / export  reduce per-step sums to costs; hand predictions out in the reference layout
+//   scores / export  reduce per-step sums to costs (mean over tasks or trade-off weights, mean over
+//                    latent draws); hand predictions out in the reference layout (camera axis)
+//   register         bilinear warp by a flow field + designated-pixel re-localisation + warp error
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,15 +21,23 @@ constexpr int kCompTile = 16;           // composite: 16x16 pixels per workgroup
 constexpr float kReluShift = 1e-12f;
 
 // ------------------------------------------------------------------------------------------
-__global__ void set_context_kernel(const uint8_t *frames_u8, float *frames_f, int n_frames,
-                                   const float *src_a, float *dst_a, int n_a,
-                                   const float *src_b, float *dst_b, int n_b,
-                                   const float *src_c, float *dst_c, int n_c) {
+// frames_u8 [nc][ncam][HW3] -> frames_f [ncam][nc][HW3] / 255; distrib [nc][ncam][HWD] -> [ncam][nc][HWD];
+// states and context actions are shared by the views and copied as they are
+__global__ void set_context_kernel(const uint8_t *frames_u8, float *frames_f, int nc, int ncam, int hw3,
+                                   const float *src_d, float *dst_d, int hwd,
+                                   const float *src_s, float *dst_s, int n_s,
+                                   const float *src_a, float *dst_a, int n_a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_frames) frames_f[i] = (float)frames_u8[i] / 255.0f;
+    if (i < nc * ncam * hw3) {
+        const int e = i % hw3, v = (i / hw3) % ncam, t = i / (hw3 * ncam);
+        frames_f[((long long)v * nc + t) * hw3 + e] = (float)frames_u8[i] / 255.0f;
+    }
+    if (i < nc * ncam * hwd) {
+        const int e = i % hwd, v = (i / hwd) % ncam, t = i / (hwd * ncam);
+        dst_d[((long long)v * nc + t) * hwd + e] = src_d[i];
+    }
+    if (i < n_s) dst_s[i] = src_s[i];
     if (i < n_a) dst_a[i] = src_a[i];
-    if (i < n_b) dst_b[i] = src_b[i];
-    if (i < n_c) dst_c[i] = src_c[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -115,7 +125,9 @@ struct CompositeParams {
     float *out_frame; long long out_frame_bstride;
     float *out_distrib; long long out_distrib_bstride;
     double *out_sums;                   // [B][ND][ntiles][2]: sum d, sum d * dist(goal)
-    int goal[kMaxDesig][2];             // (row, col)
+    int goal[kMaxDesig][2];             // (row, col); read by the per-layer kernel only - the persistent
+                                        // kernel takes the goals from its launch arguments, so a schedule
+                                        // does not depend on them
 };
 
 // LDS floats needed by composite_tile<ND, K>
@@ -126,7 +138,8 @@ __host__ __device__ constexpr int composite_lds_floats() {
 
 // one 16x16 pixel tile of one sample
 template <int ND, int K, class PT>
-__device__ __forceinline__ void composite_tile(const PT &p, const int tile, const int b, float *smem) {
+__device__ __forceinline__ void composite_tile(const PT &p, const int tile, const int b, const int *goal,
+                                               float *smem) {
     constexpr int TS = kCompTile, HS = TS + 4;
     constexpr int NM = K + 1;
     float *s_frame = smem;                              // [HS*HS*3]
@@ -251,7 +264,7 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             dout[d] = od[d];
-            const float ry = (float)(y - p.goal[d][0]), rx = (float)(x - p.goal[d][1]);
+            const float ry = (float)(y - goal[2 * d]), rx = (float)(x - goal[2 * d + 1]);
             const float dist = sqrtf(fmaf(ry, ry, rx * rx));
             cost[2 * d] = (double)od[d];
             cost[2 * d + 1] = (double)od[d] * (double)dist;
@@ -276,49 +289,192 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
 template <int ND, int K>
 __global__ __launch_bounds__(256) void composite_kernel(const CompositeParams p) {
     __shared__ __attribute__((aligned(16))) float smem[composite_lds_floats<ND, K>()];
-    composite_tile<ND, K>(p, blockIdx.x, blockIdx.y, smem);
+    composite_tile<ND, K>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
 }
 
 // ------------------------------------------------------------------------------------------
-// score_b = mean_p sum_t w_t (S1/S0) / sum_t w_t; sums[t]: [B][ND][ntiles][2]
-__global__ void scores_kernel(const double *sums, long long step_stride, int B, int T, int ND, int ntiles,
-                              float finalweight, float *scores, float *scores_per_task) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+// Cost finalisation.  Per rolled sequence r and task (view v, pixel d):
+//     e[r][v*ND+d] = sum_t w_t (S1/S0)(t, v, r, d) / sum_t w_t,      w = (1, ..., 1, finalweight)
+// (reference pixel_cost_controller.py:168-187); n_draws consecutive sequences are the latent draws
+// of one action and are averaged; the action's score is the plain mean over tasks (reference :153)
+// or, with use_weights, the trade-off weighted sum (register_gtruth_controller.py:88-94).
+// sums[t]: [ncam][Bcap][ND][ntiles][2].  A non-zero *status (a tile of the rollout gave up
+// waiting for its producers) poisons every score with NaN, so a failed rollout cannot feed CEM.
+constexpr int kMaxCam = 4;
+struct TaskWeights { int use; float w[kMaxCam * kMaxDesig]; };
+
+__global__ void scores_kernel(const double *sums, long long step_stride, long long view_stride, int n_actions,
+                              int n_draws, int T, int ND, int ncam, int ntiles, float finalweight,
+                              const TaskWeights tw, const int *status, float *scores, float *scores_per_task) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_actions) return;
+    const int ntask = ncam * ND;
+    const bool poisoned = status && *status != 0;
     double total = 0.0;
-    for (int d = 0; d < ND; ++d) {
-        double acc = 0.0, wsum = 0.0;
-        for (int t = 0; t < T; ++t) {
-            const double *pp = sums + (long long)t * step_stride + ((long long)b * ND + d) * ntiles * 2;
-            double s0 = 0.0, s1 = 0.0;
-            for (int k = 0; k < ntiles; ++k) { s0 += pp[2 * k]; s1 += pp[2 * k + 1]; }
-            const double w = (t == T - 1) ? (double)finalweight : 1.0;
-            acc += w * (s1 / s0);
-            wsum += w;
+    for (int v = 0; v < ncam; ++v)
+        for (int d = 0; d < ND; ++d) {
+            double over_draws = 0.0;
+            for (int j = 0; j < n_draws; ++j) {
+                const long long b = (long long)a * n_draws + j;
+                double acc = 0.0, wsum = 0.0;
+                for (int t = 0; t < T; ++t) {
+                    const double *pp = sums + (long long)t * step_stride + (long long)v * view_stride +
+                                       (b * ND + d) * ntiles * 2;
+                    double s0 = 0.0, s1 = 0.0;
+                    for (int k = 0; k < ntiles; ++k) { s0 += pp[2 * k]; s1 += pp[2 * k + 1]; }
+                    const double w = (t == T - 1) ? (double)finalweight : 1.0;
+                    acc += w * (s1 / s0);
+                    wsum += w;
+                }
+                over_draws += acc / wsum;
+            }
+            const double sc = over_draws / n_draws;
+            const int col = v * ND + d;
+            if (scores_per_task)
+                scores_per_task[(long long)a * ntask + col] = poisoned ? __builtin_nanf("") : (float)sc;
+            total += tw.use ? (double)tw.w[col] * sc : sc;
         }
-        const double sc = acc / wsum;
-        if (scores_per_task) scores_per_task[(long long)b * ND + d] = (float)sc;
-        total += sc;
-    }
-    scores[b] = (float)(total / ND);
+    const double out = tw.use ? total : total / ntask;
+    scores[a] = poisoned ? __builtin_nanf("") : (float)out;
 }
 
-// normalised distributions out: dst[b][t][h][w][d] = src / S0(b,t,d)
-__global__ void export_distrib_kernel(const float *src, const double *sums, long long step_stride,
-                                      int first, int count, int T, int HW, int ND, int ntiles,
-                                      float *dst) {
+// predictions out in the reference layout: dst[bb][t][view][hw][C] <- src[view][Bcap][t][hw][C]
+// (reference vpred_model_interface.py:78,88 stacks the views on axis 2)
+__global__ void export_frames_kernel(const float *src, long long view_stride, int first, int count, int T,
+                                     int ncam, int HWC, float *dst) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long per_sample = (long long)T * HW * ND;
+    const long long per_sample = (long long)T * ncam * HWC;
     if (i >= (long long)count * per_sample) return;
     const int bb = (int)(i / per_sample);
     const long long r = i - (long long)bb * per_sample;
-    const int t = (int)(r / ((long long)HW * ND));
-    const int d = (int)(r % ND);
+    const int t = (int)(r / ((long long)ncam * HWC));
+    const int v = (int)((r / HWC) % ncam);
+    const int e = (int)(r % HWC);
+    dst[i] = src[(long long)v * view_stride + ((long long)(first + bb) * T + t) * HWC + e];
+}
+
+// normalised distributions out: dst[bb][t][view][hw][d] = src[view][b][t][hw][d] / S0(t, view, b, d)
+__global__ void export_distrib_kernel(const float *src, long long view_stride, const double *sums,
+                                      long long step_stride, long long sums_view_stride, int first, int count,
+                                      int T, int ncam, int HW, int ND, int ntiles, float *dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per_sample = (long long)T * ncam * HW * ND;
+    if (i >= (long long)count * per_sample) return;
+    const int bb = (int)(i / per_sample);
+    const long long r = i - (long long)bb * per_sample;
+    const int t = (int)(r / ((long long)ncam * HW * ND));
+    const int v = (int)((r / ((long long)HW * ND)) % ncam);
+    const long long e = r % ((long long)HW * ND);
+    const int d = (int)(e % ND);
     const int b = first + bb;
-    const double *pp = sums + (long long)t * step_stride + ((long long)b * ND + d) * ntiles * 2;
+    const double *pp = sums + (long long)t * step_stride + (long long)v * sums_view_stride +
+                       ((long long)b * ND + d) * ntiles * 2;
     double s0 = 0.0;
     for (int k = 0; k < ntiles; ++k) s0 += pp[2 * k];
-    dst[i] = (float)((double)src[(long long)b * per_sample + r] / s0);
+    dst[i] = (float)((double)src[(long long)v * view_stride + ((long long)b * T + t) * HW * ND + e] / s0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Registration (reference register_gtruth_controller.py:54-173).  A flow field (dx, dy) per
+// reference pixel - the output of the plug-in registration network - maps reference pixel
+// (r, c) to the point (x, y) = (c + dx, r + dy) of the current frame ("warp_pts", :64-66).
+__device__ __forceinline__ float bilinear_clamped(const float *img, int H, int W, float x, float y, int ch) {
+    x = fminf(fmaxf(x, 0.f), (float)(W - 1));
+    y = fminf(fmaxf(y, 0.f), (float)(H - 1));
+    const int x0 = (int)floorf(x), y0 = (int)floorf(y);
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const float fx = x - (float)x0, fy = y - (float)y0;
+    const float a = img[((long long)y0 * W + x0) * 3 + ch], b = img[((long long)y0 * W + x1) * 3 + ch];
+    const float c = img[((long long)y1 * W + x0) * 3 + ch], d = img[((long long)y1 * W + x1) * 3 + ch];
+    const float top = fmaf(fx, b - a, a), bot = fmaf(fx, d - c, c);
+    return fmaf(fy, bot - top, top);
+}
+
+// warped[cam][r][c][:] = bilinear(current[cam], warp_pts[cam][r][c]);  pts[cam][r][c] = (x, y)
+__global__ void warp_image_kernel(const float *cur, const float *flow, int ncam, int H, int W, float *warped,
+                                  float *pts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncam * H * W) return;
+    const int cam = i / (H * W), r = (i / W) % H, c = i % W;
+    const float x = (float)c + flow[2 * i], y = (float)r + flow[2 * i + 1];
+    if (pts) { pts[2 * i] = x; pts[2 * i + 1] = y; }
+    if (warped)
+        for (int ch = 0; ch < 3; ++ch)
+            warped[3 * (long long)i + ch] = bilinear_clamped(cur + (long long)cam * H * W * 3, H, W, x, y, ch);
+}
+
+// One workgroup (128 threads) per (camera, task): re-localise the task's pixel and measure the
+// warp error.  region == 0: the flow and the L2 photometric error at the pixel itself (:129-135,
+// 163-170); region > 0: median flow and mean squared error over the (2*region+1)^2 window
+// clipped to [0, size - clip_sub] (:139-161; the reference clips the start window with
+// clip_sub = 1 and the goal window with 0).  desig = (row, col) float; an empty window gives NaN.
+constexpr int kRegMaxWin = 11 * 11;
+__global__ __launch_bounds__(128) void register_kernel(const float *cur, const float *ref, const float *flow,
+                                                       const int *pix, int ncam, int ntask, int H, int W,
+                                                       int region, int clip_sub, float *desig, float *err) {
+    __shared__ float s_x[kRegMaxWin], s_y[kRegMaxWin];
+    __shared__ double s_red[2];
+    __shared__ float s_med[4];
+    const int cam = blockIdx.x / ntask, task = blockIdx.x % ntask, tid = threadIdx.x;
+    const int pr = pix[(cam * ntask + task) * 2], pc = pix[(cam * ntask + task) * 2 + 1];
+    const float *cur_c = cur + (long long)cam * H * W * 3, *ref_c = ref + (long long)cam * H * W * 3;
+    const float *flow_c = flow + (long long)cam * H * W * 2;
+    float *out_d = desig + (cam * ntask + task) * 2;
+    if (region == 0) {
+        if (tid == 0) {
+            const int r = min(max(pr, 0), H - 1), c = min(max(pc, 0), W - 1);
+            const float x = (float)c + flow_c[(r * W + c) * 2], y = (float)r + flow_c[(r * W + c) * 2 + 1];
+            double acc = 0.0;
+            for (int ch = 0; ch < 3; ++ch) {
+                const float df = ref_c[(r * W + c) * 3 + ch] - bilinear_clamped(cur_c, H, W, x, y, ch);
+                acc += (double)df * (double)df;
+            }
+            out_d[0] = y; out_d[1] = x;
+            err[cam * ntask + task] = (float)sqrt(acc);
+        }
+        return;
+    }
+    const int hi_r = H - clip_sub, hi_c = W - clip_sub;
+    const int r0 = min(max(pr - region, 0), hi_r), r1 = min(max(pr + region + 1, 0), hi_r);
+    const int c0 = min(max(pc - region, 0), hi_c), c1 = min(max(pc + region + 1, 0), hi_c);
+    const int wh = max(r1 - r0, 0), ww = max(c1 - c0, 0), n = wh * ww;
+    if (n == 0) {
+        if (tid == 0) { out_d[0] = out_d[1] = __builtin_nanf(""); err[cam * ntask + task] = __builtin_nanf(""); }
+        return;
+    }
+    double sq = 0.0;
+    if (tid < n) {
+        const int r = r0 + tid / ww, c = c0 + tid % ww;
+        const float x = (float)c + flow_c[(r * W + c) * 2], y = (float)r + flow_c[(r * W + c) * 2 + 1];
+        s_x[tid] = x; s_y[tid] = y;
+        for (int ch = 0; ch < 3; ++ch) {
+            const float df = ref_c[(r * W + c) * 3 + ch] - bilinear_clamped(cur_c, H, W, x, y, ch);
+            sq += (double)df * (double)df;
+        }
+    }
+    sq = wave_sum(sq);
+    if ((tid & 63) == 0) s_red[tid >> 6] = sq;
+    __syncthreads();
+    // medians by rank: element i has rank #{j : v_j < v_i or (v_j == v_i and j < i)}
+    if (tid < n) {
+        const float vx = s_x[tid], vy = s_y[tid];
+        int rx = 0, ry = 0;
+        for (int j = 0; j < n; ++j) {
+            rx += (s_x[j] < vx) || (s_x[j] == vx && j < tid);
+            ry += (s_y[j] < vy) || (s_y[j] == vy && j < tid);
+        }
+        const int lo = (n - 1) / 2, hi = n / 2;
+        if (rx == lo) s_med[0] = vx;
+        if (rx == hi) s_med[1] = vx;
+        if (ry == lo) s_med[2] = vy;
+        if (ry == hi) s_med[3] = vy;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        out_d[0] = 0.5f * (s_med[2] + s_med[3]);        // row <- median y
+        out_d[1] = 0.5f * (s_med[0] + s_med[1]);        // col <- median x
+        err[cam * ntask + task] = (float)((s_red[0] + s_red[1]) / (double)(3 * n));
+    }
 }
 
 }  // namespace vf

@@ -17,6 +17,13 @@ intent on top of ``PixelCostController``:
 The reference stores the trade-off but its parent scores with a plain mean over tasks
 (``pixel_cost_controller.py:153``); ``trade_off_reg=True`` (the reference's commented-out
 hyper-parameter, ``:32``) applies the weights, ``False`` keeps the plain mean.
+
+With a predictor that offers ``register()`` (``HipVPredEvaluation``) the arithmetic of
+``get_warp_err`` - bilinear warp of the current frame by the registration network's flow field,
+window median of the warp points, photometric warp error - runs on the GPU (``vf_register``,
+``include/vf_hip.h``) and the trade-off weights are applied inside the fused score kernel; the
+plug-in only has to supply the flow field.  Any other predictor takes the NumPy path of
+``registration.py`` on the plug-in's own ``(warped, flow, warp_pts)``.
 """
 import numpy as np
 
@@ -41,6 +48,7 @@ class RegisterGtruthController(PixelCostController):
         params.add_hparam('register_region', False)
         params.add_hparam('trade_off_reg', False)
         params.add_hparam('registration_warper', None)    # callable, see registration.py
+        params.add_hparam('registration_on_device', True)  # use predictor.register() when it exists
         return params
 
     # ------------------------------------------------------------------ registration
@@ -49,18 +57,33 @@ class RegisterGtruthController(PixelCostController):
         if self.goal_image_warper is None:
             raise ValueError("RegisterGtruthController needs the 'registration_warper' hyper-parameter")
         regs = self._hp.register_gtruth
-        warped_start = start_pts = warped_goal = goal_pts = None
-        if 'start' in regs:
-            warped_start, _, start_pts = self.goal_image_warper(current_image, start_image)
-        if 'goal' in regs:
-            warped_goal, _, goal_pts = self.goal_image_warper(current_image, self.goal_image)
-        errs, desig = [], []
-        for icam in range(self._n_cam):
-            e, d = get_warp_err(icam, self.desig_pix_t0[icam], self.goal_pix_sel[icam], start_image,
-                                self.goal_image, start_pts, goal_pts, warped_start, warped_goal,
-                                register_gtruth=regs, register_region=self._hp.register_region)
-            errs.append(e)
-            desig.append(d)
+        H = start_image.shape[1]
+        if hasattr(self.predictor, 'register') and self._hp.registration_on_device:
+            region = (5 if H >= 96 else 2) if self._hp.register_region else 0
+            per_reg = []
+            if 'start' in regs:
+                _, flow, _ = self.goal_image_warper(current_image, start_image)
+                per_reg.append(self.predictor.register(current_image, start_image, flow, self.desig_pix_t0,
+                                                       region=region, clip_sub=1))
+            if 'goal' in regs:
+                _, flow, _ = self.goal_image_warper(current_image, self.goal_image)
+                per_reg.append(self.predictor.register(current_image, self.goal_image, flow, self.goal_pix_sel,
+                                                       region=region, clip_sub=0))
+            desig = [np.stack([d[icam] for d, _ in per_reg], axis=1) for icam in range(self._n_cam)]   # [ntask, nreg, 2]
+            errs = [np.stack([e[icam] for _, e in per_reg], axis=1) for icam in range(self._n_cam)]    # [ntask, nreg]
+        else:
+            warped_start = start_pts = warped_goal = goal_pts = None
+            if 'start' in regs:
+                warped_start, _, start_pts = self.goal_image_warper(current_image, start_image)
+            if 'goal' in regs:
+                warped_goal, _, goal_pts = self.goal_image_warper(current_image, self.goal_image)
+            errs, desig = [], []
+            for icam in range(self._n_cam):
+                e, d = get_warp_err(icam, self.desig_pix_t0[icam], self.goal_pix_sel[icam], start_image,
+                                    self.goal_image, start_pts, goal_pts, warped_start, warped_goal,
+                                    register_gtruth=regs, register_region=self._hp.register_region)
+                errs.append(e)
+                desig.append(d)
         warperrs = np.stack(errs, 0)                                    # [ncam, ntask, nreg]
         tradeoff = tradeoff_weights(warperrs).reshape(self._n_cam, self._n_desig)
         self.plan_stat['tradeoff'] = tradeoff

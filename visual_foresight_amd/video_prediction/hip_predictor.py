@@ -10,6 +10,10 @@ slices the last ``n_context`` frames itself (reference ``video_prediction/pred_u
 and chunks the sample batch by ``run_batch_size`` (``pred_util.py:21-48``; the last chunk is
 simply run ragged instead of zero-padded - samples are independent).
 
+Multi-view models (the reference's ``IndepMultiSAVP...`` family: one network per view sharing
+actions and states, outputs stacked on a camera axis, ``vpred_model_interface.py:60-88``) are
+one engine with ``ncam`` weight sets: every view of every sample is rolled by the same launch.
+
 On top of that contract it offers the fused fast path ``score()``: rollouts are reduced to
 per-sample costs on the GPU, sharded over the ranks of ``torch.distributed`` when that is
 initialised (rank r evaluates samples ``[r*M/G, (r+1)*M/G)``; reference tower slicing
@@ -32,19 +36,22 @@ from visual_foresight_amd.video_prediction.sharding import dist_info as _dist_in
 
 class HipVPredEvaluation(object):
     wants_agent_params = True       # PixelCostController passes adim/sdim/size/sequence_length
+    supports_task_weights = True    # score(..., task_weights=) applies trade-off weights on the device
     n_context_default = 2
 
     def __init__(self, model_path, hparams, n_gpus=1, first_gpu=0):
         import torch
         self._torch = torch
         hp = dict(hparams)
-        self.model_path = os.path.expanduser(model_path) if model_path else ''
+        if isinstance(model_path, (list, tuple)):
+            self.model_path = [os.path.expanduser(p) for p in model_path]
+        else:
+            self.model_path = os.path.expanduser(model_path) if model_path else ''
         self.n_context = int(hp.get('n_context', self.n_context_default))
         self.sequence_length = int(hp.get('sequence_length', 15))
         self.n_cam = int(hp.get('ncam', 1))
-        if self.n_cam != 1:
-            raise NotImplementedError('HipVPredEvaluation drives one view; multi-view is one predictor per view')
-        self.run_batch_size = int(hp.get('run_batch_size', 200))
+        self.n_draws = int(hp.get('n_draws', 1))        # latent draws per action (stochastic_predictor.py)
+        self.run_batch_size = int(hp.get('run_batch_size', 200)) * self.n_draws
         self.seed = int(hp.get('seed', 0))
         self.cfg = CdnaConfig(height=hp.get('image_height', 64), width=hp.get('image_width', 64),
                               adim=hp.get('adim', 4), sdim=hp.get('sdim', 5),
@@ -64,7 +71,7 @@ class HipVPredEvaluation(object):
         self.precision = {'fp32': 0, '0': 0, 0: 0, 'bf16x6': 1, '1': 1, 1: 1}[precision]
         self._c_cfg = _lib.VfConfig(c.height, c.width, c.adim, c.sdim, c.ndesig, c.n_context,
                                     c.sequence_length, c.num_masks, self.run_batch_size,
-                                    self.device_index, self.precision)
+                                    self.device_index, self.precision, self.n_cam, self.n_draws)
         self._handle = ctypes.c_void_p()
         _lib.check(self._libh.vf_create(ctypes.byref(self._c_cfg), ctypes.byref(self._handle)))
         self.set_substreams(int(hp.get('substreams', os.environ.get('VF_SUBSTREAMS', 1))))
@@ -101,9 +108,17 @@ class HipVPredEvaluation(object):
         self.persistent = bool(enable)
 
     def device_status(self):
+        """Synchronise, return the sticky failure word of the persistent kernel (0 = healthy), re-arm it."""
         st = ctypes.c_int32()
         _lib.check(self._libh.vf_device_status(self._handle, ctypes.byref(st)))
         return st.value
+
+    def _check_scores(self, scores_np):
+        """A rollout whose tiles gave up waiting poisons its scores with NaN (vf_hip.h): never hand
+        them to the elite selection."""
+        if np.isnan(scores_np).any():
+            raise _lib.VfError('the persistent rollout kernel reported a failure (device status %d): a tile gave '
+                               'up waiting for its producers; scores are invalid' % self.device_status())
 
     def set_dedup(self, enable):
         """Switch context de-duplication (bit-identical results either way; for A/B timing)."""
@@ -116,16 +131,24 @@ class HipVPredEvaluation(object):
 
     # ------------------------------------------------------------------ weights
     def restore(self, weights=None):
-        """Load ``model_path`` (manifest.json + weights.bin) or, with no path, seeded random weights."""
+        """Load ``model_path`` (manifest.json + weights.bin; ``view%d/`` sub-directories or a list of paths for
+        several views) or, with no path, seeded random weights (seed + view)."""
         if weights is None:
-            if self.model_path:
-                weights = CdnaWeights.load(self.model_path, self.cfg)
-            else:
-                weights = CdnaWeights.random(self.cfg, seed=self.seed)
-        self.weights = weights
+            weights = []
+            for v in range(self.n_cam):
+                path = self.model_path[v] if isinstance(self.model_path, (list, tuple)) else self.model_path
+                if path and self.n_cam > 1 and os.path.isdir(os.path.join(path, 'view%d' % v)):
+                    path = os.path.join(path, 'view%d' % v)
+                weights.append(CdnaWeights.load(path, self.cfg) if path else
+                               CdnaWeights.random(self.cfg, seed=self.seed + v))
+        elif not isinstance(weights, (list, tuple)):
+            weights = [weights]
+        if len(weights) != self.n_cam:
+            raise ValueError('need one weight set per view (%d), got %d' % (self.n_cam, len(weights)))
+        self.weights = weights[0] if self.n_cam == 1 else list(weights)
         self._ctx_key = None
-        blob = np.concatenate([v.ravel() for v in weights.tensors.values()]).astype(np.float32)
-        want = self._libh.vf_weight_count(ctypes.byref(self._c_cfg))
+        blob = np.concatenate([v.ravel() for w in weights for v in w.tensors.values()]).astype(np.float32)
+        want = self._libh.vf_weight_count(ctypes.byref(self._c_cfg)) * self.n_cam
         if blob.size != want:
             raise _lib.VfError('weight blob has %d floats, library expects %d' % (blob.size, want))
         _lib.check(self._libh.vf_load_weights(self._handle, blob.ctypes.data_as(ctypes.c_void_p),
@@ -138,14 +161,15 @@ class HipVPredEvaluation(object):
 
     def _set_context(self, context):
         torch, nc, c = self._torch, self.n_context, self.cfg
-        frames = np.ascontiguousarray(np.asarray(context['context_frames'])[-nc:, 0])
-        if frames.dtype != np.uint8 or frames.shape != (nc, c.height, c.width, 3):
-            raise ValueError('context_frames must be uint8 [>=%d, 1, %d, %d, 3], got %s %s'
-                             % (nc, c.height, c.width, frames.dtype, frames.shape))
+        ncam = self.n_cam
+        frames = np.ascontiguousarray(np.asarray(context['context_frames'])[-nc:, :ncam])
+        if frames.dtype != np.uint8 or frames.shape != (nc, ncam, c.height, c.width, 3):
+            raise ValueError('context_frames must be uint8 [>=%d, %d, %d, %d, 3], got %s %s'
+                             % (nc, ncam, c.height, c.width, frames.dtype, frames.shape))
         distrib = np.ascontiguousarray(
-            np.asarray(context['context_pixel_distributions'], dtype=np.float32)[-nc:, 0])
+            np.asarray(context['context_pixel_distributions'], dtype=np.float32)[-nc:, :ncam])
         states = np.ascontiguousarray(np.asarray(context['context_states'], dtype=np.float32)[-nc:])
-        if states.shape != (nc, c.sdim) or distrib.shape != (nc, c.height, c.width, c.ndesig):
+        if states.shape != (nc, c.sdim) or distrib.shape != (nc, ncam, c.height, c.width, c.ndesig):
             raise ValueError('bad context shapes: states %s distrib %s' % (states.shape, distrib.shape))
         if nc > 1:
             acts = np.asarray(context['context_actions'], dtype=np.float32).reshape(-1, c.adim)[-(nc - 1):]
@@ -167,76 +191,81 @@ class HipVPredEvaluation(object):
                                              d.data_ptr(), self._stream()))
 
     # ------------------------------------------------------------------ rollouts
-    def _rollout_chunk(self, actions_dev, goal_pix, finalweight, scores_dev, per_task_dev):
+    def _rollout_chunk(self, actions_dev, goal_pix, finalweight, scores_dev, per_task_dev, task_weights=None):
         B = actions_dev.shape[0]
-        goal = (ctypes.c_int32 * (2 * self.cfg.ndesig))(*[int(v) for v in np.asarray(goal_pix).reshape(-1)])
-        _lib.check(self._libh.vf_rollout(self._handle, actions_dev.data_ptr(), B, goal,
-                                         ctypes.c_float(finalweight), scores_dev.data_ptr(),
+        ntask = self.n_cam * self.cfg.ndesig
+        goal = np.asarray(goal_pix).reshape(-1)
+        if goal.size != 2 * ntask:
+            raise ValueError('goal_pix must hold [ncam=%d][ndesig=%d][2] values, got %d'
+                             % (self.n_cam, self.cfg.ndesig, goal.size))
+        goal_c = (ctypes.c_int32 * (2 * ntask))(*[int(v) for v in goal])
+        tw = None
+        if task_weights is not None:
+            w = np.asarray(task_weights, dtype=np.float64).reshape(-1)
+            if w.size != ntask:
+                raise ValueError('task_weights must hold ncam*ndesig = %d values' % ntask)
+            tw = (ctypes.c_float * ntask)(*[float(v) for v in w])
+        _lib.check(self._libh.vf_rollout(self._handle, actions_dev.data_ptr(), B, goal_c,
+                                         ctypes.c_float(finalweight), tw, scores_dev.data_ptr(),
                                          per_task_dev.data_ptr(), self._stream()))
 
     def _check_actions(self, actions):
         actions = np.asarray(actions)
         T = self.sequence_length - self.n_context
-        if actions.ndim != 3 or actions.shape[1] != T or actions.shape[2] != self.cfg.adim:
-            raise ValueError('actions must be [M, %d, %d], got %s' % (T, self.cfg.adim, actions.shape))
+        if actions.ndim != 3 or actions.shape[1] != T or actions.shape[2] != self._adim_in():
+            raise ValueError('actions must be [M, %d, %d], got %s' % (T, self._adim_in(), actions.shape))
         return actions
 
-    def _score_device(self, context, actions, goal_pix, finalweight, index_base=0):
-        """Roll ALL given action sequences on this rank -> device tensors (scores[n], per_task[n, nd]).
+    # hooks of the stochastic predictor: the caller's actions -> the sequences the engine rolls
+    def _adim_in(self):
+        return self.cfg.adim
+
+    def _prepare(self, context, actions):
+        """(context, actions[n]) -> (engine context, sequences[n * n_draws])."""
+        return context, actions
+
+    def _score_device(self, context, actions, goal_pix, finalweight, index_base=0, task_weights=None):
+        """Roll ALL given actions on this rank -> device tensors (scores[n], per_task[n, ncam*nd]).
 
         ``index_base`` is the global index of ``actions[0]`` (what ``fetch_pixel_distributions`` is asked for).
         """
         torch = self._torch
-        nd = self.cfg.ndesig
-        goal = np.asarray(goal_pix).reshape(self.n_cam, nd, 2)[0]
+        ntask = self.n_cam * self.cfg.ndesig
+        nd = self.n_draws
         n = actions.shape[0]
+        context, seqs = self._prepare(context, actions)
         self._set_context(context)
-        local = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32)).to(self.device)
+        local = torch.from_numpy(np.ascontiguousarray(seqs, dtype=np.float32)).to(self.device)
         scores = torch.empty(n, dtype=torch.float32, device=self.device)
-        per_task = torch.empty((n, nd), dtype=torch.float32, device=self.device)
-        bs = self.run_batch_size
+        per_task = torch.empty((n, ntask), dtype=torch.float32, device=self.device)
+        bs = self.run_batch_size // nd          # actions per chunk
         for c0 in range(0, n, bs):
             c1 = min(c0 + bs, n)
-            self._rollout_chunk(local[c0:c1], goal, finalweight, scores[c0:c1], per_task[c0:c1])
+            self._rollout_chunk(local[c0 * nd:c1 * nd], goal_pix, finalweight, scores[c0:c1], per_task[c0:c1],
+                                task_weights)
             self._last_lo, self._last_M = index_base + c0, c1 - c0
         return scores, per_task
 
-    def _score_local(self, context, actions, goal_pix, finalweight):
-        """Like ``score`` but without sharding or collectives -> (scores, per_task) float64."""
-        actions = self._check_actions(actions)
-        with self._torch.cuda.device(self.device):
-            scores, per_task = self._score_device(context, actions, goal_pix, finalweight)
-            return scores.cpu().numpy().astype(np.float64), per_task.cpu().numpy().astype(np.float64)
+    def score(self, context, inputs, goal_pix, finalweight=10., only_take_first_view=False, task_weights=None):
+        """Fused rollout + expected-pixel-distance cost.  Returns (scores[M], scores_per_task[M, ncam*nd]) float64.
 
-    def fetch_pixel_distributions_local(self, local_index):
-        """Like fetch_pixel_distributions, for an index into the block passed to _score_local."""
-        torch, c = self._torch, self.cfg
-        T = self.sequence_length - self.n_context
-        k = local_index - self._last_lo
-        if not 0 <= k < self._last_M:
-            raise IndexError('sample %d is not resident' % local_index)
-        out = torch.zeros((T, c.height, c.width, c.ndesig), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(self._libh.vf_export(self._handle, int(k), 1, None, out.data_ptr(), None, self._stream()))
-        return out.cpu().numpy()[:, None]
-
-    def score(self, context, inputs, goal_pix, finalweight=10., only_take_first_view=False):
-        """Fused rollout + expected-pixel-distance cost.  Returns (scores[M], scores_per_task[M, nd]) float64.
-
-        Only the chunk evaluated last stays resident for ``fetch_pixel_distributions``; with
-        ``M <= run_batch_size`` (the reference default, ``pixel_cost_controller.py:31``) that is
-        the whole local shard.
+        ``task_weights`` ([ncam, ndesig] trade-off weights, reference ``register_gtruth_controller.py:88-94``)
+        replace the plain mean over tasks.  Only the chunk evaluated last stays resident for
+        ``fetch_pixel_distributions``; with ``M <= run_batch_size`` (the reference default,
+        ``pixel_cost_controller.py:31``) that is the whole local shard.
         """
         actions = self._check_actions(inputs['actions'])
         M = actions.shape[0]
         rank, world = _dist_info()
         lo, hi = shard_bounds(M, rank, world)
         with self._torch.cuda.device(self.device):
-            scores, per_task = self._score_device(context, actions[lo:hi], goal_pix, finalweight, index_base=lo)
+            scores, per_task = self._score_device(context, actions[lo:hi], goal_pix, finalweight, index_base=lo,
+                                                  task_weights=task_weights)
             if world > 1:
                 scores, per_task = self._all_gather(scores, per_task, M, world)
             scores_np = scores.cpu().numpy().astype(np.float64)
             per_task_np = per_task.cpu().numpy().astype(np.float64)
+        self._check_scores(scores_np)
         if only_take_first_view:
             per_task_np = per_task_np[:, :1]
             scores_np = per_task_np[:, 0].copy()
@@ -249,17 +278,19 @@ class HipVPredEvaluation(object):
         return out[:, 0].contiguous(), out[:, 1:].contiguous()
 
     def fetch_pixel_distributions(self, sample_index):
-        """Normalised distributions ``[T, ncam, H, W, ndesig]`` of one sample of the last rollout."""
+        """Normalised distributions ``[T, ncam, H, W, ndesig]`` of one action of the last rollout (its first
+        latent draw).  Under ``torch.distributed`` the owning rank exports it and a tiny all-reduce hands it
+        to the others (everybody else adds zeros)."""
         torch, c = self._torch, self.cfg
         T = self.sequence_length - self.n_context
         rank, world = _dist_info()
         local = sample_index - self._last_lo
         have = 0 <= local < self._last_M
-        out = torch.zeros((T, c.height, c.width, c.ndesig), dtype=torch.float32, device=self.device)
+        out = torch.zeros((T, self.n_cam, c.height, c.width, c.ndesig), dtype=torch.float32, device=self.device)
         if have:
             with torch.cuda.device(self.device):
-                _lib.check(self._libh.vf_export(self._handle, int(local), 1, None, out.data_ptr(), None,
-                                                self._stream()))
+                _lib.check(self._libh.vf_export(self._handle, int(local) * self.n_draws, 1, None, out.data_ptr(),
+                                                None, self._stream()))
         if world > 1:
             import torch.distributed as dist
             if dist.get_backend() == 'gloo':
@@ -271,7 +302,40 @@ class HipVPredEvaluation(object):
         elif not have:
             raise IndexError('sample %d is not resident (last chunk holds [%d, %d))'
                              % (sample_index, self._last_lo, self._last_lo + self._last_M))
-        return out.cpu().numpy()[:, None]
+        return out.cpu().numpy()
+
+    # ------------------------------------------------------------------ registration
+    def register(self, current, reference, flow, pix, region=0, clip_sub=1, want_warped=False):
+        """Device side of ``get_warp_err`` (reference ``register_gtruth_controller.py:113-173``).
+
+        current, reference ``[ncam, H, W, 3]`` float images, flow ``[ncam, H, W, 2]`` (dx, dy) of the plug-in
+        registration network, pix ``[ncam, ntask, 2]`` (row, col) in the reference image.  Returns
+        ``desig [ncam, ntask, 2]`` (row, col in the current frame), ``err [ncam, ntask]`` and, on request,
+        the warped frame ``[ncam, H, W, 3]`` and the warp points ``[ncam, H, W, 2]`` (x, y).
+        """
+        torch, c = self._torch, self.cfg
+        cur = np.ascontiguousarray(current, dtype=np.float32)
+        ref = np.ascontiguousarray(reference, dtype=np.float32)
+        fl = np.ascontiguousarray(flow, dtype=np.float32)
+        px = np.ascontiguousarray(pix, dtype=np.int32).reshape(self.n_cam, -1, 2)
+        if cur.shape != (self.n_cam, c.height, c.width, 3) or ref.shape != cur.shape or \
+                fl.shape != (self.n_cam, c.height, c.width, 2):
+            raise ValueError('register: need [ncam, H, W, 3] images and a [ncam, H, W, 2] flow field')
+        ntask = px.shape[1]
+        with torch.cuda.device(self.device):
+            d_cur, d_ref, d_fl, d_px = (torch.from_numpy(a).to(self.device) for a in (cur, ref, fl, px))
+            desig = torch.empty((self.n_cam, ntask, 2), dtype=torch.float32, device=self.device)
+            err = torch.empty((self.n_cam, ntask), dtype=torch.float32, device=self.device)
+            warped = torch.empty_like(d_cur) if want_warped else None
+            pts = torch.empty_like(d_fl) if want_warped else None
+            _lib.check(self._libh.vf_register(
+                self._handle, d_cur.data_ptr(), d_ref.data_ptr(), d_fl.data_ptr(), d_px.data_ptr(), ntask,
+                int(region), int(clip_sub), warped.data_ptr() if want_warped else None,
+                pts.data_ptr() if want_warped else None, desig.data_ptr(), err.data_ptr(), self._stream()))
+            out = desig.cpu().numpy().astype(np.float64), err.cpu().numpy().astype(np.float64)
+            if want_warped:
+                out = out + (warped.cpu().numpy(), pts.cpu().numpy())
+        return out
 
     def predictor_func(self):
         """The legacy boundary (reference ``video_prediction/setup_predictor.py:164-200``): a callable
@@ -289,6 +353,8 @@ class HipVPredEvaluation(object):
         """
         nc, c = self.n_context, self.cfg
         T = self.sequence_length - nc
+        if self.n_cam != 1 or self.n_draws != 1:
+            raise NotImplementedError('the legacy predictor_func boundary is single-view, deterministic')
 
         def predictor_func(input_images=None, input_one_hot_images=None, input_state=None, input_actions=None):
             acts = np.asarray(input_actions, dtype=np.float64)
@@ -318,32 +384,37 @@ class HipVPredEvaluation(object):
         return predictor_func
 
     def __call__(self, context, inputs):
-        """Reference-compatible path: materialise all predicted frames and distributions on the host."""
+        """Reference-compatible path: materialise all predicted frames and distributions on the host
+        (``[M, T, ncam, H, W, C]``; with latent draws, the first draw of every action)."""
         torch, c = self._torch, self.cfg
         actions = self._check_actions(inputs['actions'])
         M, T = actions.shape[:2]
-        frames = np.empty((M, T, 1, c.height, c.width, 3), np.float32)
-        distrib = np.empty((M, T, 1, c.height, c.width, c.ndesig), np.float32)
+        ncam, nd = self.n_cam, self.n_draws
+        frames = np.empty((M, T, ncam, c.height, c.width, 3), np.float32)
+        distrib = np.empty((M, T, ncam, c.height, c.width, c.ndesig), np.float32)
         states = np.empty((M, T, c.sdim), np.float32)
-        zero_goal = np.zeros((c.ndesig, 2), np.int32)
-        bs = self.run_batch_size
+        zero_goal = np.zeros((ncam, c.ndesig, 2), np.int32)
+        bs = self.run_batch_size // nd
         with torch.cuda.device(self.device):
+            context, seqs = self._prepare(context, actions)
             self._set_context(context)
-            acts = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32)).to(self.device)
+            acts = torch.from_numpy(np.ascontiguousarray(seqs, dtype=np.float32)).to(self.device)
             scores = torch.empty(bs, dtype=torch.float32, device=self.device)
-            per_task = torch.empty((bs, c.ndesig), dtype=torch.float32, device=self.device)
+            per_task = torch.empty((bs, ncam * c.ndesig), dtype=torch.float32, device=self.device)
             for c0 in range(0, M, bs):
                 c1 = min(c0 + bs, M)
                 n = c1 - c0
-                self._rollout_chunk(acts[c0:c1], zero_goal, 1.0, scores[:n], per_task[:n])
+                self._rollout_chunk(acts[c0 * nd:c1 * nd], zero_goal, 1.0, scores[:n], per_task[:n])
                 self._last_lo, self._last_M = c0, n
-                f = torch.empty((n, T, c.height, c.width, 3), dtype=torch.float32, device=self.device)
-                d = torch.empty((n, T, c.height, c.width, c.ndesig), dtype=torch.float32, device=self.device)
-                s = torch.empty((n, T, c.sdim), dtype=torch.float32, device=self.device)
-                _lib.check(self._libh.vf_export(self._handle, 0, n, f.data_ptr(), d.data_ptr(), s.data_ptr(),
+                f = torch.empty((n * nd, T, ncam, c.height, c.width, 3), dtype=torch.float32, device=self.device)
+                d = torch.empty((n * nd, T, ncam, c.height, c.width, c.ndesig), dtype=torch.float32,
+                                device=self.device)
+                s = torch.empty((n * nd, T, c.sdim), dtype=torch.float32, device=self.device)
+                _lib.check(self._libh.vf_export(self._handle, 0, n * nd, f.data_ptr(), d.data_ptr(), s.data_ptr(),
                                                 self._stream()))
-                frames[c0:c1, :, 0] = f.cpu().numpy()
-                distrib[c0:c1, :, 0] = d.cpu().numpy()
-                states[c0:c1] = s.cpu().numpy()
+                frames[c0:c1] = f[::nd].cpu().numpy()
+                distrib[c0:c1] = d[::nd].cpu().numpy()
+                states[c0:c1] = s[::nd].cpu().numpy()
+            self._check_scores(scores[:n].cpu().numpy())
         return {'predicted_frames': frames, 'predicted_pixel_distributions': distrib,
                 'predicted_states': states}

@@ -11,19 +11,18 @@ latent ``z_t`` enters exactly where the action does (tiled and concatenated at t
 Every action sequence is rolled ``n_latent`` times with common random numbers (draw ``d`` uses the
 same ``z[d, t]`` for every action, redrawn per planning call from ``latent_seed``), which keeps the
 comparison between candidates low-variance; the reference's vestigial hook repeats each action
-``stochastic_planning[0]`` times (``samplers/gaussian_sampler.py:140-141``).  Draws of one action
-stay on one rank, so the mean is local and the all-gather still moves one row per action.
+``stochastic_planning[0]`` times (``samplers/gaussian_sampler.py:140-141``).  The draws of one
+action are consecutive rows of the rolled batch, the engine averages their costs on the device
+(``vf_config.n_draws``), so one score row per ACTION leaves the GPU and the all-gather and the
+propagation fetch work exactly as for the deterministic predictor (sharded by action, owner rank
+exports, all-reduce).
 """
 import numpy as np
 
 from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
-from visual_foresight_amd.video_prediction.sharding import dist_info, shard_bounds, all_gather_rows
 
 
-class StochasticHipPredictor(object):
-    wants_agent_params = True
-    n_context_default = HipVPredEvaluation.n_context_default
-
+class StochasticHipPredictor(HipVPredEvaluation):
     options = {}            # class-level defaults, see with_options()
 
     @classmethod
@@ -38,62 +37,38 @@ class StochasticHipPredictor(object):
         self.zdim = int(hp.pop('zdim', 8))
         self.latent_seed = int(hp.pop('latent_seed', 0))
         self.adim = int(hp.get('adim', 4))
-        batch = int(hp.get('run_batch_size', 200))
-        inner = dict(hp, adim=self.adim + self.zdim, run_batch_size=batch * self.n_latent)
-        self.engine = HipVPredEvaluation(model_path, inner, n_gpus=n_gpus, first_gpu=first_gpu)
-        self.n_context, self.sequence_length = self.engine.n_context, self.engine.sequence_length
-        self.n_cam = 1
         self._calls = 0
-
-    def restore(self, weights=None):
-        self.engine.restore(weights)
-        return self
-
-    @property
-    def weights(self):
-        return self.engine.weights
+        self._z = None
+        inner = dict(hp, adim=self.adim + self.zdim, n_draws=self.n_latent)
+        super(StochasticHipPredictor, self).__init__(model_path, inner, n_gpus=n_gpus, first_gpu=first_gpu)
 
     def draw_latents(self, T):
         """z[n_latent, T, zdim] for this planning call (deterministic in latent_seed and call count)."""
         rs = np.random.RandomState(self.latent_seed + self._calls)
         return rs.normal(0.0, 1.0, (self.n_latent, T, self.zdim))
 
-    def _augment(self, context, actions, z):
-        M, T = actions.shape[:2]
-        tiled = np.repeat(actions, self.n_latent, axis=0)                                   # [M*n, T, adim]
-        zz = np.tile(z, (M, 1, 1))                                                          # draw-minor order
+    def _adim_in(self):
+        return self.adim
+
+    def _prepare(self, context, actions):
+        """Fold the latent draws into the sample axis, draw-minor: row ``a * n_latent + d`` = action a, draw d."""
+        actions = np.asarray(actions, dtype=np.float64)
+        n, T = actions.shape[:2]
+        z = self._z if self._z is not None else self.draw_latents(T)
+        tiled = np.repeat(actions, self.n_latent, axis=0)                                   # [n*nl, T, adim]
+        zz = np.tile(z, (n, 1, 1))
         ctx_actions = np.asarray(context['context_actions'], dtype=np.float64).reshape(-1, self.adim)
         ctx = dict(context, context_actions=np.concatenate(
             [ctx_actions, np.zeros((ctx_actions.shape[0], self.zdim))], axis=1))
         return ctx, np.concatenate([tiled, zz], axis=2)
 
-    def score(self, context, inputs, goal_pix, finalweight=10., only_take_first_view=False):
-        import torch
-        actions = np.asarray(inputs['actions'], dtype=np.float64)
-        M, T = actions.shape[:2]
-        z = self.draw_latents(T)
+    def score(self, context, inputs, goal_pix, finalweight=10., only_take_first_view=False, task_weights=None):
+        T = np.asarray(inputs['actions']).shape[1]
+        self._z = self.draw_latents(T)          # one set of draws per scoring call, shared by every rank
         self._calls += 1
-        rank, world = dist_info()
-        lo, hi = shard_bounds(M, rank, world)            # shard ACTIONS; their draws stay together
-        ctx, aug = self._augment(context, actions[lo:hi], z)
-        # the engine must not shard again: temporarily score the local block as a whole
-        scores, per_task = self.engine._score_local(ctx, aug, goal_pix, finalweight)
-        scores = scores.reshape(hi - lo, self.n_latent).mean(axis=1)
-        per_task = per_task.reshape(hi - lo, self.n_latent, -1).mean(axis=1)
-        if world > 1:
-            packed = torch.from_numpy(np.concatenate([scores[:, None], per_task], axis=1)).to(self.engine.device)
-            full = all_gather_rows(packed, M).cpu().numpy()
-            scores, per_task = full[:, 0].copy(), full[:, 1:].copy()
-        return scores, per_task
-
-    def fetch_pixel_distributions(self, sample_index):
-        """Distributions of the first latent draw of the given action."""
-        return self.engine.fetch_pixel_distributions_local(sample_index * self.n_latent)
-
-    def __call__(self, context, inputs):
-        actions = np.asarray(inputs['actions'], dtype=np.float64)
-        z = self.draw_latents(actions.shape[1])
-        ctx, aug = self._augment(context, actions, z)
-        out = self.engine(ctx, {'actions': aug})
-        n = self.n_latent       # report the first draw of every action, like a deterministic predictor would
-        return {k: v[::n] for k, v in out.items()}
+        try:
+            return super(StochasticHipPredictor, self).score(
+                context, inputs, goal_pix, finalweight=finalweight, only_take_first_view=only_take_first_view,
+                task_weights=task_weights)
+        finally:
+            self._z = None
