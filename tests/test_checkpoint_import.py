@@ -1,0 +1,51 @@
+"""Checkpoint import (reference ``checkpoint_matcher.py:4-39``, ``setup_predictor.py:130-145``): suffix
+matching, layout conversion and round trip on named arrays."""
+import os
+
+import numpy as np
+import pytest
+
+from visual_foresight_amd.video_prediction import checkpoint_import as ci
+from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights, tensor_shapes
+
+
+def test_every_tensor_has_a_distinct_tf_name():
+    cfg = CdnaConfig(height=32, width=32)
+    names = [ci.tf_name(n)[0] for n in tensor_shapes(cfg)]
+    assert len(set(names)) == len(names)
+    assert ci.tf_name('lstm3/w') == ('state3/Gates/weights', False)
+    assert ci.tf_name('ln9/g') == ('layer_norm9/gamma', False)
+    assert ci.tf_name('convt2/w') == ('convt2/weights', True) and ci.tf_name('convt2/b') == ('convt2/biases', False)
+    assert ci.tf_name('rgb/w')[0] == 'convt4/weights' and ci.tf_name('masks/b')[0] == 'convt7/biases'
+
+
+def test_suffix_matching_follows_the_reference_rule():
+    avail = ['generator/model/state1/Gates/weights', 'generator/model/state11/Gates/weights', 'model/conv2/biases']
+    assert ci.match_suffix('state1/Gates/weights', avail) == avail[0]          # whole parts, not substrings
+    assert ci.match_suffix('conv2/biases', avail) == avail[2]
+    with pytest.raises(ValueError, match='did not find variable'):
+        ci.match_suffix('conv3/biases', avail)
+
+
+def test_roundtrip_through_npz_and_model_dir(tmp_path):
+    cfg = CdnaConfig(height=32, width=32, adim=3, sdim=3)
+    w = CdnaWeights.random(cfg, seed=7, bias_scale=0.1, ln_jitter=0.1)
+    named = ci.export_named_arrays(w, scope='generator/model')
+    # transposed convs are stored [kh, kw, cout, cin] on the TensorFlow side
+    assert named['generator/model/convt2/weights'].shape == (3, 3, 64, 96)
+    assert named['generator/model/conv2/weights'].shape == (3, 3, 32, 32)
+    # optimiser slots and unrelated variables in the checkpoint are ignored
+    named['generator/model/state1/Gates/weights/Adam'] = np.zeros(1)
+    named['global_step'] = np.zeros(())
+    npz = os.path.join(str(tmp_path), 'ckpt.npz')
+    np.savez(npz, **named)
+    back = ci.convert_npz(npz, os.path.join(str(tmp_path), 'model'), cfg)
+    loaded = CdnaWeights.load(os.path.join(str(tmp_path), 'model'), cfg)
+    for k in w.tensors:
+        np.testing.assert_array_equal(back.tensors[k], w.tensors[k])
+        np.testing.assert_array_equal(loaded.tensors[k], w.tensors[k])
+    # a wrong shape is refused with the offending names
+    bad = dict(named)
+    bad['generator/model/convt1/weights'] = bad['generator/model/convt1/weights'][:, :, :-1]
+    with pytest.raises(ValueError, match='convt1/w'):
+        ci.import_named_arrays(bad, cfg)

@@ -80,7 +80,7 @@ def test_config3_two_view_registration_planning_call(trade_off):
         ctrl.reset()
         weights = ctrl.predictor.weights
         rec = _Recorder(ctrl.predictor)
-        np.random.seed(0)
+        np.random.seed(3)       # a candidate set whose K / K+1 score gap is not razor thin (asserted below)
         kw = dict(goal_image=goal_image, i_tr=0, desig_pix=[[32, 32], [30, 36]], goal_pix=[[16, 48], [20, 44]])
         ctrl.act(t=0, images=frames[:1], state=states[:1], **kw)
         out = ctrl.act(t=1, images=frames, state=states, **kw)

@@ -1,0 +1,23 @@
+"""ASan + UBSan CPU build of the engine's host side (weight packers, layer planner, rollout emitter,
+persistent-schedule builder), SURVEY.md section 5.  tools/sanitize/host_selftest.cc drives the product's
+own host code over several shapes / view counts / batch sizes and checks the schedule invariants; any
+sanitizer report aborts the run.  CPU only - there is no GPU sanitizer on this pool."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_side_is_clean_under_asan_ubsan():
+    if not (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')):
+        pytest.skip('hipcc not available')
+    proc = subprocess.run(['bash', os.path.join(REPO, 'tools', 'sanitize', 'build_and_run.sh')],
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-4000:]
+    assert 'HOST SELFTEST OK' in proc.stdout
+    assert 'runtime error' not in proc.stdout and 'AddressSanitizer' not in proc.stdout
+    # the 2-view 600-sample schedule (BASELINE configs[2]) was built and verified
+    assert 'ncam 2 prec 0  B=600  full' in proc.stdout

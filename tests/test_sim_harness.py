@@ -36,7 +36,29 @@ def test_sim_runs_and_writes_reference_layout(tmp_path):
     assert 'scores_itr2' in policy_out[1]['plan_stat']
     obs = pickle.load(open(os.path.join(traj, 'obs_dict.pkl'), 'rb'))
     assert obs['state'].shape == (6, 5) and 'images' not in obs
-    assert np.load(os.path.join(traj, 'images0', 'im_5.npy')).shape == (16, 16, 3)
+    # frames: images{c}/im_{t}.png as the reference writes them (simulator.py:82-86), lossless RGB
+    from visual_foresight_amd.utils.png import read_png
+    assert sorted(os.listdir(os.path.join(traj, 'images0'))) == sorted('im_%d.png' % t for t in range(6))
+    blob = open(os.path.join(traj, 'images0', 'im_5.png'), 'rb').read()
+    assert blob[:8] == b'\x89PNG\r\n\x1a\n' and blob[12:16] == b'IHDR' and blob[-8:-4] == b'IEND'
+    frame = read_png(os.path.join(traj, 'images0', 'im_5.png'))
+    assert frame.shape == (16, 16, 3) and frame.dtype == np.uint8
+
+
+def test_png_roundtrip_and_header(tmp_path):
+    import struct
+    from visual_foresight_amd.utils.png import read_png, write_png
+    rs = np.random.RandomState(0)
+    for shape in ((48, 64, 3), (1, 1, 3), (7, 5, 3)):
+        img = rs.randint(0, 256, shape).astype(np.uint8)
+        path = os.path.join(str(tmp_path), 'x.png')
+        write_png(path, img)
+        np.testing.assert_array_equal(read_png(path), img)
+        blob = open(path, 'rb').read()
+        w, h, depth, ctype = struct.unpack('>IIBB', blob[16:26])
+        assert (w, h, depth, ctype) == (shape[1], shape[0], 8, 2)          # 8-bit truecolour
+    with pytest.raises(ValueError):
+        write_png(path, np.zeros((4, 4), np.uint8))
 
 
 @pytest.mark.gpu

@@ -1,0 +1,75 @@
+// host_selftest.cc - driver of the ASan/UBSan CPU build of the engine's host-side code
+// ("build the C-ABI lib with an ASan/UBSan CPU variant").
+//
+// vf_engine.hip is compiled for the HOST ONLY with -DVF_HOST_SELFTEST: device allocations become
+// address reservations, uploads become checksums.  What runs under the sanitizers is exactly the
+// product's host code: the tensor table, the layer planner, the weight packers (fp32 and
+// split-bf16), the rollout emitter and the persistent-schedule builder - for several shapes,
+// view counts, batch sizes and both schedule variants - and vf_selftest_schedule() checks the
+// invariants the device relies on (contiguous tickets, dependencies on earlier phases only,
+// counters in range, every pointer of every phase inside a buffer of the handle).
+// Never built for or run on a GPU (GPU sanitizers are not available on this pool).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/vf_hip.h"
+
+extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared, int64_t *out_items,
+                                    uint64_t *out_upload_checksum);
+
+static int run_case(int H, int W, int adim, int sdim, int nd, int nctx, int T, int max_batch, int precision, int ncam,
+                    int n_draws, const int *batches, int n_batches) {
+    vf_config cfg = {H, W, adim, sdim, nd, nctx, nctx + T, 10, max_batch, 0, precision, ncam, n_draws};
+    const size_t n = vf_weight_count(&cfg);
+    if (n == 0) { std::fprintf(stderr, "weight count failed: %s\n", vf_last_error()); return 1; }
+    std::vector<float> blob(n * (size_t)ncam);
+    uint32_t s = 12345u + (uint32_t)(H * 7 + W * 3 + adim + ncam);
+    for (float &x : blob) { s = s * 1664525u + 1013904223u; x = ((float)(s >> 8) / 16777216.0f - 0.5f) * 0.2f; }
+    vf_handle *h = nullptr;
+    if (vf_create(&cfg, &h)) { std::fprintf(stderr, "vf_create failed: %s\n", vf_last_error()); return 1; }
+    if (vf_load_weights(h, blob.data(), blob.size()) != 0 ||
+        vf_load_weights(h, blob.data(), blob.size()) != 0) {            // a reload reuses the same buffers
+        std::fprintf(stderr, "vf_load_weights failed: %s\n", vf_last_error());
+        return 1;
+    }
+    if (vf_load_weights(h, blob.data(), blob.size() - 1) == 0) { std::fprintf(stderr, "short blob accepted\n"); return 1; }
+    uint64_t sum = 0;
+    for (int i = 0; i < n_batches; ++i)
+        for (int skip = 0; skip < 2; ++skip) {
+            int64_t items = 0;
+            if (vf_selftest_schedule(h, batches[i], skip, &items, &sum)) {
+                std::fprintf(stderr, "schedule B=%d skip=%d: %s\n", batches[i], skip, vf_last_error());
+                return 1;
+            }
+            std::printf("  %dx%d adim %d nd %d ncam %d prec %d  B=%-4d %s: %lld items\n", H, W, adim, nd, ncam,
+                        precision, batches[i], skip ? "cached-context" : "full", (long long)items);
+        }
+    std::printf("  packed-weight checksum %016llx\n", (unsigned long long)sum);
+    vf_destroy(h);
+    return 0;
+}
+
+int main() {
+    const int b_small[] = {1, 7, 16, 37};
+    const int b_c2[] = {200, 125, 25};
+    const int b_c3[] = {600, 88};
+    const int b_c5[] = {50, 5};
+    int rc = 0;
+    rc |= run_case(32, 32, 4, 5, 1, 2, 3, 37, 0, 1, 1, b_small, 4);
+    rc |= run_case(48, 64, 3, 3, 2, 2, 2, 37, 1, 1, 1, b_small, 4);
+    rc |= run_case(64, 64, 4, 5, 1, 1, 2, 16, 0, 1, 1, b_small, 3);
+    rc |= run_case(64, 64, 4, 5, 1, 2, 13, 200, 0, 1, 1, b_c2, 3);
+    rc |= run_case(64, 64, 4, 5, 2, 2, 13, 600, 0, 2, 1, b_c3, 2);
+    rc |= run_case(128, 128, 12, 5, 1, 2, 15, 50, 1, 1, 5, b_c5, 2);
+    rc |= run_case(40, 56, 5, 5, 4, 2, 2, 16, 0, 3, 1, b_small, 3);
+    // invalid configurations are refused, not crashed on
+    vf_config bad = {60, 64, 4, 5, 1, 2, 15, 10, 8, 0, 0, 1, 1};
+    vf_handle *h = nullptr;
+    if (vf_create(&bad, &h) == 0) { std::fprintf(stderr, "invalid config accepted\n"); rc = 1; }
+    vf_config bad2 = {64, 64, 4, 5, 1, 2, 15, 10, 8, 0, 0, 5, 1};
+    if (vf_create(&bad2, &h) == 0) { std::fprintf(stderr, "ncam 5 accepted\n"); rc = 1; }
+    std::printf(rc ? "HOST SELFTEST FAILED\n" : "HOST SELFTEST OK\n");
+    return rc;
+}

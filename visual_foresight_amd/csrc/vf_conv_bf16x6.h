@@ -212,7 +212,7 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx,
 // which spills once the tile is an out-of-line body of the persistent kernel.  219.9 x 6 = 1.32 PF/s of
 // bf16 MFMA is where tuned bf16 GEMMs on random data land on this chip (power-limited clocks).
 template <int MREP>
-__global__ __launch_bounds__(kConvThreads, 2) void conv_lstm_bf16x6_kernel(const ConvParams p) {
+VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_lstm_bf16x6_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     conv_lstm_bf16x6_tile<MREP>(p, blockIdx.x, blockIdx.y, smem);
 }

@@ -23,6 +23,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// -DVF_HOST_SELFTEST (tools/sanitize/): the file is compiled for the host only and no kernel may be
+// emitted (a translation unit with kernels references the device binary); kernels then degrade to
+// plain device functions, which the host pass parses but never generates.
+#ifdef VF_HOST_SELFTEST
+#define VF_GLOBAL __device__
+#define VF_LAUNCH_BOUNDS(...)
+#else
+#define VF_GLOBAL __global__
+#define VF_LAUNCH_BOUNDS(...) __launch_bounds__(__VA_ARGS__)
+#endif
+
 namespace vf {
 
 #ifdef VF_TILE_STATS
@@ -464,7 +475,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 }
 
 template <int G, int EPI, int MREP>
-__global__ __launch_bounds__(kConvThreads, 2) void conv_mfma_kernel(const ConvParams p) {
+VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_mfma_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     conv_tile<G, EPI, MREP>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }

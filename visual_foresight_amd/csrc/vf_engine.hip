@@ -503,6 +503,7 @@ static int allow_lds(K kernel, size_t bytes) {
     return VF_OK;
 }
 
+#ifndef VF_HOST_SELFTEST
 static int configure_kernels(vf_handle *h) {
     const size_t n = h->max_lds;
     int rc;
@@ -556,6 +557,8 @@ static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st
         return launch_conv_m<G, EPI, 1>(l, p, st);
     }
 }
+
+#endif  // VF_HOST_SELFTEST
 
 struct SegArg {
     const float *ptr; long long bstride; const double *ln_part; long long ln_bstride; int ln_nparts; float ln_inv_n;

@@ -144,7 +144,7 @@ __device__ __noinline__ void small_item_call(const PhaseDesc *P, int type, int b
 // WPS = waves per SIMD the kernel is compiled for (= resident workgroups per CU).  WPS 3 leaves
 // 168 VGPRs per lane, which fits every tile body except the 256-row conv-LSTM tile (MREP 2).
 template <int ND, int WPS>
-__global__ __launch_bounds__(kConvThreads, WPS) void rollout_persistent_kernel(
+VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
     const PhaseDesc *__restrict__ phases, const Schedule sched) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     // all LDS in one dynamic array: the control block first, the tile workspace after it

@@ -23,7 +23,7 @@ constexpr float kReluShift = 1e-12f;
 // ------------------------------------------------------------------------------------------
 // frames_u8 [nc][ncam][HW3] -> frames_f [ncam][nc][HW3] / 255; distrib [nc][ncam][HWD] -> [ncam][nc][HWD];
 // states and context actions are shared by the views and copied as they are
-__global__ void set_context_kernel(const uint8_t *frames_u8, float *frames_f, int nc, int ncam, int hw3,
+VF_GLOBAL void set_context_kernel(const uint8_t *frames_u8, float *frames_f, int nc, int ncam, int hw3,
                                    const float *src_d, float *dst_d, int hwd,
                                    const float *src_s, float *dst_s, int n_s,
                                    const float *src_a, float *dst_a, int n_a) {
@@ -72,7 +72,7 @@ __device__ __forceinline__ void sa_sample(const PT &p, const int b, const int t,
     }
 }
 
-__global__ void sa_kernel(const SaParams p) {
+VF_GLOBAL void sa_kernel(const SaParams p) {
     __shared__ float sa[32];
     sa_sample(p, blockIdx.x, threadIdx.x, sa);
 }
@@ -105,7 +105,7 @@ __device__ __forceinline__ void cdna_finalize_sample(const PT &p, const int b, f
     if (t < n) p.kern[(long long)b * n + t] = v[t] / norm[t % p.K];
 }
 
-__global__ void cdna_finalize_kernel(const FinParams p) {
+VF_GLOBAL void cdna_finalize_kernel(const FinParams p) {
     __shared__ float scratch[kTaps * 16 + 16];
     cdna_finalize_sample(p, blockIdx.x, scratch);
 }
@@ -287,7 +287,7 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
 }
 
 template <int ND, int K>
-__global__ __launch_bounds__(256) void composite_kernel(const CompositeParams p) {
+VF_GLOBAL VF_LAUNCH_BOUNDS(256) void composite_kernel(const CompositeParams p) {
     __shared__ __attribute__((aligned(16))) float smem[composite_lds_floats<ND, K>()];
     composite_tile<ND, K>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
 }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompositeParams p)
 constexpr int kMaxCam = 4;
 struct TaskWeights { int use; float w[kMaxCam * kMaxDesig]; };
 
-__global__ void scores_kernel(const double *sums, long long step_stride, long long view_stride, int n_actions,
+VF_GLOBAL void scores_kernel(const double *sums, long long step_stride, long long view_stride, int n_actions,
                               int n_draws, int T, int ND, int ncam, int ntiles, float finalweight,
                               const TaskWeights tw, const int *status, float *scores, float *scores_per_task) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -340,7 +340,7 @@ __global__ void scores_kernel(const double *sums, long long step_stride, long lo
 
 // predictions out in the reference layout: dst[bb][t][view][hw][C] <- src[view][Bcap][t][hw][C]
 // (reference vpred_model_interface.py:78,88 stacks the views on axis 2)
-__global__ void export_frames_kernel(const float *src, long long view_stride, int first, int count, int T,
+VF_GLOBAL void export_frames_kernel(const float *src, long long view_stride, int first, int count, int T,
                                      int ncam, int HWC, float *dst) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per_sample = (long long)T * ncam * HWC;
@@ -354,7 +354,7 @@ __global__ void export_frames_kernel(const float *src, long long view_stride, in
 }
 
 // normalised distributions out: dst[bb][t][view][hw][d] = src[view][b][t][hw][d] / S0(t, view, b, d)
-__global__ void export_distrib_kernel(const float *src, long long view_stride, const double *sums,
+VF_GLOBAL void export_distrib_kernel(const float *src, long long view_stride, const double *sums,
                                       long long step_stride, long long sums_view_stride, int first, int count,
                                       int T, int ncam, int HW, int ND, int ntiles, float *dst) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -391,7 +391,7 @@ __device__ __forceinline__ float bilinear_clamped(const float *img, int H, int W
 }
 
 // warped[cam][r][c][:] = bilinear(current[cam], warp_pts[cam][r][c]);  pts[cam][r][c] = (x, y)
-__global__ void warp_image_kernel(const float *cur, const float *flow, int ncam, int H, int W, float *warped,
+VF_GLOBAL void warp_image_kernel(const float *cur, const float *flow, int ncam, int H, int W, float *warped,
                                   float *pts) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ncam * H * W) return;
@@ -409,7 +409,7 @@ __global__ void warp_image_kernel(const float *cur, const float *flow, int ncam,
 // clipped to [0, size - clip_sub] (:139-161; the reference clips the start window with
 // clip_sub = 1 and the goal window with 0).  desig = (row, col) float; an empty window gives NaN.
 constexpr int kRegMaxWin = 11 * 11;
-__global__ __launch_bounds__(128) void register_kernel(const float *cur, const float *ref, const float *flow,
+VF_GLOBAL VF_LAUNCH_BOUNDS(128) void register_kernel(const float *cur, const float *ref, const float *flow,
                                                        const int *pix, int ncam, int ntask, int H, int W,
                                                        int region, int clip_sub, float *desig, float *err) {
     __shared__ float s_x[kRegMaxWin], s_y[kRegMaxWin];

@@ -10,7 +10,7 @@ config dict shaped like the reference's ``experiments/**/hparams.py`` (``{'agent
 * every step calls ``policy.act(**get_policy_args(policy, obs, t, i_tr, agent_data))`` with the growing
   history ``obs = {'images': [t+1, ncam, H, W, 3], 'state': [t+1, sdim]}`` (``general_agent.py:196-206``);
 * ``save_raw_images`` writes ``traj_group{g}/traj{i}/{agent_data,obs_dict,policy_out}.pkl`` plus the
-  frames (``simulator.py:64-93``; frames as ``.npy`` - there is no image codec in this stack).
+  frames as ``images{c}/im_{t}.png`` (``simulator.py:64-93``; 8-bit RGB PNGs from ``utils/png.py``).
 """
 import os
 import pickle as pkl
@@ -19,6 +19,7 @@ import shutil
 import numpy as np
 
 from visual_foresight_amd.policy.policy import get_policy_args
+from visual_foresight_amd.utils.png import write_png
 from .synthetic_env import SyntheticPushEnv
 
 
@@ -98,7 +99,7 @@ class Sim(object):
         for c in range(images.shape[1]):
             os.mkdir(os.path.join(traj, 'images%d' % c))
             for t in range(images.shape[0]):
-                np.save(os.path.join(traj, 'images%d' % c, 'im_%d.npy' % t), images[t, c])
+                write_png(os.path.join(traj, 'images%d' % c, 'im_%d.png' % t), images[t, c])
         for name, obj in (('agent_data', agent_data), ('obs_dict', obs_dict), ('policy_out', policy_outputs)):
             with open(os.path.join(traj, name + '.pkl'), 'wb') as f:
                 pkl.dump(obj, f)
