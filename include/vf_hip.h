@@ -24,8 +24,10 @@
  *   predicted frames        [B][T][ncam][H][W][3]           in [0,1]
  *   predicted distrib       [B][T][ncam][H][W][ndesig]      each (b,t,c,.,.,p) plane sums to 1
  *   predicted states        [B][T][sdim]
- *   scores                  [B / n_draws], scores_per_task [B / n_draws][ncam * ndesig]
- *                           (camera-major, as pixel_cost_controller.py:138-149 stacks them)
+ *   scores        float64   [B / n_draws], scores_per_task [B / n_draws][ncam * ndesig]
+ *                           (camera-major, as pixel_cost_controller.py:138-149 stacks them; float64
+ *                           like the reference's host cost under NumPy >= 2, so device rounding
+ *                           cannot create ties in front of the elite argsort)
  */
 #ifndef VF_HIP_H
 #define VF_HIP_H
@@ -122,8 +124,8 @@ int vf_set_context(vf_handle *h, const uint8_t *d_frames, const float *d_states,
  * waiting for its producers (see vf_device_status) every score of this and of later rollouts
  * is NaN until the status has been read. */
 int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *goal_pix,
-               float finalweight, const float *task_weights, float *d_scores,
-               float *d_scores_per_task, void *stream);
+               float finalweight, const float *task_weights, double *d_scores,
+               double *d_scores_per_task, void *stream);
 
 /* Copy the predictions of the last vf_rollout out in the reference's layout (camera axis,
  * normalised distributions).  Any destination may be NULL.  first/count select a range of rolled
@@ -154,14 +156,14 @@ int vf_register(vf_handle *h, const float *d_current, const float *d_reference, 
                 const int32_t *d_pix, int32_t ntask, int32_t region, int32_t clip_sub,
                 float *d_warped, float *d_warp_pts, float *d_desig, float *d_err, void *stream);
 
-/* The one collective of multi-GPU planning: all-gather every rank's n_local score floats
+/* The one collective of multi-GPU planning: all-gather every rank's n_local score values (float64)
  * (n_local equal on all ranks: pad ragged shards) into d_all [world * n_local] with RCCL over
  * xGMI, on the caller's stream.  nccl_comm is the caller's ncclComm_t (one rank per GPU).  The
  * reference instead concatenates whole predicted videos of its towers on the host,
  * visual_mpc/video_prediction/setup_predictor.py:155-162.  RCCL is bound with dlopen at first use,
  * so the library has no link-time dependency on it. */
-int vf_allgather_scores(vf_handle *h, void *nccl_comm, const float *d_local, int32_t n_local,
-                        float *d_all, void *stream);
+int vf_allgather_scores(vf_handle *h, void *nccl_comm, const double *d_local, int32_t n_local,
+                        double *d_all, void *stream);
 
 /* Sub-batch concurrency (no reference counterpart).  Samples never interact before their
  * scores are compared, so vf_rollout may cut the batch into n contiguous sub-batches that

@@ -47,8 +47,8 @@ def test_device_failure_is_reported_in_band():
     _lib.check(pred._libh.vf_debug_poison_status(pred._handle))
     with torch.cuda.device(pred.device):
         a = torch.from_numpy(actions.astype(np.float32)).to(pred.device)
-        sc = torch.zeros(len(actions), device=pred.device)
-        pt = torch.zeros((len(actions), 1), device=pred.device)
+        sc = torch.zeros(len(actions), dtype=torch.float64, device=pred.device)
+        pt = torch.zeros((len(actions), 1), dtype=torch.float64, device=pred.device)
         for _ in range(2):
             pred._rollout_chunk(a, [[[3, 20]]], 10., sc, pt)
             assert torch.isnan(sc).all() and torch.isnan(pt).all()
@@ -106,8 +106,8 @@ def test_allgather_scores_entry_point():
     rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, NcclUniqueId, ctypes.c_int]
     with torch.cuda.device(pred.device):
         assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
-        local = torch.arange(14, dtype=torch.float32, device=pred.device) * 0.5
-        out = torch.zeros(14, dtype=torch.float32, device=pred.device)
+        local = torch.arange(14, dtype=torch.float64, device=pred.device) * 0.5 + 1e-12
+        out = torch.zeros(14, dtype=torch.float64, device=pred.device)
         _lib.check(pred._libh.vf_allgather_scores(pred._handle, comm, local.data_ptr(), 14, out.data_ptr(),
                                                   pred._stream()))
         torch.cuda.synchronize()

@@ -175,7 +175,7 @@ def test_errors_are_loud():
     h = ctypes.c_void_p()
     _lib.check(lib.vf_create(ctypes.byref(cfg), ctypes.byref(h)))
     acts = torch.zeros((2, 3, 4), device='cuda')
-    sc = torch.zeros(2, device='cuda')
+    sc = torch.zeros(2, dtype=torch.float64, device='cuda')
     goal = (ctypes.c_int32 * 2)(0, 0)
     assert lib.vf_rollout(h, acts.data_ptr(), 2, goal, ctypes.c_float(1.), None, sc.data_ptr(), None, None) == -4
     assert b'vf_load_weights' in lib.vf_last_error()

@@ -98,3 +98,34 @@ def test_stochastic_predictor_host_logic():
         for d in range(3):
             np.testing.assert_array_equal(aug[m * 3 + d, :, :4], actions[m])
             np.testing.assert_array_equal(aug[m * 3 + d, :, 4:], z[d])
+
+
+def test_trajectory_layout_matches_reference_golden(tmp_path, golden_dir):
+    """tests/golden/traj_layout.*: what the reference's own ``Sim._save_raw_data`` (``simulator.py:64-93``) wrote
+    for a synthetic trajectory (tools/make_golden.py, cv2.imwrite recorded): same tree, same file names, same
+    pickles, and every PNG decodes to the frame the reference handed to OpenCV (BGR there, RGB in the file)."""
+    import json
+    import types
+    from visual_foresight_amd.utils.png import read_png
+    meta = json.load(open(os.path.join(golden_dir, 'traj_layout.json')))
+    gold = np.load(os.path.join(golden_dir, 'traj_layout.npz'))
+    obs = {'images': gold['images'], 'state': gold['state']}
+    fake = types.SimpleNamespace(agentparams={'data_save_dir': str(tmp_path)}, _hyperparams={'ngroup': meta['ngroup']},
+                                 task_mode='train')
+    policy_out = [{'actions': np.zeros(4)} for _ in range(meta['n_policy_out'])]
+    Sim._save_raw_data(fake, meta['itr'], dict(meta['agent_data']), obs, policy_out)
+    root = str(tmp_path)
+    files = sorted(os.path.relpath(os.path.join(d, f), root) for d, _, fs in os.walk(root) for f in fs)
+    dirs = sorted(os.path.relpath(os.path.join(d, x), root) for d, xs, _ in os.walk(root) for x in xs)
+    assert dirs == meta['dirs']
+    assert files == sorted(meta['files_on_disk'] + meta['imwrite_paths'])
+    traj = os.path.join(root, 'train', 'traj_group2', 'traj23')
+    for rel in meta['imwrite_paths']:
+        name = os.path.relpath(rel, os.path.join('train', 'traj_group2', 'traj23'))
+        bgr = gold['imwrite/' + name]
+        np.testing.assert_array_equal(read_png(os.path.join(root, rel)), bgr[:, :, ::-1])
+    back = pickle.load(open(os.path.join(traj, 'obs_dict.pkl'), 'rb'))
+    assert sorted(back.keys()) == meta['obs_dict_keys']
+    np.testing.assert_array_equal(back['state'], gold['state'])
+    assert pickle.load(open(os.path.join(traj, 'agent_data.pkl'), 'rb')) == meta['agent_data']
+    assert len(pickle.load(open(os.path.join(traj, 'policy_out.pkl'), 'rb'))) == meta['n_policy_out']

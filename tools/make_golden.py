@@ -418,6 +418,45 @@ def golden_pred_util(ref):
     return arrays, meta
 
 
+# ----------------------------------------------------------------------------- f4: trajectory layout
+def golden_traj_layout():
+    """Drive the reference's own ``Sim._save_raw_data`` (``visual_mpc/sim/simulator.py:64-93``) on a synthetic
+    trajectory, with ``cv2.imwrite`` replaced by a recorder: the directory tree it creates, the image file
+    names, the pixel array each ``imwrite`` call receives (BGR = the RGB frame with channels reversed) and the
+    pickles' contents pin the on-disk layout this repo's rollout harness must reproduce."""
+    import pickle
+    import tempfile
+    import cv2
+    from visual_mpc.sim.simulator import Sim
+    written = {}
+    cv2.imwrite = lambda path, arr: written.__setitem__(path, np.array(arr))
+    rs = np.random.RandomState(12)
+    T, ncam, H, W = 4, 2, 6, 8
+    images = rs.randint(0, 256, (T, ncam, H, W, 3)).astype(np.uint8)
+    obs = {'images': images.copy(), 'state': rs.normal(0, 1, (T, 5))}
+    agent_data = {'traj_ok': True, 'final_goal_distance': 3.5}
+    policy_out = [{'actions': rs.normal(0, 1, 4)} for _ in range(T - 1)]
+    with tempfile.TemporaryDirectory() as tmp:
+        fake = types.SimpleNamespace(agentparams={'data_save_dir': tmp}, _hyperparams={'ngroup': 10},
+                                     task_mode='train')
+        with quiet():
+            Sim._save_raw_data(fake, 23, agent_data, obs, policy_out)
+        tree = sorted(os.path.relpath(os.path.join(d, f), tmp) for d, _, fs in os.walk(tmp) for f in fs)
+        dirs = sorted(os.path.relpath(os.path.join(d, x), tmp) for d, xs, _ in os.walk(tmp) for x in xs)
+        traj = os.path.join(tmp, 'train', 'traj_group2', 'traj23')
+        obs_back = pickle.load(open(os.path.join(traj, 'obs_dict.pkl'), 'rb'))
+        meta = {'files_on_disk': tree, 'dirs': dirs,
+                'imwrite_paths': sorted(os.path.relpath(p, tmp) for p in written),
+                'obs_dict_keys': sorted(obs_back.keys()),
+                'agent_data': pickle.load(open(os.path.join(traj, 'agent_data.pkl'), 'rb')),
+                'n_policy_out': len(pickle.load(open(os.path.join(traj, 'policy_out.pkl'), 'rb'))),
+                'itr': 23, 'ngroup': 10, 'numpy': np.__version__}
+        arrays = {'images': images, 'state': obs_back['state']}
+        for p, arr in written.items():
+            arrays['imwrite/' + os.path.relpath(p, traj)] = arr
+    return arrays, meta
+
+
 def main():
     install_stubs()
     from visual_mpc.policy.cem_controllers import PixelCostController, CEMBaseController
@@ -436,6 +475,7 @@ def main():
     dump('cost', *golden_cost(ref))
     dump('act', *golden_act(ref))
     dump('pred_util', *golden_pred_util(ref))
+    dump('traj_layout', *golden_traj_layout())
     print('wrote fixtures to', OUT, 'with numpy', np.__version__)
     for fn in sorted(os.listdir(OUT)):
         print('  %-20s %8d B' % (fn, os.path.getsize(os.path.join(OUT, fn))))

@@ -34,6 +34,12 @@
 #define VF_LAUNCH_BOUNDS(...) __launch_bounds__(__VA_ARGS__)
 #endif
 
+// VF_LSTM_B_DIRECT=1 (experiment): conv-LSTM tiles read the weight operand straight from L1/L2 instead of
+// staging it through LDS - frees 32 KiB of LDS per workgroup (3 resident workgroups per CU)
+#ifndef VF_LSTM_B_DIRECT
+#define VF_LSTM_B_DIRECT 0
+#endif
+
 namespace vf {
 
 #ifdef VF_TILE_STATS
@@ -239,7 +245,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     constexpr int WROWS = MREP * 32;    // GEMM rows per wave
     // B through LDS pays for the long-K conv-LSTM tiles; the transposed convs (4 taps, 2-4 chunks)
     // lose more to its per-tap barrier than they gain, so they read B straight from L1/L2
-    constexpr bool kBLds = (EPI == EPI_LSTM);
+    constexpr bool kBLds = (EPI == EPI_LSTM) && !VF_LSTM_B_DIRECT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     const int KC = p.KC, KCpad = KC + 4, K8 = KC >> 3;

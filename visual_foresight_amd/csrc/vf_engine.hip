@@ -158,7 +158,7 @@ static size_t conv_lds_bytes(const ConvLayer &l, int KC) {
     const int LH = (l.TH - 1) * l.stride + l.KH, LW = (l.TW - 1) * l.stride + l.KW;
     // A tile + LayerNorm table + reduction scratch (+ for 4-gate layers the double-buffered
     // per-tap B blocks: 2 x KC/8 x [4 gates][64 lanes] float4)
-    const size_t b_lds = l.mode == PACK_LSTM ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
+    const size_t b_lds = (l.mode == PACK_LSTM && !VF_LSTM_B_DIRECT) ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
     return ((size_t)l.NI * LH * LW * (KC + 4) + 4 * (size_t)l.NI) * 4 + 64 + b_lds;
 }
 
@@ -1516,7 +1516,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
 extern "C" {
 
 int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *goal_pix, float finalweight,
-               const float *task_weights, float *d_scores, float *d_scores_per_task, void *stream) {
+               const float *task_weights, double *d_scores, double *d_scores_per_task, void *stream) {
     if (!h || !d_actions || !goal_pix || !d_scores) return fail(VF_ERR_INVALID, "null argument");
     if (!h->have_weights) return fail(VF_ERR_NOWEIGHTS, "vf_load_weights has not been called");
     if (!h->have_context) return fail(VF_ERR_NOCONTEXT, "vf_set_context has not been called");
@@ -1715,7 +1715,7 @@ int vf_register(vf_handle *h, const float *d_current, const float *d_reference, 
 
 // RCCL is bound at first use (dlopen of the library the process already carries - PyTorch ships
 // its own librccl.so - or the system one), so libvf_hip.so itself has no link dependency on it.
-int vf_allgather_scores(vf_handle *h, void *nccl_comm, const float *d_local, int32_t n_local, float *d_all,
+int vf_allgather_scores(vf_handle *h, void *nccl_comm, const double *d_local, int32_t n_local, double *d_all,
                         void *stream) {
     if (!h || !nccl_comm || !d_local || !d_all || n_local < 1) return fail(VF_ERR_INVALID, "null or empty argument");
     if (!h->nccl_all_gather) {
@@ -1728,8 +1728,8 @@ int vf_allgather_scores(vf_handle *h, void *nccl_comm, const float *d_local, int
         if (!h->nccl_all_gather) return fail(VF_ERR_HIP, "ncclAllGather not found in the RCCL library");
     }
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
-    const int nccl_float32 = 7;     // ncclFloat32 in nccl.h
-    const int rc = h->nccl_all_gather(d_local, d_all, (size_t)n_local, nccl_float32, nccl_comm, stream);
+    const int nccl_float64 = 8;     // ncclFloat64 in nccl.h
+    const int rc = h->nccl_all_gather(d_local, d_all, (size_t)n_local, nccl_float64, nccl_comm, stream);
     if (rc != 0) return fail(VF_ERR_HIP, "ncclAllGather failed with ncclResult_t " + std::to_string(rc));
     return VF_OK;
 }

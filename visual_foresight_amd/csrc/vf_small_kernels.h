@@ -298,6 +298,8 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(256) void composite_kernel(const CompositeParams p) {
 // (reference pixel_cost_controller.py:168-187); n_draws consecutive sequences are the latent draws
 // of one action and are averaged; the action's score is the plain mean over tasks (reference :153)
 // or, with use_weights, the trade-off weighted sum (register_gtruth_controller.py:88-94).
+// Scores leave the device in float64 (the reference's host cost is float64 under NumPy >= 2,
+// SURVEY section 7): no fp32 rounding can merge two distinct costs into a tie before the argsort.
 // sums[t]: [ncam][Bcap][ND][ntiles][2].  A non-zero *status (a tile of the rollout gave up
 // waiting for its producers) poisons every score with NaN, so a failed rollout cannot feed CEM.
 constexpr int kMaxCam = 4;
@@ -305,7 +307,7 @@ struct TaskWeights { int use; float w[kMaxCam * kMaxDesig]; };
 
 VF_GLOBAL void scores_kernel(const double *sums, long long step_stride, long long view_stride, int n_actions,
                               int n_draws, int T, int ND, int ncam, int ntiles, float finalweight,
-                              const TaskWeights tw, const int *status, float *scores, float *scores_per_task) {
+                              const TaskWeights tw, const int *status, double *scores, double *scores_per_task) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_actions) return;
     const int ntask = ncam * ND;
@@ -331,11 +333,11 @@ VF_GLOBAL void scores_kernel(const double *sums, long long step_stride, long lon
             const double sc = over_draws / n_draws;
             const int col = v * ND + d;
             if (scores_per_task)
-                scores_per_task[(long long)a * ntask + col] = poisoned ? __builtin_nanf("") : (float)sc;
+                scores_per_task[(long long)a * ntask + col] = poisoned ? __builtin_nan("") : sc;
             total += tw.use ? (double)tw.w[col] * sc : sc;
         }
     const double out = tw.use ? total : total / ntask;
-    scores[a] = poisoned ? __builtin_nanf("") : (float)out;
+    scores[a] = poisoned ? __builtin_nan("") : out;
 }
 
 // predictions out in the reference layout: dst[bb][t][view][hw][C] <- src[view][Bcap][t][hw][C]

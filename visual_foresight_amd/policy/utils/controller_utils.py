@@ -10,30 +10,19 @@ import numpy as np
 _MAX_ROT = np.pi / 4
 
 
-def _axis_limits(hp, adim):
-    """Per action-dimension clip limit (or None): xy -> 2*initial_std, theta -> pi/4."""
-    xy_limit = hp.initial_std * 2
-    if hp.action_order is not None:
-        table = {'x': xy_limit, 'y': xy_limit, 'theta': _MAX_ROT}
-        return [table.get(a) for a in hp.action_order]
-    limits = [xy_limit, xy_limit] + [None] * max(adim - 2, 0)
-    if adim >= 4:
-        limits[3] = _MAX_ROT
-    return limits[:max(adim, 2)]
-
-
 def truncate_movement(actions, hp):
-    """Clip translation (and rotation, when present) of sampled actions in place."""
+    """Clip translation (and rotation, when present) of sampled actions in place: xy to 2*initial_std, theta to
+    pi/4.  Without ``action_order`` the first two dims are xy and dim 3 (if it exists) the rotation."""
     if actions.ndim not in (2, 3):
         raise NotImplementedError
     adim = actions.shape[-1]
+    xy_limit = hp.initial_std * 2
     if hp.action_order is None:
-        # the default layout always clips the first two dims, and dim 3 if it exists
-        actions[..., :2] = np.clip(actions[..., :2], -hp.initial_std * 2, hp.initial_std * 2)
-        if adim >= 4:
-            actions[..., 3] = np.clip(actions[..., 3], -_MAX_ROT, _MAX_ROT)
-        return actions
-    for i, lim in enumerate(_axis_limits(hp, adim)):
+        limits = [xy_limit, xy_limit, None, _MAX_ROT][:adim]
+    else:
+        table = {'x': xy_limit, 'y': xy_limit, 'theta': _MAX_ROT}
+        limits = [table.get(a) for a in hp.action_order]
+    for i, lim in enumerate(limits):
         if lim is not None:
             actions[..., i] = np.clip(actions[..., i], -lim, lim)
     return actions

@@ -236,8 +236,8 @@ class HipVPredEvaluation(object):
         context, seqs = self._prepare(context, actions)
         self._set_context(context)
         local = torch.from_numpy(np.ascontiguousarray(seqs, dtype=np.float32)).to(self.device)
-        scores = torch.empty(n, dtype=torch.float32, device=self.device)
-        per_task = torch.empty((n, ntask), dtype=torch.float32, device=self.device)
+        scores = torch.empty(n, dtype=torch.float64, device=self.device)
+        per_task = torch.empty((n, ntask), dtype=torch.float64, device=self.device)
         bs = self.run_batch_size // nd          # actions per chunk
         for c0 in range(0, n, bs):
             c1 = min(c0 + bs, n)
@@ -263,8 +263,8 @@ class HipVPredEvaluation(object):
                                                   task_weights=task_weights)
             if world > 1:
                 scores, per_task = self._all_gather(scores, per_task, M, world)
-            scores_np = scores.cpu().numpy().astype(np.float64)
-            per_task_np = per_task.cpu().numpy().astype(np.float64)
+            scores_np = scores.cpu().numpy()
+            per_task_np = per_task.cpu().numpy()
         self._check_scores(scores_np)
         if only_take_first_view:
             per_task_np = per_task_np[:, :1]
@@ -399,8 +399,8 @@ class HipVPredEvaluation(object):
             context, seqs = self._prepare(context, actions)
             self._set_context(context)
             acts = torch.from_numpy(np.ascontiguousarray(seqs, dtype=np.float32)).to(self.device)
-            scores = torch.empty(bs, dtype=torch.float32, device=self.device)
-            per_task = torch.empty((bs, ncam * c.ndesig), dtype=torch.float32, device=self.device)
+            scores = torch.empty(bs, dtype=torch.float64, device=self.device)
+            per_task = torch.empty((bs, ncam * c.ndesig), dtype=torch.float64, device=self.device)
             for c0 in range(0, M, bs):
                 c1 = min(c0 + bs, M)
                 n = c1 - c0
