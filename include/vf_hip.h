@@ -182,6 +182,13 @@ int vf_set_substreams(vf_handle *h, int32_t n);
 int vf_set_persistent(vf_handle *h, int32_t enable);
 int vf_device_status(vf_handle *h, int32_t *status);
 
+/* conv-LSTM tile selection (no reference counterpart): 0 (default) = single input buffer, weights
+ * staged through LDS, one barrier per tap; 2 = double-buffered LDS-DMA input staging
+ * (global_load_lds_dwordx4) with the weight operand read straight from L2 and one barrier per
+ * 32-channel chunk.  Same arithmetic in the same order: results are bit-identical; measured equally
+ * fast, so the switch exists for A/B measurements. */
+int vf_set_lstm_tile(vf_handle *h, int32_t variant);
+
 /* Context de-duplication (default on).  While a step's inputs are context, part of the network
  * sees identical inputs for every sample (step < n_context-1: everything; step < n_context: the
  * encoder up to enc2); those launches then run once with batch 1 and are broadcast.  The

@@ -189,8 +189,8 @@ def test_errors_are_loud():
 
 
 def test_launch_strategies_are_bit_identical():
-    """Context de-duplication, sub-batch streams and the persistent single-launch rollout only
-    reorganise the same per-sample arithmetic: same bits out."""
+    """Context de-duplication, sub-batch streams, the persistent single-launch rollout and the two conv-LSTM
+    tile generations only reorganise the same per-sample arithmetic: same bits out."""
     H = W = 32
     T, M = 3, 37
     pred, _ = _predictor(H, W, T, 2, bs=M)
@@ -199,10 +199,12 @@ def test_launch_strategies_are_bit_identical():
     actions = rs.normal(0, 0.1, (M, T, 4))
     goal = np.array([[[3, 20], [30, 1]]])
     outs = []
-    for dedup, nsub, persistent in ((1, 1, 0), (0, 1, 0), (1, 2, 0), (0, 3, 0), (1, 1, 1), (0, 1, 1)):
+    for dedup, nsub, persistent, tile in ((1, 1, 0, 2), (0, 1, 0, 0), (1, 2, 0, 2), (0, 3, 0, 2), (1, 1, 1, 2),
+                                          (0, 1, 1, 2), (1, 1, 1, 0), (1, 1, 0, 0)):
         pred.set_dedup(dedup)
         pred.set_substreams(nsub)
         pred.set_persistent(persistent)
+        pred.set_lstm_tile(tile)        # 2: LDS-DMA double-buffered conv-LSTM tile, 0: first-generation tile
         s, pt = pred.score(ctx, {'actions': actions}, goal)
         assert pred.device_status() == 0
         got = pred(ctx, {'actions': actions})

@@ -138,6 +138,7 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
     int KC, nchunk[2];
     int mrep;                       // MFMA row blocks per wave: the workgroup covers 128 * mrep rows
     int prec = 0;                   // 1: split-bf16 tile (conv-LSTM only)
+    size_t lds_dma = 0;             // conv-LSTM, fp32: LDS bytes of the DMA tile (0: tile not applicable)
     int NI, TH, TW, RPI, tilesY, tilesX;
     int ncg, Cout;
     int nsplit, chunks_per_split, n_valid;
@@ -195,6 +196,13 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
         l.lds_bytes = bf16x6_lds_bytes(l.NI, LH, LW);
     }
     l.stats_nparts = (l.NI == 1 ? l.tilesY * l.tilesX : 1) * l.ncg;
+    // second-generation conv-LSTM tile (vf_conv_mfma.h, conv_lstm_dma_tile): same packing, needs 32-channel chunks
+    l.lds_dma = 0;
+    if (l.mode == PACK_LSTM && l.prec == 0 && KC == 32 && l.mrep == 1 && l.stride == 1) {
+        const int LH = l.TH - 1 + l.KH, LW = l.TW - 1 + l.KW;
+        const size_t need = lstm_dma_lds_bytes(l.NI, LH, LW);
+        if (need <= 79 * 1024 && l.NI * LH * LW <= 288) l.lds_dma = need;
+    }
 }
 
 // canonical [KH][KW][Cin][Ctot] -> packed [chunk][tap][k8][khalf][Ntot][4]
@@ -377,7 +385,7 @@ struct vf_handle {
     struct SchedCache {                 // device copy of one schedule + the key it was built for
         PhaseDesc *d_phases = nullptr;
         int B = -1, items = 0, counters = 0, phases = 0;
-        bool dedup = true;
+        bool dedup = true, lstm_dma = false;
         double flops = 0.0;
         size_t lds = 0;
         std::vector<int> types, nitems;
@@ -394,6 +402,8 @@ struct vf_handle {
     bool phase_stats = false;
     int persist_wgs_per_cu = 2;
     size_t max_lds = 0;                 // largest dynamic LDS any tile of this engine needs
+    float *d_zeros = nullptr;           // 256 bytes of zeros (LDS-DMA source for padding positions)
+    bool lstm_dma = false;              // conv-LSTM layers use the DMA tile where it applies (vf_set_lstm_tile)
 
     // cross-rollout cache of the shared (batch-1, context-only) units
     bool cache_shared = true, shared_valid = false;
@@ -515,6 +525,7 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_CONVT_RAW_STATS, 1>, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_PARTIAL, 2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_bf16x6_kernel<1>, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_dma_kernel<1>, n))) return rc;
     const size_t np = n + kCtlWords * sizeof(int);
     if ((rc = allow_lds(&rollout_persistent_kernel<1, 2>, np))) return rc;
     if ((rc = allow_lds(&rollout_persistent_kernel<2, 2>, np))) return rc;
@@ -536,6 +547,13 @@ static int launch_conv_m(const ConvLayer &l, const ConvParams &p, hipStream_t st
     return VF_OK;
 }
 
+static int launch_lstm_dma(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
+    const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
+    hipLaunchKernelGGL((conv_lstm_dma_kernel<1>), dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_dma, st, p);
+    VF_HIP_CHECK(hipGetLastError());
+    return VF_OK;
+}
+
 template <int MREP>
 static int launch_lstm_bf16x6(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
@@ -550,6 +568,7 @@ template <int G, int EPI>
 static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     if constexpr (EPI == EPI_LSTM) {
         if (l.prec == 1) return launch_lstm_bf16x6<1>(l, p, st);        // 128-row tiles only
+        if (p.tile_variant == 2) return launch_lstm_dma(l, p, st);
         return l.mrep == 1 ? launch_conv_m<G, EPI, 1>(l, p, st) : launch_conv_m<G, EPI, 2>(l, p, st);
     } else if constexpr (EPI == EPI_PARTIAL) {
         return launch_conv_m<G, EPI, 2>(l, p, st);
@@ -565,7 +584,8 @@ struct SegArg {
     const float *gamma, *beta; int gamma_mod; int relu;
 };
 
-static ConvParams make_params(const ConvLayer &l, const LayerW &w, int B, const SegArg &s0, const SegArg *s1) {
+static ConvParams make_params(const ConvLayer &l, const LayerW &w, int B, const SegArg &s0, const SegArg *s1,
+                              const float *zeros = nullptr, bool lstm_dma = false) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
     const SegArg *sa[2] = {&s0, s1};
@@ -586,6 +606,8 @@ static ConvParams make_params(const ConvLayer &l, const LayerW &w, int B, const 
     p.ncg = l.ncg; p.Cout = l.Cout; p.Wp = w.w; p.Wp16 = w.w16; p.bias = w.b;
     p.chunks_per_split = l.chunks_per_split; p.n_valid = l.n_valid;
     p.stats_nparts = l.stats_nparts;
+    p.zeros = zeros;
+    p.tile_variant = l.prec == 1 ? 1 : (lstm_dma && l.lds_dma ? 2 : 0);
     return p;
 }
 
@@ -690,7 +712,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     h->max_lds = (size_t)composite_lds_floats<kMaxDesig, 10>() * 4;
     for (size_t i = 0; i < h->layers.size(); ++i) {
         h->layers[i]->id = (int)i;
-        h->max_lds = std::max(h->max_lds, h->layers[i]->lds_bytes);
+        h->max_lds = std::max(h->max_lds, std::max(h->layers[i]->lds_bytes, h->layers[i]->lds_dma));
     }
     h->max_lds += 16;
 
@@ -762,6 +784,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     VF_ALLOC(h->sched[1].d_phases, h->sched_capacity);
     VF_ALLOC(h->d_sync, 1 + h->counter_capacity);
     VF_ALLOC(h->d_status, 1);
+    VF_ALLOC(h->d_zeros, 64);
     VF_ALLOC(h->d_stats, h->sched_capacity * 2);
     for (int i = 0; i < NV * kMaxSubBatches; ++i) {
         BatchView sv;
@@ -785,7 +808,8 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     }
 #undef VF_ALLOC
 #ifndef VF_HOST_SELFTEST
-    if (hipMemset(h->d_sync, 0, sizeof(int)) != hipSuccess || hipMemset(h->d_status, 0, sizeof(int)) != hipSuccess) {
+    if (hipMemset(h->d_sync, 0, sizeof(int)) != hipSuccess || hipMemset(h->d_status, 0, sizeof(int)) != hipSuccess ||
+        hipMemset(h->d_zeros, 0, 64 * sizeof(float)) != hipSuccess) {
         vf_destroy(h);
         return fail(VF_ERR_HIP, "hipMemset of the scheduler words failed");
     }
@@ -1058,8 +1082,8 @@ struct ScheduleSink {
         P.gy = l.ncg;
         P.whole = type == PH_FC_PARTIAL;
         P.mrep = l.mrep;
-        P.prec = l.prec;
-        max_lds = std::max(max_lds, l.lds_bytes);
+        P.prec = p.tile_variant;
+        max_lds = std::max(max_lds, p.tile_variant == 2 ? l.lds_dma : l.lds_bytes);
         const double rows = (double)p.B * l.Hout * l.Wout;
         const double taps = l.mode == PACK_CONVT ? 9.0 / 4.0 * 4.0 : (double)l.KH * l.KW;   // real taps
         flops += 2.0 * rows * taps * (l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0)) *
@@ -1111,7 +1135,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
     const int *L = kLstmSizes;
     const int lh[7] = {H2, H2, H4, H4, H8, H4, H2}, lw[7] = {W2, W2, W4, W4, W8, W4, W2};
     auto params = [&](const ConvLayer &l, int Bp, const SegArg &s0, const SegArg *s1) {
-        return make_params(l, vd.lw[l.id], Bp, s0, s1);
+        return make_params(l, vd.lw[l.id], Bp, s0, s1, h->d_zeros, h->lstm_dma);
     };
 
     auto all_shared = [&](int s) { return h->dedup && s < nc - 1; };
@@ -1443,7 +1467,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     const int cfg = 1000;
     const bool skip_shared = shared_cache_hit(h, cfg);
     vf_handle::SchedCache &sc_host = h->sched[skip_shared ? 1 : 0];
-    if (sc_host.B != B || sc_host.dedup != h->dedup) {
+    if (sc_host.B != B || sc_host.dedup != h->dedup || sc_host.lstm_dma != h->lstm_dma) {
         BuiltSchedule bs;
         if ((rc = build_schedule(h, B, skip_shared, bs))) return rc;
         // Upload without synchronising the caller's stream: the copy is stream-ordered behind the
@@ -1458,7 +1482,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
                                     hipMemcpyHostToDevice, st));
         VF_HIP_CHECK(hipEventRecord(h->stage_done[slot], st));
         h->stage_used[slot] = true;
-        sc_host.B = B; sc_host.dedup = h->dedup;
+        sc_host.B = B; sc_host.dedup = h->dedup; sc_host.lstm_dma = h->lstm_dma;
         sc_host.items = bs.items; sc_host.counters = bs.counters;
         sc_host.phases = (int)bs.phases.size();
         sc_host.types.clear(); sc_host.nitems.clear();
@@ -1633,6 +1657,12 @@ int vf_debug_tile_clocks(uint64_t *out /*[16][8]*/, int32_t reset) {
     return VF_OK;
 }
 #endif
+
+int vf_set_lstm_tile(vf_handle *h, int32_t variant) {
+    if (!h || (variant != 0 && variant != 2)) return fail(VF_ERR_INVALID, "tile variant must be 0 (LDS-B tile) or 2 (DMA tile)");
+    h->lstm_dma = variant == 2;
+    return VF_OK;
+}
 
 int vf_set_dedup(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");

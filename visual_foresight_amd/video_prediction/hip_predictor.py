@@ -77,6 +77,7 @@ class HipVPredEvaluation(object):
         self.set_substreams(int(hp.get('substreams', os.environ.get('VF_SUBSTREAMS', 1))))
         self.set_dedup(int(hp.get('dedup', os.environ.get('VF_DEDUP', 1))))
         self.set_persistent(int(hp.get('persistent', os.environ.get('VF_PERSISTENT', 1))))
+        self.set_lstm_tile(int(hp.get('lstm_tile', os.environ.get('VF_LSTM_TILE', 0))))
         self.weights = None
         self._ctx_key = None
         self._last_M = 0
@@ -106,6 +107,12 @@ class HipVPredEvaluation(object):
         """Run each rollout as one persistent launch (bit-identical results; see vf_persistent.h)."""
         _lib.check(self._libh.vf_set_persistent(self._handle, int(bool(enable))))
         self.persistent = bool(enable)
+
+    def set_lstm_tile(self, variant):
+        """conv-LSTM tile: 0 = weights through LDS, barrier per tap (default); 2 = LDS-DMA double-buffered input
+        staging, weights from L2; same bits, same speed (A/B switch)."""
+        _lib.check(self._libh.vf_set_lstm_tile(self._handle, int(variant)))
+        self.lstm_tile = int(variant)
 
     def device_status(self):
         """Synchronise, return the sticky failure word of the persistent kernel (0 = healthy), re-arm it."""
