@@ -53,7 +53,7 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx,
     const int plane_units = p.NI * tile_px * kBfRowUnits;          // 16-B units per bf16 plane
     u16x8 *aP = reinterpret_cast<u16x8 *>(smem);                   // [3][pixel][3 units]
     float *lnTab = smem + (size_t)3 * plane_units * 4;             // [2][NI][2]
-    double *red = reinterpret_cast<double *>(lnTab + 4 * p.NI);
+    long long *red = reinterpret_cast<long long *>(lnTab + 4 * p.NI);
     u16x8 *bsm = reinterpret_cast<u16x8 *>(lnTab + 4 * p.NI + 16);  // [2 buf][4 gates][3 planes][64]
     const int cg = by;
     const int tiles_per_img = p.tilesY * p.tilesX;
@@ -74,14 +74,10 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx,
         float mean = 0.f, rstd = 1.f;
         const int b = bimg0 + img;
         if (sg.ln_part && b < p.B) {
-            double su = 0.0, sq = 0.0;
-            const double *pp = sg.ln_part + (long long)b * sg.ln_bstride;
+            long long su = 0, sq = 0;
+            const long long *pp = sg.ln_part + (long long)b * sg.ln_bstride;
             for (int k = 0; k < sg.ln_nparts; ++k) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
-            const double m = su * (double)sg.ln_inv_n;
-            double var = sq * (double)sg.ln_inv_n - m * m;
-            var = var < 0.0 ? 0.0 : var;
-            mean = (float)m;
-            rstd = (float)(1.0 / sqrt(var + (double)kLnEps));
+            ln_from_totals(su, sq, sg.ln_inv_n, mean, rstd);
         }
         lnTab[2 * i] = mean;
         lnTab[2 * i + 1] = rstd;

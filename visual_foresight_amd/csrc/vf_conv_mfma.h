@@ -75,8 +75,8 @@ struct ConvSeg {
     long long bstride;      // floats between samples (0: one image broadcast to every sample)
     int C;                  // channels (= pixel stride)
     int nchunk;             // ceil(C / KC)
-    const double *ln_part;  // LayerNorm partial sums [B][ln_nparts][2] (sum, sumsq) or null
-    long long ln_bstride;   // doubles between samples (0: shared statistics)
+    const long long *ln_part;  // LayerNorm partial sums [B][ln_nparts][2] (sum, sumsq; Q31.32 integers) or null
+    long long ln_bstride;   // entries between samples (0: shared statistics)
     int ln_nparts;
     float ln_inv_n;         // 1 / (elements normalised together)
     const float *gamma;     // [gamma_mod]
@@ -106,7 +106,7 @@ struct ConvParams {
     float *cstate;          // EPI_LSTM: new cell state [B][H][W][C]
     const float *cstate_in; // EPI_LSTM: previous cell state (may alias cstate)
     long long cin_bstride;  // floats between samples of cstate_in (0: shared)
-    double *stats;          // LayerNorm partial sums of the output [B][stats_nparts][2]
+    long long *stats;       // LayerNorm partial sums of the output [B][stats_nparts][2] (Q31.32 integers)
     int stats_nparts;
     int chunks_per_split;   // K split (blockIdx.z)
     int n_valid;            // EPI_PARTIAL: valid output columns
@@ -127,12 +127,36 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+__device__ __forceinline__ long long wave_sum(long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// LayerNorm statistics are EXACT: every element contributes the integers trunc(v * 2^32) and
+// trunc(v^2 * 2^32) (a deterministic function of the element alone; resolution 2.3e-10, far below
+// fp32 rounding), and integer addition is associative.  The per-sample totals - and therefore every
+// result of the network - do not depend on how a layer is cut into tiles, waves and lanes, which is
+// what allows the tile plan to follow the batch size without giving up bit-identical scores across
+// chunkings, rank counts and launch strategies.  Range: |v| < 46340 (outputs here are O(1) .. O(100)).
+constexpr double kStatScale = 4294967296.0;         // 2^32
+__device__ __forceinline__ long long stat_q(const float v) { return (long long)((double)v * kStatScale); }
+__device__ __forceinline__ long long stat_q2(const float v) { return (long long)((double)v * (double)v * kStatScale); }
+// mean / rstd from the integer totals of n = 1 / inv_n elements
+__device__ __forceinline__ void ln_from_totals(const long long su, const long long sq, const float inv_n,
+                                               float &mean, float &rstd) {
+    const double m = (double)su * (1.0 / kStatScale) * (double)inv_n;
+    double var = (double)sq * (1.0 / kStatScale) * (double)inv_n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)kLnEps));
+}
 
 // Shared epilogue of the fp32 and the split-bf16 tiles: accumulators (MFMA 32x32 C layout) ->
 // bias / activation / cell update / stores + deterministic LayerNorm partial sums.
 template <int G, int EPI, int MREP, class PT>
 __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G], const int bx, const int by,
-                                              const int bz, double *red) {
+                                              const int bz, long long *red) {
     constexpr int WROWS = MREP * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
@@ -154,7 +178,7 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
 #pragma unroll
     for (int g = 0; g < G; ++g) bias_g[g] = (EPI == EPI_PARTIAL) ? 0.f : p.bias[(cg * G + g) * 32 + n];
 
-    float ssum = 0.f, ssq = 0.f;            // LayerNorm partials over this lane's outputs
+    long long ssum = 0, ssq = 0;            // exact LayerNorm partials over this lane's outputs
 
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
@@ -178,14 +202,14 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
                 const float h_new = tanhf_(c_new) * sigmoidf_(go);
                 p.cstate[o] = c_new;
                 p.out[o] = h_new;
-                ssum += h_new; ssq = fmaf(h_new, h_new, ssq);
+                ssum += stat_q(h_new); ssq += stat_q2(h_new);
             } else if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_RAW_STATS) {
                 if (ch < p.Cout) {
                     float v = acc[m][0][r] + bias_g[0];
                     if (p.sbias) v += p.sbias[(long long)b * p.sbias_ld + ch];
                     if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
                     p.out[(((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch] = v;
-                    ssum += v; ssq = fmaf(v, v, ssq);
+                    if constexpr (EPI == EPI_RAW_STATS) { ssum += stat_q(v); ssq += stat_q2(v); }
                 }
             } else if constexpr (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS) {
                 if (ch < p.Cout) {
@@ -195,7 +219,7 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
                         float v = acc[m][g][r] + bias_g[g];
                         if (EPI == EPI_CONVT_RELU) v = fmaxf(v, 0.f);
                         p.out[(((long long)b * (2 * p.Hout) + oy) * (2 * p.Wout) + ox) * p.Cout + ch] = v;
-                        ssum += v; ssq = fmaf(v, v, ssq);
+                        if constexpr (EPI == EPI_CONVT_RAW_STATS) { ssum += stat_q(v); ssq += stat_q2(v); }
                     }
                 }
             } else {    // EPI_PARTIAL: [split][B][n_valid]
@@ -206,16 +230,16 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
     }
 
     if constexpr (EPI == EPI_LSTM || EPI == EPI_RAW_STATS || EPI == EPI_CONVT_RAW_STATS) {
-        // deterministic reduction: lane -> wave (xor butterfly) -> fixed-order sum over waves
-        const double wsum = wave_sum((double)ssum), wsq = wave_sum((double)ssq);
+        // exact integer reduction: lane -> wave (xor butterfly) -> waves -> one partial per tile
+        const long long wsum = wave_sum(ssum), wsq = wave_sum(ssq);
         __syncthreads();
         if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
         __syncthreads();
         if (p.NI == 1) {
             if (tid == 0 && bimg0 < p.B) {
-                double su = 0.0, sq = 0.0;
+                long long su = 0, sq = 0;
                 for (int w = 0; w < 4; ++w) { su += red[2 * w]; sq += red[2 * w + 1]; }
-                double *dst = p.stats + ((long long)bimg0 * p.stats_nparts + tile_id * p.ncg + cg) * 2;
+                long long *dst = p.stats + ((long long)bimg0 * p.stats_nparts + tile_id * p.ncg + cg) * 2;
                 dst[0] = su; dst[1] = sq;
             }
         } else {
@@ -226,9 +250,9 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
                 const int img = wave / waves_per_img;
                 const int b = bimg0 + img;
                 if (img < p.NI && b < p.B) {
-                    double su = 0.0, sq = 0.0;
+                    long long su = 0, sq = 0;
                     for (int w = 0; w < waves_per_img; ++w) { su += red[2 * (wave + w)]; sq += red[2 * (wave + w) + 1]; }
-                    double *dst = p.stats + ((long long)b * p.stats_nparts + cg) * 2;
+                    long long *dst = p.stats + ((long long)b * p.stats_nparts + cg) * 2;
                     dst[0] = su; dst[1] = sq;
                 }
             }
@@ -255,7 +279,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     const int tile_px = LH * LW;
     const int tile_floats = p.NI * tile_px * KCpad;
     float *lnTab = smem + tile_floats;                       // [2][NI][2]: mean, rstd
-    double *red = reinterpret_cast<double *>(lnTab + 4 * p.NI);   // [4 waves][2]
+    long long *red = reinterpret_cast<long long *>(lnTab + 4 * p.NI);   // [4 waves][2]
     const int cg = by;
     const int tiles_per_img = p.tilesY * p.tilesX;
 
@@ -280,14 +304,10 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
         float mean = 0.f, rstd = 1.f;
         const int b = bimg0 + img;
         if (sg.ln_part && b < p.B) {
-            double su = 0.0, sq = 0.0;
-            const double *pp = sg.ln_part + (long long)b * sg.ln_bstride;
+            long long su = 0, sq = 0;
+            const long long *pp = sg.ln_part + (long long)b * sg.ln_bstride;
             for (int k = 0; k < sg.ln_nparts; ++k) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
-            const double m = su * (double)sg.ln_inv_n;
-            double var = sq * (double)sg.ln_inv_n - m * m;
-            var = var < 0.0 ? 0.0 : var;
-            mean = (float)m;
-            rstd = (float)(1.0 / sqrt(var + (double)kLnEps));
+            ln_from_totals(su, sq, sg.ln_inv_n, mean, rstd);
         }
         lnTab[2 * i] = mean;
         lnTab[2 * i + 1] = rstd;
@@ -511,7 +531,7 @@ __device__ __forceinline__ void conv_lstm_dma_tile(const PT &p, const int bx, co
     const int n_dma = (total_px + 7) >> 3;                  // DMA instructions per chunk (8 pixels each)
     const int buf_floats = n_dma * 8 * KC;                  // whole KiB blocks
     float *lnTab = smem + 2 * buf_floats;                   // [2][NI][2]: mean, rstd
-    double *red = reinterpret_cast<double *>(lnTab + 4 * p.NI + (p.NI & 1) * 2);
+    long long *red = reinterpret_cast<long long *>(lnTab + 4 * p.NI + (p.NI & 1) * 2);
     const int cg = by;
     const int tiles_per_img = p.tilesY * p.tilesX;
 
@@ -533,14 +553,10 @@ __device__ __forceinline__ void conv_lstm_dma_tile(const PT &p, const int bx, co
         float mean = 0.f, rstd = 1.f;
         const int b = bimg0 + img;
         if (sg.ln_part && b < p.B) {
-            double su = 0.0, sq = 0.0;
-            const double *pp = sg.ln_part + (long long)b * sg.ln_bstride;
+            long long su = 0, sq = 0;
+            const long long *pp = sg.ln_part + (long long)b * sg.ln_bstride;
             for (int k = 0; k < sg.ln_nparts; ++k) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
-            const double m = su * (double)sg.ln_inv_n;
-            double var = sq * (double)sg.ln_inv_n - m * m;
-            var = var < 0.0 ? 0.0 : var;
-            mean = (float)m;
-            rstd = (float)(1.0 / sqrt(var + (double)kLnEps));
+            ln_from_totals(su, sq, sg.ln_inv_n, mean, rstd);
         }
         lnTab[2 * i] = mean;
         lnTab[2 * i + 1] = rstd;

@@ -125,7 +125,7 @@ static const TensorDesc *find_tensor(const std::vector<TensorDesc> &t, const std
 
 // ------------------------------------------------------------------ one dense layer
 enum PackMode { PACK_PLAIN, PACK_LSTM, PACK_CONVT };
-static const int kNumConvLayers = 15;
+static const int kNumConvLayers = 22;       // 15 layers + the 256-row plans of the 7 conv-LSTMs
 
 struct ConvLayer {          // geometry only: shared by every view; the packed weights are per view
     std::string name;
@@ -319,7 +319,7 @@ using namespace vf;
 struct BatchView {
     float *enc0_o, *enc1_o, *enc2_o, *enc3_o, *enc4_o, *enc5_o, *enc6_o;
     float *c_state[7], *h_state[7][2];
-    double *st_enc0, *st_h[7], *st_enc6;
+    long long *st_enc0, *st_h[7], *st_enc6;
     float *sbias, *fc_part, *kern;
     float *frames_all, *distrib_all, *states_all;
     double *sums;
@@ -352,6 +352,14 @@ struct vf_handle {
 
     // layers (geometry)
     ConvLayer enc0, lstm[7], enc1, enc2, enc3, convt1, convt2, convt3, fc;
+    // Second tile plan of every conv-LSTM (256 GEMM rows per workgroup, 16-channel chunks): fewer, longer
+    // items - better per FLOP once a phase has far more items than workgroup slots, worse for the per-sample
+    // dependency chain of a small batch.  LayerNorm statistics are exact integers (vf_conv_mfma.h), so the
+    // choice is invisible in the results and may follow the batch size.
+    ConvLayer lstm_big[7];
+    bool have_big = false;
+    int st_rows[7] = {0};               // LayerNorm partial-sum slots per sample of lstm k (max over its plans)
+    int mrep_override[7] = {0};         // VF_DEBUG_KNOBS: 1 / 2 forces a plan, 0 = automatic
     std::vector<ConvLayer *> layers;    // in slot order
     std::vector<ViewData> views;
 
@@ -364,7 +372,7 @@ struct vf_handle {
     float *enc0_o = nullptr, *enc1_o = nullptr, *enc2_o = nullptr, *enc3_o = nullptr;
     float *enc4_o = nullptr, *enc5_o = nullptr, *enc6_o = nullptr;
     float *c_state[7] = {nullptr}, *h_state[7][2] = {{nullptr}};
-    double *st_enc0 = nullptr, *st_h[7] = {nullptr}, *st_enc6 = nullptr;
+    long long *st_enc0 = nullptr, *st_h[7] = {nullptr}, *st_enc6 = nullptr;
     float *sbias = nullptr, *fc_part = nullptr, *kern = nullptr;
 
     // predictions of the last rollout
@@ -580,7 +588,7 @@ static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st
 #endif  // VF_HOST_SELFTEST
 
 struct SegArg {
-    const float *ptr; long long bstride; const double *ln_part; long long ln_bstride; int ln_nparts; float ln_inv_n;
+    const float *ptr; long long bstride; const long long *ln_part; long long ln_bstride; int ln_nparts; float ln_inv_n;
     const float *gamma, *beta; int gamma_mod; int relu;
 };
 
@@ -605,7 +613,7 @@ static ConvParams make_params(const ConvLayer &l, const LayerW &w, int B, const 
     p.NI = l.NI; p.TH = l.TH; p.TW = l.TW; p.RPI = l.RPI; p.tilesY = l.tilesY; p.tilesX = l.tilesX;
     p.ncg = l.ncg; p.Cout = l.Cout; p.Wp = w.w; p.Wp16 = w.w16; p.bias = w.b;
     p.chunks_per_split = l.chunks_per_split; p.n_valid = l.n_valid;
-    p.stats_nparts = l.stats_nparts;
+    p.stats_nparts = l.stats_nparts;    // row stride of p.stats; the conv-LSTM plans overwrite it with st_rows[k]
     p.zeros = zeros;
     p.tile_variant = l.prec == 1 ? 1 : (lstm_dma && l.lds_dma ? 2 : 0);
     return p;
@@ -678,10 +686,10 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
 
     // rows per LSTM workgroup: 128 (mrep 1) keeps items short - the per-sample dependency chain,
     // not the MFMA rate, bounds a 200-sample rollout
-    int lstm_mrep[7] = {1, 1, 1, 1, 1, 1, 1};
+    const int lstm_mrep[7] = {1, 1, 1, 1, 1, 1, 1};
 #ifdef VF_DEBUG_KNOBS
     if (const char *e = getenv("VF_LSTM_MREP"))
-        for (int k = 0; k < 7 && e[k]; ++k) lstm_mrep[k] = e[k] == '2' ? 2 : 1;
+        for (int k = 0; k < 7 && e[k]; ++k) h->mrep_override[k] = e[k] == '2' ? 2 : (e[k] == '1' ? 1 : 0);
 #endif
     init_layer(h->enc0, "enc0", PACK_PLAIN, H, W, H2, W2, 5, 5, 2, 1, 3, 0, 32, true);
     init_layer(h->lstm[0], "lstm1", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, 32, L[0], L[0], true, false, lstm_mrep[0], cfg->precision);
@@ -709,6 +717,16 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     }
     h->layers = {&h->enc0, &h->lstm[0], &h->lstm[1], &h->enc1, &h->lstm[2], &h->lstm[3], &h->enc2, &h->enc3,
                  &h->lstm[4], &h->convt1, &h->lstm[5], &h->convt2, &h->lstm[6], &h->convt3, &h->fc};
+    h->have_big = cfg->precision == 0;      // the split-bf16 tile has 128 rows only
+    for (int k = 0; k < 7; ++k) {
+        h->st_rows[k] = h->lstm[k].stats_nparts;
+        if (!h->have_big) continue;
+        const ConvLayer &sm = h->lstm[k];
+        init_layer(h->lstm_big[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[0],
+                   sm.segC[1], sm.Cout, true, false, 2, 0);
+        h->layers.push_back(&h->lstm_big[k]);
+        h->st_rows[k] = std::max(h->st_rows[k], h->lstm_big[k].stats_nparts);
+    }
     h->max_lds = (size_t)composite_lds_floats<kMaxDesig, 10>() * 4;
     for (size_t i = 0; i < h->layers.size(); ++i) {
         h->layers[i]->id = (int)i;
@@ -764,7 +782,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         VF_ALLOC(h->c_state[k], elems);
         VF_ALLOC(h->h_state[k][0], elems);
         VF_ALLOC(h->h_state[k][1], elems);
-        VF_ALLOC(h->st_h[k], BV * h->lstm[k].stats_nparts * 2);
+        VF_ALLOC(h->st_h[k], BV * h->st_rows[k] * 2);
     }
     VF_ALLOC(h->st_enc0, BV * h->enc0.stats_nparts * 2);
     VF_ALLOC(h->st_enc6, BV * h->convt3.stats_nparts * 2);
@@ -800,7 +818,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
             VF_ALLOC(sv.c_state[k], per);
             VF_ALLOC(sv.h_state[k][0], per);
             VF_ALLOC(sv.h_state[k][1], per);
-            VF_ALLOC(sv.st_h[k], (size_t)h->lstm[k].stats_nparts * 2);
+            VF_ALLOC(sv.st_h[k], (size_t)h->st_rows[k] * 2);
         }
         VF_ALLOC(sv.st_enc0, (size_t)h->enc0.stats_nparts * 2);
         VF_ALLOC(sv.sbias, (size_t)L[3]);
@@ -970,7 +988,7 @@ static BatchView make_view(vf_handle *h, int view, const float *d_actions, int b
         v.c_state[k] = h->c_state[k] + b * per;
         v.h_state[k][0] = h->h_state[k][0] + b * per;
         v.h_state[k][1] = h->h_state[k][1] + b * per;
-        v.st_h[k] = h->st_h[k] + b * h->lstm[k].stats_nparts * 2;
+        v.st_h[k] = h->st_h[k] + b * h->st_rows[k] * 2;
     }
     v.st_enc0 = h->st_enc0 + b * h->enc0.stats_nparts * 2;
     v.st_enc6 = h->st_enc6 + b * h->convt3.stats_nparts * 2;
@@ -1138,6 +1156,14 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         return make_params(l, vd.lw[l.id], Bp, s0, s1, h->d_zeros, h->lstm_dma);
     };
 
+    // tile plan of conv-LSTM k for a phase of Bp samples: the 256-row plan once the phase has many more items than
+    // the chip has workgroup slots (everything from ~500 64x64-samples on; the two widest layers from ~150)
+    auto lstm_plan = [&](int k, int Bp) -> const ConvLayer & {
+        if (!h->have_big) return h->lstm[k];
+        if (h->mrep_override[k]) return h->mrep_override[k] == 2 ? h->lstm_big[k] : h->lstm[k];
+        const double beff = (double)Bp * H * W / 4096.0;
+        return (beff >= 500.0 || (beff >= 150.0 && k < 2)) ? h->lstm_big[k] : h->lstm[k];
+    };
     auto all_shared = [&](int s) { return h->dedup && s < nc - 1; };
     auto enc_shared = [&](int s) { return h->dedup && s < nc; };
     // is the output of lstm k at step s one shared image?  (s < 0: the shared zero state)
@@ -1146,10 +1172,10 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
     auto plain = [](const float *ptr, long long bs) {
         SegArg s; memset(&s, 0, sizeof(s)); s.ptr = ptr; s.bstride = bs; s.gamma_mod = 1; return s;
     };
-    auto normed = [](const float *ptr, long long bs, const double *part, int nparts, bool shared,
+    auto normed = [](const float *ptr, long long bs, const long long *part, int nparts, int row_slots, bool shared,
                      long long count, const float *g, const float *b, int gmod, int relu) {
         SegArg s; s.ptr = ptr; s.bstride = bs; s.ln_part = part; s.ln_nparts = nparts;
-        s.ln_bstride = shared ? 0 : (long long)nparts * 2;
+        s.ln_bstride = shared ? 0 : (long long)row_slots * 2;
         s.ln_inv_n = (float)(1.0 / (double)count); s.gamma = g; s.beta = b; s.gamma_mod = gmod; s.relu = relu;
         return s;
     };
@@ -1193,35 +1219,36 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         VF_EMIT_SH(u_enc0, enc_sh, sink.conv(PH_CONV_RAW, h->enc0, p, {last}))
 
         SegArg enc0_n = normed(E.enc0_o, bs(enc_sh, (long long)H2 * W2 * 32), E.st_enc0, h->enc0.stats_nparts,
-                               enc_sh, (long long)H2 * W2 * 32, vd.ln_g[0], vd.ln_b[0], 32, 1);
+                               h->enc0.stats_nparts, enc_sh, (long long)H2 * W2 * 32, vd.ln_g[0], vd.ln_b[0], 32, 1);
         // LayerNorm index: ln1 = enc0, ln2..ln8 = lstm1..7, ln9 = convt3
         auto h_normed = [&](int k) {        // normalised new hidden state of lstm k at this step
             const bool shd = lstm_shared(k, s);
             const BatchView &O = shd ? sh : v;
             const long long per = (long long)lh[k] * lw[k] * L[k];
-            return normed(O.h_state[k][nxt], bs(shd, per), O.st_h[k], h->lstm[k].stats_nparts, shd, per,
-                          vd.ln_g[k + 1], vd.ln_b[k + 1], L[k], 0);
+            return normed(O.h_state[k][nxt], bs(shd, per), O.st_h[k], lstm_plan(k, shd ? 1 : B).stats_nparts,
+                          h->st_rows[k], shd, per, vd.ln_g[k + 1], vd.ln_b[k + 1], L[k], 0);
         };
         auto lstm_params = [&](int k, const SegArg &x) {
             const bool out_sh = lstm_shared(k, s), in_sh = lstm_shared(k, s - 1);
             const BatchView &O = out_sh ? sh : v, &I = in_sh ? sh : v;
             const long long per = (long long)lh[k] * lw[k] * L[k];
             SegArg hs = plain(I.h_state[k][cur], bs(in_sh, per));
-            ConvParams q = params(h->lstm[k], out_sh ? 1 : B, x, &hs);
+            ConvParams q = params(lstm_plan(k, out_sh ? 1 : B), out_sh ? 1 : B, x, &hs);
             q.out = O.h_state[k][nxt]; q.cstate = O.c_state[k]; q.stats = O.st_h[k];
+            q.stats_nparts = h->st_rows[k];
             q.cstate_in = I.c_state[k]; q.cin_bstride = bs(in_sh, per);
             return q;
         };
-        VF_EMIT_SH(u_l1, lstm_shared(0, s), sink.conv(PH_LSTM, h->lstm[0], lstm_params(0, enc0_n), {u_enc0}))
-        VF_EMIT_SH(u_l2, lstm_shared(1, s), sink.conv(PH_LSTM, h->lstm[1], lstm_params(1, h_normed(0)), {u_l1}))
+        VF_EMIT_SH(u_l1, lstm_shared(0, s), sink.conv(PH_LSTM, lstm_plan(0, lstm_shared(0, s) ? 1 : B), lstm_params(0, enc0_n), {u_enc0}))
+        VF_EMIT_SH(u_l2, lstm_shared(1, s), sink.conv(PH_LSTM, lstm_plan(1, lstm_shared(1, s) ? 1 : B), lstm_params(1, h_normed(0)), {u_l1}))
 
         p = params(h->enc1, BE, h_normed(1), nullptr);
         p.out = E.enc1_o;
         VF_EMIT_SH(u_enc1, enc_sh, sink.conv(PH_CONV_RELU, h->enc1, p, {u_l2}))
 
-        VF_EMIT_SH(u_l3, lstm_shared(2, s), sink.conv(PH_LSTM, h->lstm[2],
+        VF_EMIT_SH(u_l3, lstm_shared(2, s), sink.conv(PH_LSTM, lstm_plan(2, lstm_shared(2, s) ? 1 : B),
                                 lstm_params(2, plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]))), {u_enc1}))
-        VF_EMIT_SH(u_l4, lstm_shared(3, s), sink.conv(PH_LSTM, h->lstm[3], lstm_params(3, h_normed(2)), {u_l3}))
+        VF_EMIT_SH(u_l4, lstm_shared(3, s), sink.conv(PH_LSTM, lstm_plan(3, lstm_shared(3, s) ? 1 : B), lstm_params(3, h_normed(2)), {u_l3}))
 
         p = params(h->enc2, BE, h_normed(3), nullptr);
         p.out = E.enc2_o;
@@ -1231,7 +1258,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         p.out = D.enc3_o; p.sbias = D.sbias; p.sbias_ld = L[3];
         VF_EMIT_SH(u_enc3, all_sh, sink.conv(PH_CONV_RELU, h->enc3, p, {u_enc2, u_sa}))
 
-        VF_EMIT_SH(u_l5, lstm_shared(4, s), sink.conv(PH_LSTM, h->lstm[4],
+        VF_EMIT_SH(u_l5, lstm_shared(4, s), sink.conv(PH_LSTM, lstm_plan(4, lstm_shared(4, s) ? 1 : B),
                                 lstm_params(4, plain(D.enc3_o, bs(all_sh, (long long)H8 * W8 * L[3]))), {u_enc3}))
         SegArg h5n = h_normed(4);
 
@@ -1239,14 +1266,14 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         p = params(h->convt1, BD, h5n, nullptr);
         p.out = D.enc4_o;
         VF_EMIT_SH(u_t1, all_sh, sink.conv(PH_CONVT_RELU, h->convt1, p, {u_l5}))
-        VF_EMIT_SH(u_l6, lstm_shared(5, s), sink.conv(PH_LSTM, h->lstm[5],
+        VF_EMIT_SH(u_l6, lstm_shared(5, s), sink.conv(PH_LSTM, lstm_plan(5, lstm_shared(5, s) ? 1 : B),
                                 lstm_params(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))), {u_t1}))
 
         SegArg enc1_s = plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]));
         p = params(h->convt2, BD, h_normed(5), &enc1_s);
         p.out = D.enc5_o;
         VF_EMIT_SH(u_t2, all_sh, sink.conv(PH_CONVT_RELU, h->convt2, p, {u_l6}))
-        VF_EMIT_SH(u_l7, lstm_shared(6, s), sink.conv(PH_LSTM, h->lstm[6],
+        VF_EMIT_SH(u_l7, lstm_shared(6, s), sink.conv(PH_LSTM, lstm_plan(6, lstm_shared(6, s) ? 1 : B),
                                 lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))), {u_t2}))
         last = u_l7;
 
@@ -1451,7 +1478,7 @@ template <int ND>
 static int launch_persistent_t(vf_handle *h, const Schedule &sc, int grid, size_t lds, hipStream_t st) {
     // 3 resident workgroups per CU need the 168-VGPR build, which has no 256-row LSTM tile
     bool any_mrep2 = false;
-    for (int k = 0; k < 7; ++k) any_mrep2 = any_mrep2 || h->lstm[k].mrep == 2;
+    any_mrep2 = h->have_big;
     if (h->persist_wgs_per_cu >= 3 && !any_mrep2) return launch_persistent_w<ND, 3>(sc, grid, lds, st);
     return launch_persistent_w<ND, 2>(sc, grid, lds, st);
 }

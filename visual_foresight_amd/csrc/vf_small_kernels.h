@@ -114,7 +114,7 @@ VF_GLOBAL void cdna_finalize_kernel(const FinParams p) {
 struct CompositeParams {
     int B, H, W, ND, K;                 // K = num_masks (K+1 mask channels, K-1 kernels used)
     const float *enc6;                  // raw convT3 output [B][H][W][32]
-    const double *ln_part; int ln_nparts; float ln_inv_n;
+    const long long *ln_part; int ln_nparts; float ln_inv_n;     // exact statistics of enc6 (vf_conv_mfma.h)
     const float *gamma, *beta;          // LN9 [32]
     const float *w_rgb, *b_rgb;         // [32][3], [3]
     const float *w_mask, *b_mask;       // [32][K+1], [K+1]
@@ -157,14 +157,10 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
     const int ty0 = (tile / tilesX) * TS, tx0 = (tile % tilesX) * TS;
 
     if (tid == 0) {
-        double su = 0.0, sq = 0.0;
-        const double *pp = p.ln_part + (long long)b * p.ln_nparts * 2;
+        long long su = 0, sq = 0;
+        const long long *pp = p.ln_part + (long long)b * p.ln_nparts * 2;
         for (int k = 0; k < p.ln_nparts; ++k) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
-        const double m = su * (double)p.ln_inv_n;
-        double var = sq * (double)p.ln_inv_n - m * m;
-        var = var < 0.0 ? 0.0 : var;
-        s_ln[0] = (float)m;
-        s_ln[1] = (float)(1.0 / sqrt(var + (double)kLnEps));
+        ln_from_totals(su, sq, p.ln_inv_n, s_ln[0], s_ln[1]);
     }
     if (tid >= 64 && tid < 64 + ND) {
         const int d = tid - 64;
