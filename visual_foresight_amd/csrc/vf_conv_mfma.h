@@ -271,7 +271,9 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     constexpr int WROWS = MREP * 32;    // GEMM rows per wave
     // B through LDS pays for the long-K conv-LSTM tiles; the transposed convs (4 taps, 2-4 chunks)
     // lose more to its per-tap barrier than they gain, so they read B straight from L1/L2
-    constexpr bool kBLds = (EPI == EPI_LSTM) && !VF_LSTM_B_DIRECT;
+    // (the 256-row conv-LSTM tile reads B directly as well: its input tile needs the LDS, and it must keep the
+    // 32-channel chunks of the 128-row tile so that both plans accumulate every output in the same K order)
+    constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1 && !VF_LSTM_B_DIRECT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     const int KC = p.KC, KCpad = KC + 4, K8 = KC >> 3;

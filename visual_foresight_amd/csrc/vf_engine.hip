@@ -125,7 +125,7 @@ static const TensorDesc *find_tensor(const std::vector<TensorDesc> &t, const std
 
 // ------------------------------------------------------------------ one dense layer
 enum PackMode { PACK_PLAIN, PACK_LSTM, PACK_CONVT };
-static const int kNumConvLayers = 22;       // 15 layers + the 256-row plans of the 7 conv-LSTMs
+static const int kNumConvLayers = 15;
 
 struct ConvLayer {          // geometry only: shared by every view; the packed weights are per view
     std::string name;
@@ -159,7 +159,7 @@ static size_t conv_lds_bytes(const ConvLayer &l, int KC) {
     const int LH = (l.TH - 1) * l.stride + l.KH, LW = (l.TW - 1) * l.stride + l.KW;
     // A tile + LayerNorm table + reduction scratch (+ for 4-gate layers the double-buffered
     // per-tap B blocks: 2 x KC/8 x [4 gates][64 lanes] float4)
-    const size_t b_lds = (l.mode == PACK_LSTM && !VF_LSTM_B_DIRECT) ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
+    const size_t b_lds = (l.mode == PACK_LSTM && l.mrep == 1 && !VF_LSTM_B_DIRECT) ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
     return ((size_t)l.NI * LH * LW * (KC + 4) + 4 * (size_t)l.NI) * 4 + 64 + b_lds;
 }
 
@@ -170,6 +170,9 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
         l.TH = l.TW = 1; l.tilesY = l.tilesX = 1; l.RPI = 1; l.NI = rows;
     } else {
         l.TW = std::min(l.Wout, 32);
+#ifdef VF_DEBUG_KNOBS
+        if (const char *e = getenv("VF_TILE_W")) l.TW = std::min(l.Wout, std::max(8, atoi(e)));
+#endif
         l.TH = std::min(l.Hout, rows / l.TW);
         l.tilesX = (l.Wout + l.TW - 1) / l.TW;
         l.tilesY = (l.Hout + l.TH - 1) / l.TH;
@@ -352,12 +355,13 @@ struct vf_handle {
 
     // layers (geometry)
     ConvLayer enc0, lstm[7], enc1, enc2, enc3, convt1, convt2, convt3, fc;
-    // Second tile plan of every conv-LSTM (256 GEMM rows per workgroup, 16-channel chunks): fewer, longer
-    // items - better per FLOP once a phase has far more items than workgroup slots, worse for the per-sample
-    // dependency chain of a small batch.  LayerNorm statistics are exact integers (vf_conv_mfma.h), so the
-    // choice is invisible in the results and may follow the batch size.
+    // Second tile plan of every conv-LSTM (256 GEMM rows per workgroup, weights read straight from L2 so that
+    // the larger input tile fits the LDS with the SAME 32-channel chunks): fewer, longer items - better per
+    // FLOP once a phase has far more items than workgroup slots, worse for the per-sample dependency chain of
+    // a small batch.  Both plans accumulate every output in the same K order and LayerNorm statistics are
+    // exact integers (vf_conv_mfma.h), so the choice is invisible in the results and may follow the batch size.
     ConvLayer lstm_big[7];
-    bool have_big = false;
+    bool have_big = false, big_ok[7] = {false};
     int st_rows[7] = {0};               // LayerNorm partial-sum slots per sample of lstm k (max over its plans)
     int mrep_override[7] = {0};         // VF_DEBUG_KNOBS: 1 / 2 forces a plan, 0 = automatic
     std::vector<ConvLayer *> layers;    // in slot order
@@ -724,14 +728,20 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         const ConvLayer &sm = h->lstm[k];
         init_layer(h->lstm_big[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[0],
                    sm.segC[1], sm.Cout, true, false, 2, 0);
-        h->layers.push_back(&h->lstm_big[k]);
-        h->st_rows[k] = std::max(h->st_rows[k], h->lstm_big[k].stats_nparts);
+        // same chunking = same K order per output (bit-identical results) and the same packed weights
+        h->big_ok[k] = h->lstm_big[k].KC == sm.KC;
+        if (h->big_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_big[k].stats_nparts);
     }
     h->max_lds = (size_t)composite_lds_floats<kMaxDesig, 10>() * 4;
     for (size_t i = 0; i < h->layers.size(); ++i) {
         h->layers[i]->id = (int)i;
         h->max_lds = std::max(h->max_lds, std::max(h->layers[i]->lds_bytes, h->layers[i]->lds_dma));
     }
+    for (int k = 0; k < 7; ++k)
+        if (h->have_big && h->big_ok[k]) {
+            h->lstm_big[k].id = h->lstm[k].id;          // shares the packed weights of the 128-row plan
+            h->max_lds = std::max(h->max_lds, h->lstm_big[k].lds_bytes);
+        }
     h->max_lds += 16;
 
 #define VF_ALLOC(ptr, n)                           \
@@ -1159,7 +1169,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
     // tile plan of conv-LSTM k for a phase of Bp samples: the 256-row plan once the phase has many more items than
     // the chip has workgroup slots (everything from ~500 64x64-samples on; the two widest layers from ~150)
     auto lstm_plan = [&](int k, int Bp) -> const ConvLayer & {
-        if (!h->have_big) return h->lstm[k];
+        if (!h->have_big || !h->big_ok[k]) return h->lstm[k];
         if (h->mrep_override[k]) return h->mrep_override[k] == 2 ? h->lstm_big[k] : h->lstm[k];
         const double beff = (double)Bp * H * W / 4096.0;
         return (beff >= 500.0 || (beff >= 150.0 && k < 2)) ? h->lstm_big[k] : h->lstm[k];
