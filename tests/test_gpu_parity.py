@@ -113,6 +113,29 @@ def test_chunking_permutation_and_determinism():
     np.testing.assert_array_equal(fa['predicted_frames'], fb['predicted_frames'])
 
 
+def test_tile_plans_are_invisible_in_the_results():
+    """The conv-LSTM tile plan follows the batch size (64 / 128 / 256 rows per workgroup: DESIGN.md 4.1).  Exact
+    LayerNorm statistics and a common K order make the choice invisible: the same 160 candidates rolled as one
+    batch (256-row tiles on the two widest layers), in chunks of 70 (128-row tiles) and in chunks of 30 (64-row
+    tiles) give identical bits, for scores and for the materialised predictions."""
+    H = W = 64
+    T, M = 3, 160
+    rs = np.random.RandomState(17)
+    ctx = _context(H, W, 2, rs)
+    actions = rs.normal(0, 0.1, (M, T, 4))
+    goal = np.array([[[3, 20], [50, 9]]])
+    outs = []
+    for bs in (M, 70, 30):
+        pred, _ = _predictor(H, W, T, 2, bs=bs)
+        s, pt = pred.score(ctx, {'actions': actions}, goal)
+        got = pred(ctx, {'actions': actions[:40]})
+        outs.append((s, pt, got['predicted_frames'], got['predicted_pixel_distributions']))
+        assert pred.device_status() == 0
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_full_size_properties():
     """BASELINE config-2 size (200 x 13 x 64x64): size-independent properties."""
     H = W = 64

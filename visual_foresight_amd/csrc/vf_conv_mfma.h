@@ -260,15 +260,89 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
     }
 }
 
+// Epilogue of the 64-row conv-LSTM tile (conv_tile<4, EPI_LSTM, 1, PT, true>): wave w holds gates
+// {i, j} (w < 2) or {f, o} (w >= 2) of row block w & 1, so the pair product sigmoid(i) * tanh(j) crosses
+// through LDS (xch: [2 row blocks][16][64 lanes] floats, the idle input-tile area) and the waves
+// holding f and o finish the cell update.  Same expressions, hence the same bits, as conv_epilogue.
+template <class PT>
+__device__ __forceinline__ void lstm_half_epilogue(const PT &p, f32x16 (&acc)[1][2], const int bx, const int by,
+                                                   long long *red, float *xch) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    const int rb = wave & 1, gp = wave >> 1;
+    const int cg = by;
+    const int tiles_per_img = p.tilesY * p.tilesX;
+    const int px_per_img = p.TH * p.TW;
+    int bimg0, ty0, tx0, tile_id;
+    if (p.NI == 1) {
+        bimg0 = bx / tiles_per_img;
+        tile_id = bx % tiles_per_img;
+        ty0 = (tile_id / p.tilesX) * p.TH;
+        tx0 = (tile_id % p.tilesX) * p.TW;
+    } else {
+        bimg0 = bx * p.NI;
+        tile_id = 0; ty0 = 0; tx0 = 0;
+    }
+    const int ch = cg * 32 + n;
+    const float bias0 = p.bias[(cg * 4 + gp * 2) * 32 + n], bias1 = p.bias[(cg * 4 + gp * 2 + 1) * 32 + n];
+    __syncthreads();                        // the input tile is no longer read: its LDS becomes xch
+    if (gp == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            xch[(rb * 16 + r) * 64 + lane] = sigmoidf_(acc[0][0][r] + bias0) * tanhf_(acc[0][1][r] + bias1);
+    }
+    __syncthreads();
+    long long ssum = 0, ssq = 0;
+    if (gp == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int img = row / p.RPI, rem = row % p.RPI;
+            const int y = ty0 + rem / p.TW, x = tx0 + rem % p.TW;
+            const int b = bimg0 + img;
+            const bool ok = img < p.NI && rem < px_per_img && b < p.B && y < p.Hout && x < p.Wout;
+            if (!ok) continue;
+            const long long o = (((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch;
+            const float gf = acc[0][0][r] + bias0, go = acc[0][1][r] + bias1;
+            const float c_old = p.cstate_in[(long long)b * p.cin_bstride + ((long long)y * p.Wout + x) * p.Cout + ch];
+            const float c_new = fmaf(c_old, sigmoidf_(gf + 1.0f), xch[(rb * 16 + r) * 64 + lane]);
+            const float h_new = tanhf_(c_new) * sigmoidf_(go);
+            p.cstate[o] = c_new;
+            p.out[o] = h_new;
+            ssum += stat_q(h_new); ssq += stat_q2(h_new);
+        }
+    }
+    const long long wsum = wave_sum(ssum), wsq = wave_sum(ssq);
+    if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
+    __syncthreads();
+    if (tid == 0) {
+        // row block rb (carried by wave 2 + rb) lies in image slot rb * 32 / RPI
+        for (int img = 0; img < p.NI; ++img) {
+            if (bimg0 + img >= p.B) continue;
+            long long su = 0, sq = 0;
+            for (int r2 = 0; r2 < 2; ++r2)
+                if ((r2 * 32) / p.RPI == img) { su += red[2 * (2 + r2)]; sq += red[2 * (2 + r2) + 1]; }
+            long long *dst = p.stats + ((long long)(bimg0 + img) * p.stats_nparts +
+                                        (p.NI == 1 ? tile_id * p.ncg + cg : cg)) * 2;
+            dst[0] = su; dst[1] = sq;
+        }
+    }
+}
+
 // One workgroup tile.  (bx, by, bz) = (row tile, channel group, K split); smem = the workgroup's
 // dynamic LDS (conv_lds_bytes).  Called by the per-layer kernel below and, item by item, by the
 // persistent rollout kernel (vf_persistent.h).
 // MREP = MFMA row blocks (of 32 GEMM rows) per wave: the workgroup covers 4 * MREP * 32 rows.
 // PT = ConvParams (kernel argument) or ConvParams in the constant address space (persistent kernel).
-template <int G, int EPI, int MREP, class PT>
+// HALF (conv-LSTM, B through LDS only): the workgroup covers 64 rows instead of 128 - wave w takes row block
+// w & 1 and the gate pair w >> 1 - for batches so small that the per-sample dependency chain, not the
+// throughput, bounds a rollout; same chunking and K order, i.e. the same bits.
+template <int G, int EPI, int MREP, class PT, bool HALF = false>
 __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int by, const int bz,
                                           float *smem) {
+    static_assert(!HALF || (G == 4 && EPI == EPI_LSTM && MREP == 1), "the 64-row tile is a conv-LSTM tile");
     constexpr int WROWS = MREP * 32;    // GEMM rows per wave
+    constexpr int GA = HALF ? 2 : G;    // gates (accumulator tiles) per wave
     // B through LDS pays for the long-K conv-LSTM tiles; the transposed convs (4 taps, 2-4 chunks)
     // lose more to its per-tap barrier than they gain, so they read B straight from L1/L2
     // (the 256-row conv-LSTM tile reads B directly as well: its input tile needs the LDS, and it must keep the
@@ -276,6 +350,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1 && !VF_LSTM_B_DIRECT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
+    const int wrow0 = HALF ? (wave & 1) * 32 : wave * WROWS;       // first GEMM row of this wave
+    const int gbase = HALF ? (wave >> 1) * 2 : 0;                   // first gate of this wave
     const int KC = p.KC, KCpad = KC + 4, K8 = KC >> 3;
     const int LH = (p.TH - 1) * p.stride + p.KH, LW = (p.TW - 1) * p.stride + p.KW;
     const int tile_px = LH * LW;
@@ -320,18 +396,18 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     int abase[MREP];
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
-        const int row = wave * WROWS + m * 32 + n;
+        const int row = wrow0 + m * 32 + n;
         const int img = row / p.RPI, rem = row % p.RPI;
         const bool ok = img < p.NI && rem < px_per_img;
         const int y = rem / p.TW, x = rem % p.TW;
         abase[m] = (ok ? (img * tile_px + y * p.stride * LW + x * p.stride) * KCpad : 0) + kh * 4;
     }
 
-    f32x16 acc[MREP][G];
+    f32x16 acc[MREP][GA];
 #pragma unroll
     for (int m = 0; m < MREP; ++m)
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+        for (int g = 0; g < GA; ++g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][g][r] = 0.f;
 
@@ -422,10 +498,10 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #pragma unroll
         for (int m = 0; m < MREP; ++m) ab4[m] = abase[m] >> 2;
         const int kcp4 = KCpad >> 2;
-        f32x4 aP[MREP], aQ[MREP], bP[G], bQ[G];
+        f32x4 aP[MREP], aQ[MREP], bP[GA], bQ[GA];
 #define VF_MFMA(A_, B_)                                                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
-            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                     \
+            _Pragma("unroll") for (int g = 0; g < GA; ++g) {                                    \
                 _Pragma("unroll") for (int m = 0; m < MREP; ++m)                                \
                     acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m][j], B_[g][j], acc[m][g], 0, 0, 0); \
             }                                                                                   \
@@ -437,8 +513,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
             {                                                                                   \
                 _Pragma("unroll") for (int m = 0; m < MREP; ++m)                                \
                     A_[m] = smem4[ab4[m] + ao + (Q_) * 2];                            \
-                _Pragma("unroll") for (int g = 0; g < G; ++g)                                   \
-                    B_[g] = bsm[((buf * K8 + (Q_)) * 4 + g) * 64 + lane];                       \
+                _Pragma("unroll") for (int g = 0; g < GA; ++g)                                  \
+                    B_[g] = bsm[((buf * K8 + (Q_)) * 4 + gbase + g) * 64 + lane];               \
             }
             for (int ky = 0; ky < p.KH; ++ky) {
                 for (int kx = 0; kx < p.KW; ++kx) {
@@ -493,7 +569,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #undef VF_WRITEB
 
     [[maybe_unused]] const unsigned long long ts2 = VF_TS_NOW();
-    conv_epilogue<G, EPI, MREP>(p, acc, bx, by, bz, red);
+    if constexpr (HALF) lstm_half_epilogue(p, acc, bx, by, red, smem);
+    else conv_epilogue<G, EPI, MREP>(p, acc, bx, by, bz, red);
 #ifdef VF_TILE_STATS
     if constexpr (EPI == EPI_LSTM) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -769,6 +846,11 @@ template <int G, int EPI, int MREP>
 VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_mfma_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     conv_tile<G, EPI, MREP>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_lstm_half_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_tile<4, EPI_LSTM, 1, ConvParams, true>(p, blockIdx.x, blockIdx.y, 0, smem);
 }
 
 template <int MREP>

@@ -136,7 +136,8 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
     int KH, KW, stride, pad;        // kernel geometry as the GEMM sees it
     int segC[2], nseg;
     int KC, nchunk[2];
-    int mrep;                       // MFMA row blocks per wave: the workgroup covers 128 * mrep rows
+    int mrep;                       // MFMA row blocks per wave: the workgroup covers 128 * mrep rows;
+                                    // 0 = the 64-row conv-LSTM tile (waves split rows x gate pairs)
     int prec = 0;                   // 1: split-bf16 tile (conv-LSTM only)
     size_t lds_dma = 0;             // conv-LSTM, fp32: LDS bytes of the DMA tile (0: tile not applicable)
     int NI, TH, TW, RPI, tilesY, tilesX;
@@ -159,13 +160,13 @@ static size_t conv_lds_bytes(const ConvLayer &l, int KC) {
     const int LH = (l.TH - 1) * l.stride + l.KH, LW = (l.TW - 1) * l.stride + l.KW;
     // A tile + LayerNorm table + reduction scratch (+ for 4-gate layers the double-buffered
     // per-tap B blocks: 2 x KC/8 x [4 gates][64 lanes] float4)
-    const size_t b_lds = (l.mode == PACK_LSTM && l.mrep == 1 && !VF_LSTM_B_DIRECT) ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
+    const size_t b_lds = (l.mode == PACK_LSTM && l.mrep <= 1 && !VF_LSTM_B_DIRECT) ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
     return ((size_t)l.NI * LH * LW * (KC + 4) + 4 * (size_t)l.NI) * 4 + 64 + b_lds;
 }
 
 // choose tile shape and chunk size for a layer whose GEMM row grid is Hout x Wout
 static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images) {
-    const int rows = 128 * l.mrep, wrows = 32 * l.mrep;
+    const int rows = l.mrep == 0 ? 64 : 128 * l.mrep, wrows = l.mrep == 0 ? 32 : 32 * l.mrep;
     if (one_pixel_images) {         // FC: every sample is a 1x1 image with many channels
         l.TH = l.TW = 1; l.tilesY = l.tilesX = 1; l.RPI = 1; l.NI = rows;
     } else {
@@ -201,7 +202,7 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
     l.stats_nparts = (l.NI == 1 ? l.tilesY * l.tilesX : 1) * l.ncg;
     // second-generation conv-LSTM tile (vf_conv_mfma.h, conv_lstm_dma_tile): same packing, needs 32-channel chunks
     l.lds_dma = 0;
-    if (l.mode == PACK_LSTM && l.prec == 0 && KC == 32 && l.mrep == 1 && l.stride == 1) {
+    if (l.mode == PACK_LSTM && l.prec == 0 && KC == 32 && l.mrep == 1 && l.stride == 1) {   // (128-row plan only)
         const int LH = l.TH - 1 + l.KH, LW = l.TW - 1 + l.KW;
         const size_t need = lstm_dma_lds_bytes(l.NI, LH, LW);
         if (need <= 79 * 1024 && l.NI * LH * LW <= 288) l.lds_dma = need;
@@ -362,8 +363,12 @@ struct vf_handle {
     // exact integers (vf_conv_mfma.h), so the choice is invisible in the results and may follow the batch size.
     ConvLayer lstm_big[7];
     bool have_big = false, big_ok[7] = {false};
+    // Third plan: 64 GEMM rows per workgroup (conv_tile<..., HALF>), for batches so small that a rollout is
+    // bound by the per-sample dependency chain: twice the items, each about half as long.
+    ConvLayer lstm_half[7];
+    bool half_ok[7] = {false};
     int st_rows[7] = {0};               // LayerNorm partial-sum slots per sample of lstm k (max over its plans)
-    int mrep_override[7] = {0};         // VF_DEBUG_KNOBS: 1 / 2 forces a plan, 0 = automatic
+    int mrep_override[7] = {0};         // VF_DEBUG_KNOBS: 1 / 2 / 3 (64 rows) forces a plan, 0 = automatic
     std::vector<ConvLayer *> layers;    // in slot order
     std::vector<ViewData> views;
 
@@ -538,6 +543,7 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_PARTIAL, 2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_bf16x6_kernel<1>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_dma_kernel<1>, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_half_kernel, n))) return rc;
     const size_t np = n + kCtlWords * sizeof(int);
     if ((rc = allow_lds(&rollout_persistent_kernel<1, 2>, np))) return rc;
     if ((rc = allow_lds(&rollout_persistent_kernel<2, 2>, np))) return rc;
@@ -555,6 +561,13 @@ static int launch_conv_m(const ConvLayer &l, const ConvParams &p, hipStream_t st
     const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
     dim3 grid(tiles, l.ncg, l.nsplit);
     hipLaunchKernelGGL((conv_mfma_kernel<G, EPI, MREP>), grid, dim3(kConvThreads), l.lds_bytes, st, p);
+    VF_HIP_CHECK(hipGetLastError());
+    return VF_OK;
+}
+
+static int launch_lstm_half(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
+    const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
+    hipLaunchKernelGGL(conv_lstm_half_kernel, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     VF_HIP_CHECK(hipGetLastError());
     return VF_OK;
 }
@@ -580,6 +593,7 @@ template <int G, int EPI>
 static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     if constexpr (EPI == EPI_LSTM) {
         if (l.prec == 1) return launch_lstm_bf16x6<1>(l, p, st);        // 128-row tiles only
+        if (l.mrep == 0) return launch_lstm_half(l, p, st);
         if (p.tile_variant == 2) return launch_lstm_dma(l, p, st);
         return l.mrep == 1 ? launch_conv_m<G, EPI, 1>(l, p, st) : launch_conv_m<G, EPI, 2>(l, p, st);
     } else if constexpr (EPI == EPI_PARTIAL) {
@@ -693,7 +707,8 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     const int lstm_mrep[7] = {1, 1, 1, 1, 1, 1, 1};
 #ifdef VF_DEBUG_KNOBS
     if (const char *e = getenv("VF_LSTM_MREP"))
-        for (int k = 0; k < 7 && e[k]; ++k) h->mrep_override[k] = e[k] == '2' ? 2 : (e[k] == '1' ? 1 : 0);
+        for (int k = 0; k < 7 && e[k]; ++k)         // per layer: h = 64 rows, 1 = 128, 2 = 256, anything else automatic
+            h->mrep_override[k] = e[k] == '2' ? 2 : (e[k] == '1' ? 1 : (e[k] == 'h' ? 3 : 0));
 #endif
     init_layer(h->enc0, "enc0", PACK_PLAIN, H, W, H2, W2, 5, 5, 2, 1, 3, 0, 32, true);
     init_layer(h->lstm[0], "lstm1", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, 32, L[0], L[0], true, false, lstm_mrep[0], cfg->precision);
@@ -731,6 +746,10 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         // same chunking = same K order per output (bit-identical results) and the same packed weights
         h->big_ok[k] = h->lstm_big[k].KC == sm.KC;
         if (h->big_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_big[k].stats_nparts);
+        init_layer(h->lstm_half[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[0],
+                   sm.segC[1], sm.Cout, true, false, 0, 0);
+        h->half_ok[k] = h->lstm_half[k].KC == sm.KC && !VF_LSTM_B_DIRECT;
+        if (h->half_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_half[k].stats_nparts);
     }
     h->max_lds = (size_t)composite_lds_floats<kMaxDesig, 10>() * 4;
     for (size_t i = 0; i < h->layers.size(); ++i) {
@@ -738,9 +757,10 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         h->max_lds = std::max(h->max_lds, std::max(h->layers[i]->lds_bytes, h->layers[i]->lds_dma));
     }
     for (int k = 0; k < 7; ++k)
-        if (h->have_big && h->big_ok[k]) {
-            h->lstm_big[k].id = h->lstm[k].id;          // shares the packed weights of the 128-row plan
-            h->max_lds = std::max(h->max_lds, h->lstm_big[k].lds_bytes);
+        if (h->have_big) {
+            h->lstm_big[k].id = h->lstm_half[k].id = h->lstm[k].id;     // the plans share the packed weights
+            if (h->big_ok[k]) h->max_lds = std::max(h->max_lds, h->lstm_big[k].lds_bytes);
+            if (h->half_ok[k]) h->max_lds = std::max(h->max_lds, h->lstm_half[k].lds_bytes);
         }
     h->max_lds += 16;
 
@@ -1169,10 +1189,18 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
     // tile plan of conv-LSTM k for a phase of Bp samples: the 256-row plan once the phase has many more items than
     // the chip has workgroup slots (everything from ~500 64x64-samples on; the two widest layers from ~150)
     auto lstm_plan = [&](int k, int Bp) -> const ConvLayer & {
-        if (!h->have_big || !h->big_ok[k]) return h->lstm[k];
-        if (h->mrep_override[k]) return h->mrep_override[k] == 2 ? h->lstm_big[k] : h->lstm[k];
+        if (!h->have_big) return h->lstm[k];
+        // 256 rows once the launch holds many more items than workgroup slots (everything from ~500
+        // 64x64-samples on, the two widest layers from ~150); 64 rows while a layer's phase would not even fill
+        // the slots once with 128-row items (measured: gpurun_out/r2_ab_half*.log)
         const double beff = (double)Bp * H * W / 4096.0;
-        return (beff >= 500.0 || (beff >= 150.0 && k < 2)) ? h->lstm_big[k] : h->lstm[k];
+        const ConvLayer &mid = h->lstm[k];
+        const long long n128 = (long long)(mid.NI == 1 ? Bp * mid.tilesY * mid.tilesX : (Bp + mid.NI - 1) / mid.NI) * mid.ncg;
+        int want = beff >= 500.0 || (beff >= 150.0 && k < 2) ? 2 : (n128 <= 2 * h->n_cu ? 3 : 1);
+        if (h->mrep_override[k]) want = h->mrep_override[k];
+        if (want == 2 && h->big_ok[k]) return h->lstm_big[k];
+        if (want == 3 && h->half_ok[k]) return h->lstm_half[k];
+        return h->lstm[k];
     };
     auto all_shared = [&](int s) { return h->dedup && s < nc - 1; };
     auto enc_shared = [&](int s) { return h->dedup && s < nc; };
