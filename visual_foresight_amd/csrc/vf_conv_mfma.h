@@ -260,16 +260,19 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
     }
 }
 
-// Epilogue of the 64-row conv-LSTM tile (conv_tile<4, EPI_LSTM, 1, PT, true>): wave w holds gates
-// {i, j} (w < 2) or {f, o} (w >= 2) of row block w & 1, so the pair product sigmoid(i) * tanh(j) crosses
-// through LDS (xch: [2 row blocks][16][64 lanes] floats, the idle input-tile area) and the waves
-// holding f and o finish the cell update.  Same expressions, hence the same bits, as conv_epilogue.
-template <class PT>
-__device__ __forceinline__ void lstm_half_epilogue(const PT &p, f32x16 (&acc)[1][2], const int bx, const int by,
-                                                   long long *red, float *xch) {
+// Epilogue of the row-split conv-LSTM tiles (conv_tile<4, EPI_LSTM, 1, PT, RB> with RB = 2 or 1 row blocks
+// per workgroup): wave w holds GA = RB gates (2: {i,j} or {f,o}; 1: a single gate) of row block w % RB, so
+// the gate pre-activations cross through LDS (xch: [RB][4 gates][16][64 lanes] floats, the idle weight
+// buffers) and every wave finishes 4 * RB of its row block's 16 accumulator rows with all four gates at hand.
+// Same expressions on the same values, hence the same bits, as conv_epilogue.
+template <int RB, class PT>
+__device__ __forceinline__ void lstm_split_epilogue(const PT &p, f32x16 (&acc)[1][RB], const int bx, const int by,
+                                                    long long *red, float *xch) {
+    constexpr int GA = RB;                  // gates per wave
+    constexpr int RSTEP = 4 * RB;           // accumulator rows finished per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
-    const int rb = wave & 1, gp = wave >> 1;
+    const int rb = wave % RB, gg = wave / RB;       // row block, gate group
     const int cg = by;
     const int tiles_per_img = p.tilesY * p.tilesX;
     const int px_per_img = p.TH * p.TW;
@@ -284,44 +287,45 @@ __device__ __forceinline__ void lstm_half_epilogue(const PT &p, f32x16 (&acc)[1]
         tile_id = 0; ty0 = 0; tx0 = 0;
     }
     const int ch = cg * 32 + n;
-    const float bias0 = p.bias[(cg * 4 + gp * 2) * 32 + n], bias1 = p.bias[(cg * 4 + gp * 2 + 1) * 32 + n];
-    __syncthreads();                        // the input tile is no longer read: its LDS becomes xch
-    if (gp == 0) {
+    __syncthreads();                        // the operand tiles are no longer read: their LDS becomes xch
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            xch[(rb * 16 + r) * 64 + lane] = sigmoidf_(acc[0][0][r] + bias0) * tanhf_(acc[0][1][r] + bias1);
+    for (int g = 0; g < GA; ++g) {
+        const int gate = gg * GA + g;
+        const float bias = p.bias[(cg * 4 + gate) * 32 + n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[((rb * 4 + gate) * 16 + r) * 64 + lane] = acc[0][g][r] + bias;
     }
     __syncthreads();
     long long ssum = 0, ssq = 0;
-    if (gp == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int img = row / p.RPI, rem = row % p.RPI;
-            const int y = ty0 + rem / p.TW, x = tx0 + rem % p.TW;
-            const int b = bimg0 + img;
-            const bool ok = img < p.NI && rem < px_per_img && b < p.B && y < p.Hout && x < p.Wout;
-            if (!ok) continue;
-            const long long o = (((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch;
-            const float gf = acc[0][0][r] + bias0, go = acc[0][1][r] + bias1;
-            const float c_old = p.cstate_in[(long long)b * p.cin_bstride + ((long long)y * p.Wout + x) * p.Cout + ch];
-            const float c_new = fmaf(c_old, sigmoidf_(gf + 1.0f), xch[(rb * 16 + r) * 64 + lane]);
-            const float h_new = tanhf_(c_new) * sigmoidf_(go);
-            p.cstate[o] = c_new;
-            p.out[o] = h_new;
-            ssum += stat_q(h_new); ssq += stat_q2(h_new);
-        }
+    for (int rr = 0; rr < RSTEP; ++rr) {
+        const int r = gg * RSTEP + rr;
+        const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int img = row / p.RPI, rem = row % p.RPI;
+        const int y = ty0 + rem / p.TW, x = tx0 + rem % p.TW;
+        const int b = bimg0 + img;
+        const bool ok = img < p.NI && rem < px_per_img && b < p.B && y < p.Hout && x < p.Wout;
+        if (!ok) continue;
+        const long long o = (((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch;
+        const float gi = xch[((rb * 4 + 0) * 16 + r) * 64 + lane], gj = xch[((rb * 4 + 1) * 16 + r) * 64 + lane];
+        const float gf = xch[((rb * 4 + 2) * 16 + r) * 64 + lane], go = xch[((rb * 4 + 3) * 16 + r) * 64 + lane];
+        const float c_old = p.cstate_in[(long long)b * p.cin_bstride + ((long long)y * p.Wout + x) * p.Cout + ch];
+        const float c_new = fmaf(c_old, sigmoidf_(gf + 1.0f), sigmoidf_(gi) * tanhf_(gj));
+        const float h_new = tanhf_(c_new) * sigmoidf_(go);
+        p.cstate[o] = c_new;
+        p.out[o] = h_new;
+        ssum += stat_q(h_new); ssq += stat_q2(h_new);
     }
     const long long wsum = wave_sum(ssum), wsq = wave_sum(ssq);
     if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
     __syncthreads();
     if (tid == 0) {
-        // row block rb (carried by wave 2 + rb) lies in image slot rb * 32 / RPI
+        // wave w carries part of row block w % RB, which lies in image slot (w % RB) * 32 / RPI
         for (int img = 0; img < p.NI; ++img) {
             if (bimg0 + img >= p.B) continue;
             long long su = 0, sq = 0;
-            for (int r2 = 0; r2 < 2; ++r2)
-                if ((r2 * 32) / p.RPI == img) { su += red[2 * (2 + r2)]; sq += red[2 * (2 + r2) + 1]; }
+            for (int w = 0; w < 4; ++w)
+                if (((w % RB) * 32) / p.RPI == img) { su += red[2 * w]; sq += red[2 * w + 1]; }
             long long *dst = p.stats + ((long long)(bimg0 + img) * p.stats_nparts +
                                         (p.NI == 1 ? tile_id * p.ncg + cg : cg)) * 2;
             dst[0] = su; dst[1] = sq;
@@ -334,15 +338,17 @@ __device__ __forceinline__ void lstm_half_epilogue(const PT &p, f32x16 (&acc)[1]
 // persistent rollout kernel (vf_persistent.h).
 // MREP = MFMA row blocks (of 32 GEMM rows) per wave: the workgroup covers 4 * MREP * 32 rows.
 // PT = ConvParams (kernel argument) or ConvParams in the constant address space (persistent kernel).
-// HALF (conv-LSTM, B through LDS only): the workgroup covers 64 rows instead of 128 - wave w takes row block
-// w & 1 and the gate pair w >> 1 - for batches so small that the per-sample dependency chain, not the
-// throughput, bounds a rollout; same chunking and K order, i.e. the same bits.
-template <int G, int EPI, int MREP, class PT, bool HALF = false>
+// RB < 4 (conv-LSTM, B through LDS only): the workgroup covers RB row blocks of 32 - 64 or 32 rows instead of
+// 128 - and wave w takes row block w % RB and RB of the four gates, for batches so small that the per-sample
+// dependency chain, not the throughput, bounds a rollout; same chunking and K order, i.e. the same bits.
+template <int G, int EPI, int MREP, class PT, int RB = 4>
 __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int by, const int bz,
                                           float *smem) {
-    static_assert(!HALF || (G == 4 && EPI == EPI_LSTM && MREP == 1), "the 64-row tile is a conv-LSTM tile");
+    constexpr bool SPLIT = RB < 4;
+    static_assert(!SPLIT || (G == 4 && EPI == EPI_LSTM && MREP == 1 && !VF_LSTM_B_DIRECT && (RB == 1 || RB == 2)),
+                  "the row-split tiles are conv-LSTM tiles");
     constexpr int WROWS = MREP * 32;    // GEMM rows per wave
-    constexpr int GA = HALF ? 2 : G;    // gates (accumulator tiles) per wave
+    constexpr int GA = SPLIT ? RB : G;  // gates (accumulator tiles) per wave
     // B through LDS pays for the long-K conv-LSTM tiles; the transposed convs (4 taps, 2-4 chunks)
     // lose more to its per-tap barrier than they gain, so they read B straight from L1/L2
     // (the 256-row conv-LSTM tile reads B directly as well: its input tile needs the LDS, and it must keep the
@@ -350,8 +356,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1 && !VF_LSTM_B_DIRECT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
-    const int wrow0 = HALF ? (wave & 1) * 32 : wave * WROWS;       // first GEMM row of this wave
-    const int gbase = HALF ? (wave >> 1) * 2 : 0;                   // first gate of this wave
+    const int wrow0 = SPLIT ? (wave % RB) * 32 : wave * WROWS;     // first GEMM row of this wave
+    const int gbase = SPLIT ? (wave / RB) * GA : 0;                 // first gate of this wave
     const int KC = p.KC, KCpad = KC + 4, K8 = KC >> 3;
     const int LH = (p.TH - 1) * p.stride + p.KH, LW = (p.TW - 1) * p.stride + p.KW;
     const int tile_px = LH * LW;
@@ -569,7 +575,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #undef VF_WRITEB
 
     [[maybe_unused]] const unsigned long long ts2 = VF_TS_NOW();
-    if constexpr (HALF) lstm_half_epilogue(p, acc, bx, by, red, smem);
+    // (xch = the double-buffered B area: 32 KiB at 32-channel chunks, disjoint from lnTab / red)
+    if constexpr (SPLIT) lstm_split_epilogue<RB>(p, acc, bx, by, red, reinterpret_cast<float *>(bsm));
     else conv_epilogue<G, EPI, MREP>(p, acc, bx, by, bz, red);
 #ifdef VF_TILE_STATS
     if constexpr (EPI == EPI_LSTM) {
@@ -848,9 +855,10 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_mfma_kernel(const ConvPara
     conv_tile<G, EPI, MREP>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
-VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_lstm_half_kernel(const ConvParams p) {
+template <int RB>
+VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_lstm_split_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    conv_tile<4, EPI_LSTM, 1, ConvParams, true>(p, blockIdx.x, blockIdx.y, 0, smem);
+    conv_tile<4, EPI_LSTM, 1, ConvParams, RB>(p, blockIdx.x, blockIdx.y, 0, smem);
 }
 
 template <int MREP>

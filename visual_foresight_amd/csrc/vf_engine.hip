@@ -137,7 +137,7 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
     int segC[2], nseg;
     int KC, nchunk[2];
     int mrep;                       // MFMA row blocks per wave: the workgroup covers 128 * mrep rows;
-                                    // 0 = the 64-row conv-LSTM tile (waves split rows x gate pairs)
+                                    // 0 / -1 = the 64- / 32-row conv-LSTM tiles (waves split rows x gates)
     int prec = 0;                   // 1: split-bf16 tile (conv-LSTM only)
     size_t lds_dma = 0;             // conv-LSTM, fp32: LDS bytes of the DMA tile (0: tile not applicable)
     int NI, TH, TW, RPI, tilesY, tilesX;
@@ -166,7 +166,7 @@ static size_t conv_lds_bytes(const ConvLayer &l, int KC) {
 
 // choose tile shape and chunk size for a layer whose GEMM row grid is Hout x Wout
 static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images) {
-    const int rows = l.mrep == 0 ? 64 : 128 * l.mrep, wrows = l.mrep == 0 ? 32 : 32 * l.mrep;
+    const int rows = l.mrep == 0 ? 64 : (l.mrep < 0 ? 32 : 128 * l.mrep), wrows = l.mrep <= 0 ? 32 : 32 * l.mrep;
     if (one_pixel_images) {         // FC: every sample is a 1x1 image with many channels
         l.TH = l.TW = 1; l.tilesY = l.tilesX = 1; l.RPI = 1; l.NI = rows;
     } else {
@@ -363,10 +363,10 @@ struct vf_handle {
     // exact integers (vf_conv_mfma.h), so the choice is invisible in the results and may follow the batch size.
     ConvLayer lstm_big[7];
     bool have_big = false, big_ok[7] = {false};
-    // Third plan: 64 GEMM rows per workgroup (conv_tile<..., HALF>), for batches so small that a rollout is
-    // bound by the per-sample dependency chain: twice the items, each about half as long.
-    ConvLayer lstm_half[7];
-    bool half_ok[7] = {false};
+    // Third and fourth plan: 64 and 32 GEMM rows per workgroup (conv_tile<..., RB = 2 / 1>), for batches so
+    // small that a rollout is bound by the per-sample dependency chain: more items, each shorter.
+    ConvLayer lstm_half[7], lstm_quarter[7];
+    bool half_ok[7] = {false}, quarter_ok[7] = {false};
     int st_rows[7] = {0};               // LayerNorm partial-sum slots per sample of lstm k (max over its plans)
     int mrep_override[7] = {0};         // VF_DEBUG_KNOBS: 1 / 2 / 3 (64 rows) forces a plan, 0 = automatic
     std::vector<ConvLayer *> layers;    // in slot order
@@ -543,7 +543,8 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_PARTIAL, 2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_bf16x6_kernel<1>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_dma_kernel<1>, n))) return rc;
-    if ((rc = allow_lds(&conv_lstm_half_kernel, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_split_kernel<2>, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_split_kernel<1>, n))) return rc;
     const size_t np = n + kCtlWords * sizeof(int);
     if ((rc = allow_lds(&rollout_persistent_kernel<1, 2>, np))) return rc;
     if ((rc = allow_lds(&rollout_persistent_kernel<2, 2>, np))) return rc;
@@ -565,9 +566,12 @@ static int launch_conv_m(const ConvLayer &l, const ConvParams &p, hipStream_t st
     return VF_OK;
 }
 
-static int launch_lstm_half(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
+static int launch_lstm_split(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
-    hipLaunchKernelGGL(conv_lstm_half_kernel, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
+    if (l.mrep == 0)
+        hipLaunchKernelGGL(conv_lstm_split_kernel<2>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
+    else
+        hipLaunchKernelGGL(conv_lstm_split_kernel<1>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     VF_HIP_CHECK(hipGetLastError());
     return VF_OK;
 }
@@ -593,7 +597,7 @@ template <int G, int EPI>
 static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     if constexpr (EPI == EPI_LSTM) {
         if (l.prec == 1) return launch_lstm_bf16x6<1>(l, p, st);        // 128-row tiles only
-        if (l.mrep == 0) return launch_lstm_half(l, p, st);
+        if (l.mrep <= 0) return launch_lstm_split(l, p, st);
         if (p.tile_variant == 2) return launch_lstm_dma(l, p, st);
         return l.mrep == 1 ? launch_conv_m<G, EPI, 1>(l, p, st) : launch_conv_m<G, EPI, 2>(l, p, st);
     } else if constexpr (EPI == EPI_PARTIAL) {
@@ -708,7 +712,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
 #ifdef VF_DEBUG_KNOBS
     if (const char *e = getenv("VF_LSTM_MREP"))
         for (int k = 0; k < 7 && e[k]; ++k)         // per layer: h = 64 rows, 1 = 128, 2 = 256, anything else automatic
-            h->mrep_override[k] = e[k] == '2' ? 2 : (e[k] == '1' ? 1 : (e[k] == 'h' ? 3 : 0));
+            h->mrep_override[k] = e[k] == '2' ? 2 : (e[k] == '1' ? 1 : (e[k] == 'h' ? 3 : (e[k] == 'q' ? 4 : 0)));
 #endif
     init_layer(h->enc0, "enc0", PACK_PLAIN, H, W, H2, W2, 5, 5, 2, 1, 3, 0, 32, true);
     init_layer(h->lstm[0], "lstm1", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, 32, L[0], L[0], true, false, lstm_mrep[0], cfg->precision);
@@ -748,8 +752,12 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         if (h->big_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_big[k].stats_nparts);
         init_layer(h->lstm_half[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[0],
                    sm.segC[1], sm.Cout, true, false, 0, 0);
-        h->half_ok[k] = h->lstm_half[k].KC == sm.KC && !VF_LSTM_B_DIRECT;
+        h->half_ok[k] = h->lstm_half[k].KC == sm.KC && sm.KC == 32 && !VF_LSTM_B_DIRECT;
         if (h->half_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_half[k].stats_nparts);
+        init_layer(h->lstm_quarter[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2,
+                   sm.segC[0], sm.segC[1], sm.Cout, true, false, -1, 0);
+        h->quarter_ok[k] = h->lstm_quarter[k].KC == sm.KC && sm.KC == 32 && !VF_LSTM_B_DIRECT;
+        if (h->quarter_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_quarter[k].stats_nparts);
     }
     h->max_lds = (size_t)composite_lds_floats<kMaxDesig, 10>() * 4;
     for (size_t i = 0; i < h->layers.size(); ++i) {
@@ -758,9 +766,10 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     }
     for (int k = 0; k < 7; ++k)
         if (h->have_big) {
-            h->lstm_big[k].id = h->lstm_half[k].id = h->lstm[k].id;     // the plans share the packed weights
+            h->lstm_big[k].id = h->lstm_half[k].id = h->lstm_quarter[k].id = h->lstm[k].id;    // shared packed weights
             if (h->big_ok[k]) h->max_lds = std::max(h->max_lds, h->lstm_big[k].lds_bytes);
             if (h->half_ok[k]) h->max_lds = std::max(h->max_lds, h->lstm_half[k].lds_bytes);
+            if (h->quarter_ok[k]) h->max_lds = std::max(h->max_lds, h->lstm_quarter[k].lds_bytes);
         }
     h->max_lds += 16;
 
@@ -1192,14 +1201,17 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         if (!h->have_big) return h->lstm[k];
         // 256 rows once the launch holds many more items than workgroup slots (everything from ~500
         // 64x64-samples on, the two widest layers from ~150); 64 rows while a layer's phase would not even fill
-        // the slots once with 128-row items (measured: gpurun_out/r2_ab_half*.log)
+        // the 2 x n_cu slots once with 128-row items, 32 rows below half of that (measured:
+        // profiles/r02_ab_experiments.log)
         const double beff = (double)Bp * H * W / 4096.0;
         const ConvLayer &mid = h->lstm[k];
         const long long n128 = (long long)(mid.NI == 1 ? Bp * mid.tilesY * mid.tilesX : (Bp + mid.NI - 1) / mid.NI) * mid.ncg;
-        int want = beff >= 500.0 || (beff >= 150.0 && k < 2) ? 2 : (n128 <= 2 * h->n_cu ? 3 : 1);
+        int want = beff >= 500.0 || (beff >= 150.0 && k < 2) ? 2
+                   : (n128 <= h->n_cu ? 4 : (n128 <= 2 * h->n_cu ? 3 : 1));
         if (h->mrep_override[k]) want = h->mrep_override[k];
         if (want == 2 && h->big_ok[k]) return h->lstm_big[k];
-        if (want == 3 && h->half_ok[k]) return h->lstm_half[k];
+        if (want == 4 && h->quarter_ok[k]) return h->lstm_quarter[k];
+        if (want >= 3 && h->half_ok[k]) return h->lstm_half[k];
         return h->lstm[k];
     };
     auto all_shared = [&](int s) { return h->dedup && s < nc - 1; };

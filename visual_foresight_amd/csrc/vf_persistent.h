@@ -45,7 +45,7 @@ struct PhaseDesc {
     int B;                  // samples this phase covers
     int NI, tiles_per_img;  // conv phases: how an item maps to samples
     int whole;              // 1: completion is counted once per item on counter 0
-    int mrep;               // MFMA row blocks per wave of this conv phase (1 or 2; 0: the 64-row conv-LSTM tile)
+    int mrep;               // MFMA row blocks per wave of this conv phase (1 or 2; 0 / -1: the 64- / 32-row conv-LSTM tiles)
     int prec;               // conv-LSTM tile: 0 fp32 (B through LDS), 1 split-bf16, 2 fp32 DMA tile
     int view;               // camera view this phase belongs to (selects the goal pixels of PH_COMPOSITE)
     int cnt_base;
@@ -121,8 +121,9 @@ template <int G, int EPI, int MREP>
 __device__ __noinline__ void conv_tile_call(const ConvParams *p, int bx, int by, int bz) {
     conv_tile<G, EPI, MREP>(const_params(p), bx, by, bz, tile_lds());
 }
-__device__ __noinline__ void lstm_half_tile_call(const ConvParams *p, int bx, int by) {
-    conv_tile<4, EPI_LSTM, 1, const VF_CONST_AS ConvParams, true>(const_params(p), bx, by, 0, tile_lds());
+template <int RB>
+__device__ __noinline__ void lstm_split_tile_call(const ConvParams *p, int bx, int by) {
+    conv_tile<4, EPI_LSTM, 1, const VF_CONST_AS ConvParams, RB>(const_params(p), bx, by, 0, tile_lds());
 }
 __device__ __noinline__ void lstm_dma_tile_call(const ConvParams *p, int bx, int by) {
     conv_lstm_dma_tile<1>(const_params(p), bx, by, tile_lds());
@@ -221,7 +222,9 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
                     if (P.prec == 1) {
                         lstm_bf16x6_tile_call<1>(&P.conv, bx, by);      // 128-row tiles only
                     } else if (P.mrep == 0) {
-                        lstm_half_tile_call(&P.conv, bx, by);
+                        lstm_split_tile_call<2>(&P.conv, bx, by);
+                    } else if (P.mrep < 0) {
+                        lstm_split_tile_call<1>(&P.conv, bx, by);
                     } else if (P.prec == 2) {
                         lstm_dma_tile_call(&P.conv, bx, by);
                     } else if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
