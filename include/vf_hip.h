@@ -182,6 +182,13 @@ int vf_set_substreams(vf_handle *h, int32_t n);
 int vf_set_persistent(vf_handle *h, int32_t enable);
 int vf_device_status(vf_handle *h, int32_t *status);
 
+/* XCD-aware ticket queues of the persistent rollout (default on; no reference counterpart).  The items
+ * of every phase are dealt to one queue per XCD so that an output-channel group's weight slice and a
+ * sample's neighbouring tiles are served from ONE XCD's L2; a workgroup draws from the queue of the XCD
+ * it runs on and steals from the others once its own is empty.  Placement only affects speed: results
+ * are bit-identical with one queue (enable = 0), which is the plain phase order. */
+int vf_set_xcd_queues(vf_handle *h, int32_t enable);
+
 /* conv-LSTM tile selection (no reference counterpart): 0 (default) = single input buffer, weights
  * staged through LDS, one barrier per tap; 2 = double-buffered LDS-DMA input staging
  * (global_load_lds_dwordx4) with the weight operand read straight from L2 and one barrier per

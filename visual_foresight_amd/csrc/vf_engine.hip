@@ -57,6 +57,7 @@ static int fail(int code, const std::string &msg) {
 static const int kLstmSizes[7] = {32, 32, 64, 64, 128, 64, 32};
 static const int kMaxSubBatches = 8;
 static const int kSchedRing = 4;            // pinned staging buffers for schedule uploads
+static const int kSyncHead = kQueues * kTicketStride;   // ints in front of the completion counters (ticket heads)
 
 // ------------------------------------------------------------------ canonical tensor table
 struct TensorDesc {
@@ -403,6 +404,7 @@ struct vf_handle {
         PhaseDesc *d_phases = nullptr;
         int B = -1, items = 0, counters = 0, phases = 0;
         bool dedup = true, lstm_dma = false;
+        int xcd_queues = 0, nq = 1, total_q[kQueues] = {0};
         double flops = 0.0;
         size_t lds = 0;
         std::vector<int> types, nitems;
@@ -413,7 +415,8 @@ struct vf_handle {
     hipEvent_t stage_done[kSchedRing] = {nullptr};
     bool stage_used[kSchedRing] = {false};
     int stage_next = 0;
-    int *d_sync = nullptr;              // [ticket, counters...]
+    int *d_sync = nullptr;              // [kQueues ticket heads, one cache line each | counters...]
+    int xcd_queues = kQueues;           // ticket queues of the persistent launch (vf_set_xcd_queues): kQueues or 1
     int *d_status = nullptr;            // sticky failure word of the persistent kernel
     unsigned long long *d_stats = nullptr;  // per-phase wait/run ticks (vf_set_phase_stats)
     bool phase_stats = false;
@@ -839,7 +842,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     h->counter_capacity = ((size_t)h->S * 20 + 8) * ((size_t)Bc + 1) * NV;
     VF_ALLOC(h->sched[0].d_phases, h->sched_capacity);
     VF_ALLOC(h->sched[1].d_phases, h->sched_capacity);
-    VF_ALLOC(h->d_sync, 1 + h->counter_capacity);
+    VF_ALLOC(h->d_sync, kSyncHead + h->counter_capacity);
     VF_ALLOC(h->d_status, 1);
     VF_ALLOC(h->d_zeros, 64);
     VF_ALLOC(h->d_stats, h->sched_capacity * 2);
@@ -865,7 +868,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     }
 #undef VF_ALLOC
 #ifndef VF_HOST_SELFTEST
-    if (hipMemset(h->d_sync, 0, sizeof(int)) != hipSuccess || hipMemset(h->d_status, 0, sizeof(int)) != hipSuccess ||
+    if (hipMemset(h->d_sync, 0, kSyncHead * sizeof(int)) != hipSuccess || hipMemset(h->d_status, 0, sizeof(int)) != hipSuccess ||
         hipMemset(h->d_zeros, 0, 64 * sizeof(float)) != hipSuccess) {
         vf_destroy(h);
         return fail(VF_ERR_HIP, "hipMemset of the scheduler words failed");
@@ -1382,6 +1385,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
 struct BuiltSchedule {
     std::vector<PhaseDesc> phases;
     int items = 0, counters = 0;
+    int nq = 1, total_q[kQueues] = {0};
     double flops = 0.0;
     size_t lds = 0;
 };
@@ -1409,6 +1413,31 @@ static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &
     int ticket = 0;
     for (PhaseDesc &P : out.phases) { P.first_ticket = ticket; ticket += P.n_items; }
     out.items = ticket;
+    // Deal every phase's items to the XCD queues (vf_persistent.h): item = (unit * q_inner + inner) * q_gy + cg
+    // goes to queue (unit % (nq / q_gy)) * q_gy + cg.  unit = sample (or sample group) of the item, inner = its
+    // tile within the sample, cg = output-channel group.  Launches too small to occupy every XCD keep one queue.
+    const int nq = (h->xcd_queues > 1 && ticket >= 4 * h->n_cu) ? kQueues : 1;
+    out.nq = nq;
+    for (int q = 0; q < kQueues; ++q) out.total_q[q] = 0;
+    for (PhaseDesc &P : out.phases) {
+        P.q_gy = 1; P.q_inner = 1;
+        if (nq > 1) {
+            if (P.type <= PH_CONVT_RAW) {
+                if (P.gy <= nq && nq % P.gy == 0) P.q_gy = P.gy;
+                if (P.NI == 1 && P.n_items == P.gx * P.gy) P.q_inner = P.tiles_per_img;
+                if (P.n_items % (P.q_gy * P.q_inner)) { P.q_gy = 1; P.q_inner = 1; }
+            } else if (P.type == PH_COMPOSITE) {
+                P.q_inner = P.gx;
+            }
+        }
+        const int units = P.n_items / (P.q_gy * P.q_inner), per = nq / P.q_gy;
+        for (int q = 0; q < kQueues; ++q) {
+            const int qb = q / P.q_gy;
+            P.first_q[q] = out.total_q[q < nq ? q : 0];
+            P.n_q[q] = (q < nq && qb < units) ? ((units - qb + per - 1) / per) * P.q_inner : 0;
+            if (q < nq) out.total_q[q] += P.n_q[q];
+        }
+    }
     out.counters = counters;
     out.lds = std::max(max_lds, (size_t)composite_lds_floats<kMaxDesig, 10>() * 4) + 16;
     if (out.phases.size() > h->sched_capacity || (size_t)counters > h->counter_capacity)
@@ -1481,6 +1510,35 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
         if (!ok) return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + " points outside the handle's buffers");
     }
     if (ticket != bs.items) return fail(VF_ERR_INVALID, "item count mismatch");
+    // the queue dealing must be a bijection: walking every queue position with the device's formula
+    // (rollout_persistent_kernel) visits each item of each phase exactly once, queues in phase order
+    {
+        int head[kQueues] = {0}, total = 0;
+        std::vector<char> seen;
+        for (size_t i = 0; i < bs.phases.size(); ++i) {
+            const PhaseDesc &P = bs.phases[i];
+            if (P.q_gy < 1 || P.q_inner < 1 || bs.nq % P.q_gy) return fail(VF_ERR_INVALID, "bad dealing rule");
+            seen.assign((size_t)P.n_items, 0);
+            for (int q = 0; q < bs.nq; ++q) {
+                if (P.first_q[q] != head[q]) return fail(VF_ERR_INVALID, "queue ranges are not contiguous");
+                for (int lq = 0; lq < P.n_q[q]; ++lq) {
+                    const int per = bs.nq / P.q_gy, qb = q / P.q_gy, cg = q - qb * P.q_gy;
+                    const int grp = lq / P.q_inner, inner = lq - grp * P.q_inner;
+                    const int local = ((grp * per + qb) * P.q_inner + inner) * P.q_gy + cg;
+                    if (local < 0 || local >= P.n_items || seen[(size_t)local])
+                        return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": dealing is not a bijection");
+                    seen[(size_t)local] = 1;
+                }
+                head[q] += P.n_q[q];
+                total += P.n_q[q];
+            }
+            for (int q = bs.nq; q < kQueues; ++q)
+                if (P.n_q[q]) return fail(VF_ERR_INVALID, "items in an unused queue");
+        }
+        for (int q = 0; q < kQueues; ++q)
+            if (head[q] != bs.total_q[q] && q < bs.nq) return fail(VF_ERR_INVALID, "queue totals mismatch");
+        if (total != bs.items) return fail(VF_ERR_INVALID, "dealt item count mismatch");
+    }
     if (out_items) *out_items = bs.items;
     if (out_upload_checksum) *out_upload_checksum = h->upload_checksum;
     return VF_OK;
@@ -1544,7 +1602,8 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     const int cfg = 1000;
     const bool skip_shared = shared_cache_hit(h, cfg);
     vf_handle::SchedCache &sc_host = h->sched[skip_shared ? 1 : 0];
-    if (sc_host.B != B || sc_host.dedup != h->dedup || sc_host.lstm_dma != h->lstm_dma) {
+    if (sc_host.B != B || sc_host.dedup != h->dedup || sc_host.lstm_dma != h->lstm_dma ||
+        sc_host.xcd_queues != h->xcd_queues) {
         BuiltSchedule bs;
         if ((rc = build_schedule(h, B, skip_shared, bs))) return rc;
         // Upload without synchronising the caller's stream: the copy is stream-ordered behind the
@@ -1560,7 +1619,10 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         VF_HIP_CHECK(hipEventRecord(h->stage_done[slot], st));
         h->stage_used[slot] = true;
         sc_host.B = B; sc_host.dedup = h->dedup; sc_host.lstm_dma = h->lstm_dma;
+        sc_host.xcd_queues = h->xcd_queues;
         sc_host.items = bs.items; sc_host.counters = bs.counters;
+        sc_host.nq = bs.nq;
+        for (int q = 0; q < kQueues; ++q) sc_host.total_q[q] = bs.total_q[q];
         sc_host.phases = (int)bs.phases.size();
         sc_host.types.clear(); sc_host.nitems.clear();
         for (const PhaseDesc &P : bs.phases) { sc_host.types.push_back(P.type); sc_host.nitems.push_back(P.n_items); }
@@ -1571,11 +1633,13 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     if (!skip_shared)
         for (int v = 0; v < h->ncam; ++v)
             if ((rc = zero_shared_state(h, h->shared_views[(size_t)v * kMaxSubBatches], st))) return rc;
-    VF_HIP_CHECK(hipMemsetAsync(h->d_sync, 0, (1 + (size_t)sc_host.counters) * sizeof(int), st));
+    VF_HIP_CHECK(hipMemsetAsync(h->d_sync, 0, (kSyncHead + (size_t)sc_host.counters) * sizeof(int), st));
     Schedule sc;
     memset(&sc, 0, sizeof(sc));
     sc.phases = sc_host.d_phases; sc.n_phases = sc_host.phases; sc.total_items = sc_host.items;
-    sc.ticket = h->d_sync; sc.counters = h->d_sync + 1; sc.status = h->d_status;
+    sc.ticket = h->d_sync; sc.counters = h->d_sync + kSyncHead; sc.status = h->d_status;
+    sc.nq = sc_host.nq;
+    for (int q = 0; q < kQueues; ++q) sc.total_q[q] = sc_host.total_q[q];
     sc.stats = nullptr;
     sc.nd = h->ND;
     for (int i = 0; i < h->ncam * h->ND * 2; ++i) sc.goal[i] = goal_pix[i];
@@ -1682,6 +1746,12 @@ int vf_set_persistent(vf_handle *h, int32_t enable) {
 #ifdef VF_DEBUG_KNOBS
     if (const char *e = getenv("VF_PERSIST_WGS_PER_CU")) h->persist_wgs_per_cu = std::max(1, std::min(4, atoi(e)));
 #endif
+    return VF_OK;
+}
+
+int vf_set_xcd_queues(vf_handle *h, int32_t enable) {
+    if (!h) return fail(VF_ERR_INVALID, "null handle");
+    h->xcd_queues = enable ? kQueues : 1;
     return VF_OK;
 }
 

@@ -29,6 +29,8 @@ enum PhaseType {
 };
 
 constexpr int kMaxDeps = 3;
+constexpr int kQueues = 8;                  // one ticket queue per XCD
+constexpr int kTicketStride = 32;           // ints between ticket heads (128 B)
 constexpr int kSaPerItem = 4;               // samples per PH_SA item (one per wave)
 constexpr unsigned kSpinLimit = 1u << 26;   // polls before a waiting item gives up (~ seconds)
 
@@ -40,7 +42,11 @@ struct PhaseDep {
 
 struct PhaseDesc {
     int type;
-    int first_ticket, n_items;
+    int first_ticket, n_items;          // position in the global phase order (bookkeeping, statistics)
+    int first_q[kQueues], n_q[kQueues]; // ticket range of this phase in each XCD's queue
+    int q_gy, q_inner;                  // dealing rule: item = (unit * q_inner + inner) * q_gy + cg  ->  queue
+                                        // (unit % (nq / q_gy)) * q_gy + cg, so a channel group's weight slice and a
+                                        // sample's tiles stay inside one XCD's L2
     int gx, gy;             // conv phases: items = gx * gy * gz, channel group (gy) fastest
     int B;                  // samples this phase covers
     int NI, tiles_per_img;  // conv phases: how an item maps to samples
@@ -64,7 +70,9 @@ struct Schedule {
     const PhaseDesc *phases;
     int n_phases;
     int total_items;
-    int *ticket;            // [1]
+    int *ticket;            // [kQueues][kTicketStride] ticket heads, one per XCD queue (own cache lines)
+    int total_q[kQueues];   // items per queue
+    int nq;                 // queues in use: kQueues, or 1 (plain phase order)
     int *counters;          // completion counters
     int *status;            // [1] sticky: set non-zero when an item gave up waiting; cleared by the host
                             //     only after it has been read (vf_device_status)
@@ -160,16 +168,48 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
     int ph = 0;
     if (tid < kMaxCam * kMaxDesig * 2) s_ctl[kCtlGoal + tid] = sched.goal[tid];    // visible after the first barrier
 
+    // XCD-aware ticketing.  A phase's items are dealt to sched.nq queues so that all items of one output-channel
+    // group and all tiles of one sample land in the same queue; a workgroup draws from the queue of the XCD it
+    // runs on, so the weight slice of that channel group (0.8 - 2.4 MB) and the halo rows shared by a sample's
+    // neighbouring tiles stay in that XCD's 4 MB L2 instead of every L2 streaming everything.  The XCD id only
+    // picks the queue (speed, never correctness): any workgroup may run any item, and a workgroup whose queue is
+    // exhausted steals from the others.  Every queue is in phase order, so the undone item of the lowest phase
+    // always has its producers done and sits at the head of its queue: deadlock-free as before.
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int nq = sched.nq;
+    const int q_own = (int)(xcc & (unsigned)(nq - 1));
+
     for (;;) {
         [[maybe_unused]] const unsigned long long ts_top = VF_TS_NOW();
         __syncthreads();                    // previous item fully retired (LDS reusable)
-        if (tid == 0) s_ctl[0] = atomicAdd(sched.ticket, 1);
+        if (tid == 0) {
+            int qq = q_own, t = 0, tries = 0;
+            for (; tries < nq; ++tries) {
+                t = atomicAdd(sched.ticket + qq * kTicketStride, 1);
+                if (t < sched.total_q[qq]) break;
+                qq = (qq + 1) & (nq - 1);
+            }
+            s_ctl[0] = tries < nq ? t : -1;
+            s_ctl[2] = qq;
+        }
         __syncthreads();
         const int t = s_ctl[0];
-        if (t >= sched.total_items) break;
-        while (t >= phases[ph].first_ticket + phases[ph].n_items) ++ph;
-        const PhaseDesc &P = phases[ph];
-        const int local = t - P.first_ticket;
+        if (t < 0) break;
+        const int qq = s_ctl[2];
+        if (qq != q_own) ph = 0;            // stolen ticket (tail of the launch): look its phase up from the start
+        while (t >= phases[ph].first_q[qq] + phases[ph].n_q[qq]) ++ph;
+        const int ph_run = ph;
+        const PhaseDesc &P = phases[ph_run];
+        if (qq != q_own) ph = 0;            // the cursor is only monotone within one queue
+        // queue position -> item of the phase
+        int local;
+        {
+            const int lq = t - P.first_q[qq];
+            const int per = nq / P.q_gy, qb = qq / P.q_gy, cg = qq - qb * P.q_gy;
+            const int grp = lq / P.q_inner, inner = lq - grp * P.q_inner;
+            local = ((grp * per + qb) * P.q_inner + inner) * P.q_gy + cg;
+        }
 
         int b0, b1;
         item_samples(P, local, b0, b1);
@@ -248,8 +288,8 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
         __syncthreads();
         if (sched.stats && tid == 0) {
             const unsigned long long t_end = wall_clock64();
-            atomicAdd(sched.stats + 2 * ph, t_run - t_start);
-            atomicAdd(sched.stats + 2 * ph + 1, t_end - t_run);
+            atomicAdd(sched.stats + 2 * ph_run, t_run - t_start);
+            atomicAdd(sched.stats + 2 * ph_run + 1, t_end - t_run);
         }
         if (wave == 0) {
             if (lane == 0) {

@@ -78,6 +78,7 @@ class HipVPredEvaluation(object):
         self.set_dedup(int(hp.get('dedup', os.environ.get('VF_DEDUP', 1))))
         self.set_persistent(int(hp.get('persistent', os.environ.get('VF_PERSISTENT', 1))))
         self.set_lstm_tile(int(hp.get('lstm_tile', os.environ.get('VF_LSTM_TILE', 0))))
+        self.set_xcd_queues(int(hp.get('xcd_queues', os.environ.get('VF_XCD_QUEUES', 1))))
         self.weights = None
         self._ctx_key = None
         self._last_M = 0
@@ -107,6 +108,11 @@ class HipVPredEvaluation(object):
         """Run each rollout as one persistent launch (bit-identical results; see vf_persistent.h)."""
         _lib.check(self._libh.vf_set_persistent(self._handle, int(bool(enable))))
         self.persistent = bool(enable)
+
+    def set_xcd_queues(self, enable):
+        """One ticket queue per XCD (default) or plain phase order; placement only, bit-identical results."""
+        _lib.check(self._libh.vf_set_xcd_queues(self._handle, int(bool(enable))))
+        self.xcd_queues = bool(enable)
 
     def set_lstm_tile(self, variant):
         """conv-LSTM tile: 0 = weights through LDS, barrier per tap (default); 2 = LDS-DMA double-buffered input
