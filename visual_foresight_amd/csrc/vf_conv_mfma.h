@@ -546,28 +546,58 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
         } else {
             // ---- K loop over (tap, k8), software pipelined: operands of step it+1 are fetched
             // (A: LDS b128, B: L1/L2 b128) before the MFMAs of step it are issued.
+            // Transposed convs: of the 16 (tap, output parity) blocks of the 2x2 view only 9 carry weights -
+            // input row tap 0 only reaches even output rows, column tap 0 only even output columns - so a step
+            // fetches and multiplies only its tap's live parities (LIVE_: bit g = parity g).  Skipped products are
+            // exact zeros: the sums are unchanged.
+            constexpr bool kConvT = (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS);
             const float *wchunk = wlane + (long long)ci * ntaps * K8 * wstep;
             const int nit = ntaps * K8;
             int ky = 0, kx = 0, k8 = 0;
-#define VF_FETCH(A_, B_, IT_)                                                                   \
+            [[maybe_unused]] int liveP = 15, liveQ = 15;
+#define VF_FETCH(A_, B_, LIVE_, IT_)                                                            \
             {                                                                                   \
                 const int ao_ = (ky * LW + kx) * kcp4 + k8 * 2;                                 \
                 _Pragma("unroll") for (int m = 0; m < MREP; ++m) A_[m] = smem4[ab4[m] + ao_]; \
                 const float *wp_ = wchunk + (long long)(IT_) * wstep;                             \
-                _Pragma("unroll") for (int g = 0; g < G; ++g)                                   \
-                    B_[g] = *reinterpret_cast<const f32x4 *>(wp_ + g * 128);                    \
+                if constexpr (kConvT) {                                                         \
+                    LIVE_ = (ky ? 15 : 3) & (kx ? 15 : 5);                                      \
+                    B_[0] = *reinterpret_cast<const f32x4 *>(wp_);                              \
+                    if (LIVE_ & 2) B_[1 % G] = *reinterpret_cast<const f32x4 *>(wp_ + 128);     \
+                    if (LIVE_ & 4) B_[2 % G] = *reinterpret_cast<const f32x4 *>(wp_ + 256);     \
+                    if (LIVE_ & 8) B_[3 % G] = *reinterpret_cast<const f32x4 *>(wp_ + 384);     \
+                } else {                                                                        \
+                    _Pragma("unroll") for (int g = 0; g < G; ++g)                               \
+                        B_[g] = *reinterpret_cast<const f32x4 *>(wp_ + g * 128);                \
+                }                                                                               \
                 if (++k8 == K8) { k8 = 0; if (++kx == p.KW) { kx = 0; ++ky; } }                 \
             }
-            VF_FETCH(aP, bP, 0)
+#define VF_MFMA_G(A_, B_, G_)                                                                   \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                     \
+                _Pragma("unroll") for (int m = 0; m < MREP; ++m)                                \
+                    acc[m][(G_) % G] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m][j], B_[(G_) % G][j], acc[m][(G_) % G], 0, 0, 0); \
+            }
+#define VF_MFMA_L(A_, B_, LIVE_)                                                                \
+            if constexpr (kConvT) {                                                             \
+                VF_MFMA_G(A_, B_, 0)                                                            \
+                if (LIVE_ & 2) { VF_MFMA_G(A_, B_, 1) }                                         \
+                if (LIVE_ & 4) { VF_MFMA_G(A_, B_, 2) }                                         \
+                if (LIVE_ & 8) { VF_MFMA_G(A_, B_, 3) }                                         \
+            } else {                                                                            \
+                VF_MFMA(A_, B_)                                                                 \
+            }
+            VF_FETCH(aP, bP, liveP, 0)
             int it = 0;
             for (; it + 2 <= nit; it += 2) {
-                VF_FETCH(aQ, bQ, it + 1)
-                VF_MFMA(aP, bP)
-                if (it + 2 < nit) VF_FETCH(aP, bP, it + 2)
-                VF_MFMA(aQ, bQ)
+                VF_FETCH(aQ, bQ, liveQ, it + 1)
+                VF_MFMA_L(aP, bP, liveP)
+                if (it + 2 < nit) VF_FETCH(aP, bP, liveP, it + 2)
+                VF_MFMA_L(aQ, bQ, liveQ)
             }
-            if (it < nit) VF_MFMA(aP, bP)
+            if (it < nit) { VF_MFMA_L(aP, bP, liveP) }
 #undef VF_FETCH
+#undef VF_MFMA_G
+#undef VF_MFMA_L
         }
 #undef VF_MFMA
     }
