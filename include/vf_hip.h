@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 3
+#define VF_ABI_VERSION 4
 
 typedef enum vf_status {
     VF_OK = 0,
@@ -78,6 +78,12 @@ typedef struct vf_config {
                                  * are averaged on the device (the reference's hook repeats each
                                  * action stochastic_planning[0] times,
                                  * samplers/gaussian_sampler.py:140-141) */
+    int32_t arch;               /* network: 0 = action-conditioned CDNA conv-LSTM (cdna_arch.py; height and
+                                 * width multiples of 8); 1 = SAVP-class stochastic generator (savp_arch.py:
+                                 * the same conv-LSTM core between one more encoder and decoder scale, the
+                                 * first context frame as an extra compositing layer, the per-step latent as
+                                 * extra action channels; multiples of 16).  The reference selects the class
+                                 * through conf['model'], vpred_model_interface.py:52-58 */
 } vf_config;
 
 typedef struct vf_handle vf_handle;

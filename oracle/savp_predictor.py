@@ -1,0 +1,126 @@
+"""ORACLE (test infrastructure): CPU restatement of the SAVP-class stochastic generator.
+
+PARITY UNPINNED.  ``SAVPVideoPredictionModel`` is only instantiated by the reference
+(``visual_mpc/video_prediction/vpred_model_interface.py:52-58``); its source lives in the
+un-vendored ``video_prediction`` package and the reference holds no golden vectors for it.  This file
+restates, in plain PyTorch CPU ops, the generator exactly as
+``visual_foresight_amd/video_prediction/savp_arch.py`` specifies it (the deterministic generator of
+arXiv:1804.01523 with per-step latent injection, four scales for 128x128 and the first-frame skip in
+the compositing; the departures from the published network are listed there), and is what the HIP
+kernels of ``vf_config.arch = 1`` are checked against.  The latent ``z_t`` arrives as extra action
+channels: ``actions[..., adim_env:]`` (``StochasticHipPredictor._prepare``), zeros at context steps.
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's cpu_baseline leg may import this.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle.cdna_predictor import OracleCdna, _same_pad
+
+LSTM_SIZES = (32, 32, 64, 64, 128, 64, 32)
+RELU_SHIFT = 1e-12
+DNA_KERN = 5
+
+
+class OracleSavp(OracleCdna):
+    def core_sizes(self):
+        H, W = self.cfg.height // 2, self.cfg.width // 2
+        return [(H // 2, W // 2)] * 2 + [(H // 4, W // 4)] * 2 + [(H // 8, W // 8)] + \
+               [(H // 4, W // 4)] + [(H // 2, W // 2)]
+
+    def step(self, frame, distrib, state_vec, action, lstm_states, first_frame=None, first_distrib=None):
+        """frame [B,3,H,W], distrib [B,nd,H,W], state_vec [B,sdim], action [B,adim+zdim];
+        first_frame / first_distrib: the first context frame / distribution, same shapes."""
+        L = LSTM_SIZES
+        B = frame.shape[0]
+        K = self.cfg.num_masks
+        new_states = [None] * 7
+
+        enc00 = F.relu(self._ln(self._conv(frame, 'enc00', 2), 'lna'))
+        enc0 = F.relu(self._ln(self._conv(enc00, 'enc0', 2), 'ln1'))
+        h1, new_states[0] = self._lstm(enc0, lstm_states[0], 'lstm1', L[0]); h1 = self._ln(h1, 'ln2')
+        h2, new_states[1] = self._lstm(h1, lstm_states[1], 'lstm2', L[1]);   h2 = self._ln(h2, 'ln3')
+        enc1 = F.relu(self._conv(h2, 'enc1', 2))
+        h3, new_states[2] = self._lstm(enc1, lstm_states[2], 'lstm3', L[2]); h3 = self._ln(h3, 'ln4')
+        h4, new_states[3] = self._lstm(h3, lstm_states[3], 'lstm4', L[3]);   h4 = self._ln(h4, 'ln5')
+        enc2 = F.relu(self._conv(h4, 'enc2', 2))
+
+        sa = torch.cat([action, state_vec], dim=1)          # action already carries the latent channels
+        smear = sa.view(B, -1, 1, 1).expand(B, sa.shape[1], enc2.shape[2], enc2.shape[3])
+        enc3 = F.relu(self._conv(torch.cat([enc2, smear], dim=1), 'enc3'))
+        h5, new_states[4] = self._lstm(enc3, lstm_states[4], 'lstm5', L[4]); h5 = self._ln(h5, 'ln6')
+        enc4 = F.relu(self._convt(h5, 'convt1'))
+        h6, new_states[5] = self._lstm(enc4, lstm_states[5], 'lstm6', L[5]); h6 = self._ln(h6, 'ln7')
+        enc5 = F.relu(self._convt(torch.cat([h6, enc1], dim=1), 'convt2'))
+        h7, new_states[6] = self._lstm(enc5, lstm_states[6], 'lstm7', L[6]); h7 = self._ln(h7, 'ln8')
+        enc6 = F.relu(self._ln(self._convt(torch.cat([h7, enc0], dim=1), 'convt3'), 'ln9'))
+        enc7 = F.relu(self._ln(self._convt(torch.cat([enc6, enc00], dim=1), 'convt4'), 'lnb'))
+
+        scratch = torch.sigmoid(self._conv(enc7, 'rgb'))
+        masks = torch.softmax(self._conv(enc7, 'masks'), dim=1)              # [B, K+1, H, W]
+
+        flat = h5.permute(0, 2, 3, 1).reshape(B, -1)
+        kern = flat @ self.p['cdna/w'] + self.p['cdna/b']
+        kern = F.relu(kern - RELU_SHIFT) + RELU_SHIFT
+        kern = kern.view(B, DNA_KERN * DNA_KERN, K)
+        kern = kern / kern.sum(dim=1, keepdim=True)
+        kern = kern.permute(0, 2, 1).reshape(B, K, DNA_KERN, DNA_KERN)
+
+        def warp(img):      # img [B, C, H, W] -> [B, K, C, H, W]; correlation, zero padded
+            Bc, C, H, W = img.shape
+            x = _same_pad(img, DNA_KERN, 1).reshape(1, Bc * C, H + 4, W + 4)
+            w = kern.repeat_interleave(C, dim=0).reshape(Bc * C * K, 1, DNA_KERN, DNA_KERN)
+            y = F.conv2d(x, w, groups=Bc * C)
+            return y.view(Bc, C, K, H, W).permute(0, 2, 1, 3, 4)
+
+        wf = warp(frame)
+        next_frame = masks[:, 0:1] * frame + masks[:, 1:2] * scratch + masks[:, 2:3] * first_frame
+        for k in range(K - 2):
+            next_frame = next_frame + masks[:, k + 3:k + 4] * wf[:, k]
+
+        wd = warp(distrib)
+        next_distrib = masks[:, 0:1] * distrib + masks[:, 2:3] * first_distrib
+        for k in range(K - 2):
+            next_distrib = next_distrib + masks[:, k + 3:k + 4] * wd[:, k]
+        next_distrib = next_distrib / next_distrib.sum(dim=(2, 3), keepdim=True)
+
+        next_state = sa @ self.p['state/w'] + self.p['state/b']
+        return next_frame, next_distrib, next_state, new_states
+
+    def rollout(self, ctx_frames_u8, ctx_actions, ctx_distrib, ctx_states, actions):
+        """Same calling convention as OracleCdna.rollout; ``actions`` / ``ctx_actions`` carry the
+        latent channels behind the environment's action channels."""
+        cfg, dt = self.cfg, self.dtype
+        nc = cfg.n_context
+        M, T = actions.shape[:2]
+        H, W = cfg.height, cfg.width
+        frames = np.asarray(ctx_frames_u8)[-nc:, 0].astype(np.float32) / 255.
+        frames = torch.from_numpy(frames).to(dt).permute(0, 3, 1, 2)
+        distr = torch.from_numpy(np.asarray(ctx_distrib, dtype=np.float32)[-nc:, 0]).to(dt).permute(0, 3, 1, 2)
+        states = torch.from_numpy(np.asarray(ctx_states, dtype=np.float64)[-nc:]).to(dt)
+        acts = torch.from_numpy(np.asarray(actions, dtype=np.float64)).to(dt)
+        if nc > 1:
+            ca = torch.from_numpy(np.asarray(ctx_actions, dtype=np.float64)[-(nc - 1):]).to(dt)
+            acts = torch.cat([ca[None].expand(M, nc - 1, cfg.adim), acts], dim=1)
+        lstm = [(torch.zeros(M, C, h, w, dtype=dt), torch.zeros(M, C, h, w, dtype=dt))
+                for C, (h, w) in zip(LSTM_SIZES, self.core_sizes())]
+        first_f = frames[0][None].expand(M, 3, H, W)
+        first_d = distr[0][None].expand(M, cfg.ndesig, H, W)
+
+        out_f, out_d, out_s = [], [], []
+        gen_f = gen_d = gen_s = None
+        for s in range(T + nc - 1):
+            if s < nc:
+                f_in = frames[s][None].expand(M, 3, H, W)
+                d_in = distr[s][None].expand(M, cfg.ndesig, H, W)
+                s_in = states[s][None].expand(M, cfg.sdim)
+            else:
+                f_in, d_in, s_in = gen_f, gen_d, gen_s
+            gen_f, gen_d, gen_s, lstm = self.step(f_in, d_in, s_in, acts[:, s], lstm, first_f, first_d)
+            if s >= nc - 1:
+                out_f.append(gen_f); out_d.append(gen_d); out_s.append(gen_s)
+        frames_out = torch.stack(out_f, 1).permute(0, 1, 3, 4, 2)[:, :, None]
+        distr_out = torch.stack(out_d, 1).permute(0, 1, 3, 4, 2)[:, :, None]
+        return (frames_out.contiguous().numpy(), distr_out.contiguous().numpy(),
+                torch.stack(out_s, 1).numpy())

@@ -236,15 +236,18 @@ def test_config4_shard_elites_match_oracle():
 
 # ---------------------------------------------------------------------------------------- config 5
 def test_config5_shard_latent_draws_128():
-    """One rank's share of configs[4] in one piece: 25 actions x 5 latent draws x horizon 15 x 128x128; the mean
-    over draws is taken on the device."""
+    """One rank's share of configs[4] in one piece: 25 actions x 5 latent draws x horizon 15 x 128x128 on the
+    SAVP-class generator (savp_arch.py); the mean over draws is taken on the device."""
+    from oracle.savp_predictor import OracleSavp
+    from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
     from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
     H = W = 128
     T, M, nl, zd = 15, 25, 5, 8
     hp = dict(designated_pixel_count=1, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,
               sequence_length=T + 2, n_latent=nl, zdim=zd, latent_seed=5)
     pred = StochasticHipPredictor('', hp)
-    cfg = CdnaConfig(height=H, width=W, adim=4 + zd, sdim=5, sequence_length=T + 2)
+    assert pred.arch == 'savp'
+    cfg = SavpConfig(height=H, width=W, adim=4 + zd, sdim=5, sequence_length=T + 2)
     weights = CdnaWeights.random(cfg, seed=2, bias_scale=0.05, ln_jitter=0.1)
     pred.restore(weights)
     rs = np.random.RandomState(3)
@@ -262,7 +265,9 @@ def test_config5_shard_latent_draws_128():
     idx = [0, 11, 24]
     ctx_o = dict(ctx, context_actions=np.concatenate([ctx['context_actions'], np.zeros((1, zd))], axis=1))
     aug = np.concatenate([np.repeat(actions[idx], nl, axis=0), np.tile(z, (len(idx), 1, 1))], axis=2)
-    _, d, _ = _oracle_rollout(weights, ctx_o, aug)
+    _, d, _ = OracleSavp(weights, torch.float32).rollout(
+        ctx_o['context_frames'], ctx_o['context_actions'], ctx_o['context_pixel_distributions'],
+        ctx_o['context_states'], aug)
     want, _ = pixel_cost.eval_pixel_cost(d, goal, 10.)
     np.testing.assert_allclose(scores[idx], want.reshape(len(idx), nl).mean(axis=1), rtol=1e-5)
     # the draws really differ (a mean over identical rollouts would hide a broken latent path)

@@ -410,15 +410,20 @@ def test_config2_planning_call_elites_match_oracle():
         np.testing.assert_array_equal(hip['actions'], ora['actions'])
 
 
-def test_stochastic_predictor_mean_over_latent_draws():
-    """BASELINE configs[4] in miniature: n_latent z-draws per action folded into the sample axis."""
+@pytest.mark.parametrize('arch', ['cdna', 'savp'])
+def test_stochastic_predictor_mean_over_latent_draws(arch):
+    """BASELINE configs[4] in miniature: n_latent z-draws per action folded into the sample axis, on the plain
+    CDNA network and on the SAVP-class generator (savp_arch.py)."""
+    from oracle.savp_predictor import OracleSavp
+    from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
     from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
     H = W = 32
     T, M, nl, zd = 2, 4, 3, 8
     hp = dict(designated_pixel_count=1, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,
-              sequence_length=T + 2, n_latent=nl, zdim=zd, latent_seed=5)
+              sequence_length=T + 2, n_latent=nl, zdim=zd, latent_seed=5, arch=arch)
     pred = StochasticHipPredictor('', hp)
-    cfg = CdnaConfig(height=H, width=W, adim=4 + zd, sdim=5, sequence_length=T + 2)
+    assert pred.arch == arch
+    cfg = (SavpConfig if arch == 'savp' else CdnaConfig)(height=H, width=W, adim=4 + zd, sdim=5, sequence_length=T + 2)
     weights = CdnaWeights.random(cfg, seed=2, bias_scale=0.05, ln_jitter=0.1)
     pred.restore(weights)
     rs = np.random.RandomState(3)
@@ -431,7 +436,9 @@ def test_stochastic_predictor_mean_over_latent_draws():
     # oracle: the same network with z appended to every action, mean over the draws
     ctx_o = dict(ctx, context_actions=np.concatenate([ctx['context_actions'], np.zeros((2, zd))], axis=1))
     aug = np.concatenate([np.repeat(actions, nl, axis=0), np.tile(z, (M, 1, 1))], axis=2)
-    _, d, _ = _oracle(weights, ctx_o, aug)
+    ora = (OracleSavp if arch == 'savp' else OracleCdna)(weights, torch.float32)
+    _, d, _ = ora.rollout(ctx_o['context_frames'], ctx_o['context_actions'], ctx_o['context_pixel_distributions'],
+                          ctx_o['context_states'], aug)
     want, _ = pixel_cost.eval_pixel_cost(d, goal, 10.)
     np.testing.assert_allclose(scores, want.reshape(M, nl).mean(axis=1), rtol=1e-5)
     assert pred.fetch_pixel_distributions(1).shape == (T, 1, H, W, 1)

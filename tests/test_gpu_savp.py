@@ -1,0 +1,105 @@
+"""GPU parity of the SAVP-class generator (vf_config.arch = 1, savp_arch.py) against its CPU oracle.
+
+Parity unpinned (the SAVP source is not part of the reference, oracle/savp_predictor.py); tolerances as
+in test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+from oracle import pixel_cost                                           # noqa: E402
+from oracle.savp_predictor import OracleSavp                            # noqa: E402
+from visual_foresight_amd.video_prediction.savp_arch import SavpConfig, CdnaWeights   # noqa: E402
+
+
+def _predictor(H, W, T, nd, bs, adim=6, seed=3, **extra):
+    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+    hp = dict(designated_pixel_count=nd, run_batch_size=bs, adim=adim, sdim=5, image_height=H, image_width=W,
+              sequence_length=T + 2, arch='savp', **extra)
+    pred = HipVPredEvaluation('', hp)
+    cfg = SavpConfig(height=H, width=W, adim=adim, ndesig=nd, sequence_length=T + 2)
+    weights = CdnaWeights.random(cfg, seed=seed, bias_scale=0.05, ln_jitter=0.1)
+    pred.restore(weights)
+    return pred, weights
+
+
+def _context(H, W, nd, adim, rs, hist=3):
+    desig = rs.randint(0, min(H, W), (1, nd, 2))
+    d = pixel_cost.one_hot_distrib(desig, 2, 1, H, W, nd)
+    d[1] = 0.5 * d[1] + 0.5 / (H * W)        # the two context distributions differ: the first-frame term is visible
+    return {'context_frames': rs.randint(0, 256, (hist, 1, H, W, 3)).astype(np.uint8),
+            'context_actions': rs.normal(0, 0.05, (hist - 1, adim)),
+            'context_states': rs.normal(0, 0.1, (hist, 5)),
+            'context_pixel_distributions': d}
+
+
+def _oracle(weights, ctx, actions, dtype=torch.float32):
+    return OracleSavp(weights, dtype).rollout(ctx['context_frames'], ctx['context_actions'],
+                                              ctx['context_pixel_distributions'], ctx['context_states'], actions)
+
+
+@pytest.mark.parametrize('H,W,T,M,nd', [(64, 64, 3, 5, 1), (48, 80, 2, 4, 2), (128, 128, 2, 3, 1), (32, 32, 3, 7, 4)])
+def test_savp_rollout_matches_oracle(H, W, T, M, nd):
+    adim = 6
+    pred, weights = _predictor(H, W, T, nd, bs=M, adim=adim)
+    rs = np.random.RandomState(H + W + T + M)
+    ctx = _context(H, W, nd, adim, rs)
+    actions = rs.normal(0, 0.1, (M, T, adim))
+    goal = rs.randint(-2, max(H, W) + 2, (1, nd, 2))
+    scores, per_task = pred.score(ctx, {'actions': actions}, goal, finalweight=10.)
+    got = pred(ctx, {'actions': actions})
+    f, d, s = _oracle(weights, ctx, actions)
+    assert np.abs(got['predicted_frames'] - f).max() <= 1e-5
+    dmax = d.max(axis=(3, 4), keepdims=True)
+    assert (np.abs(got['predicted_pixel_distributions'] - d) / dmax).max() <= 2e-5
+    assert np.abs(got['predicted_states'] - s).max() <= 1e-6
+    want, want_pt = pixel_cost.eval_pixel_cost(d, goal, 10.)
+    np.testing.assert_allclose(scores, want, rtol=1e-5)
+    np.testing.assert_allclose(per_task, want_pt, rtol=1e-5)
+    np.testing.assert_allclose(got['predicted_pixel_distributions'].sum(axis=(3, 4)), 1.0, atol=5e-6)
+    assert pred.device_status() == 0
+
+
+def test_savp_launch_strategies_and_chunking_are_bit_identical():
+    """Persistent launch == per-layer launches == ragged chunks == one XCD queue, bit for bit; context
+    de-duplication off gives the same bits too."""
+    H = W = 64
+    T, M = 3, 23
+    rs = np.random.RandomState(5)
+    ctx = _context(H, W, 1, 6, rs)
+    actions = rs.normal(0, 0.1, (M, T, 6))
+    goal = np.array([[[10, 50]]])
+    pred, weights = _predictor(H, W, T, 1, bs=M)
+    base, _ = pred.score(ctx, {'actions': actions}, goal)
+    base_out = pred(ctx, {'actions': actions})
+    for kw in (dict(persistent=0), dict(xcd_queues=0), dict(dedup=0), dict(run_batch_size=9)):
+        hp = dict(kw)
+        bs = hp.pop('run_batch_size', M)
+        other, _ = _predictor(H, W, T, 1, bs=bs, **hp)
+        got, _ = other.score(ctx, {'actions': actions}, goal)
+        np.testing.assert_array_equal(got, base, err_msg=str(kw))
+        out = other(ctx, {'actions': actions})
+        np.testing.assert_array_equal(out['predicted_frames'], base_out['predicted_frames'], err_msg=str(kw))
+    # permutation invariance and duplicates
+    perm = rs.permutation(M)
+    got, _ = pred.score(ctx, {'actions': actions[perm]}, goal)
+    np.testing.assert_array_equal(got, base[perm])
+
+
+def test_savp_split_bf16_mode_matches_oracle():
+    H = W = 64
+    T, M = 3, 6
+    rs = np.random.RandomState(9)
+    ctx = _context(H, W, 1, 6, rs)
+    actions = rs.normal(0, 0.1, (M, T, 6))
+    goal = np.array([[[40, 12]]])
+    pred, weights = _predictor(H, W, T, 1, bs=M, precision='bf16x6')
+    scores, _ = pred.score(ctx, {'actions': actions}, goal)
+    got = pred(ctx, {'actions': actions})
+    f, d, _ = _oracle(weights, ctx, actions)
+    assert np.abs(got['predicted_frames'] - f).max() <= 1e-5
+    want, _ = pixel_cost.eval_pixel_cost(d, goal, 10.)
+    np.testing.assert_allclose(scores, want, rtol=1e-5)

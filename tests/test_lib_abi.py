@@ -26,7 +26,7 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vf_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.vf_abi_version() == _lib.ABI_VERSION == 4
 
 
 @pytest.mark.parametrize('H,W,adim,sdim,nd', [(64, 64, 4, 5, 1), (48, 64, 3, 3, 2), (128, 128, 5, 5, 4)])
@@ -37,6 +37,36 @@ def test_weight_count_and_macs_agree_with_arch_table(lib, H, W, adim, sdim, nd):
     assert lib.vf_weight_count(ctypes.byref(c)) == n
     macs = sum(cdna_arch.macs_per_sample_step(cfg).values())
     assert lib.vf_macs_per_sample_step(ctypes.byref(c)) == pytest.approx(macs, rel=1e-12)
+
+
+@pytest.mark.parametrize('H,W,adim,sdim,nd', [(128, 128, 12, 5, 1), (48, 80, 6, 3, 2)])
+def test_savp_weight_count_and_macs_agree_with_arch_table(lib, H, W, adim, sdim, nd):
+    from visual_foresight_amd.video_prediction import savp_arch
+    cfg = savp_arch.SavpConfig(height=H, width=W, adim=adim, sdim=sdim, ndesig=nd)
+    c = _lib.VfConfig(H, W, adim, sdim, nd, 2, 15, 10, 8, 0, 0, 1, 1, cfg.arch_id)
+    assert cfg.arch_id == 1
+    n = sum(int(np.prod(s)) for s in cfg.tensor_shapes().values())
+    assert lib.vf_weight_count(ctypes.byref(c)) == n
+    assert lib.vf_macs_per_sample_step(ctypes.byref(c)) == pytest.approx(sum(cfg.macs_per_sample_step().values()), rel=1e-12)
+    # four scales: a 128x128 step costs about what a 64x64 step of the three-scale network costs
+    if H == 128:
+        assert sum(cfg.macs_per_sample_step().values()) < 1.1 * sum(cdna_arch.macs_per_sample_step(cdna_arch.CdnaConfig()).values())
+    bad = _lib.VfConfig(72, 64, adim, sdim, nd, 2, 15, 10, 8, 0, 0, 1, 1, 1)
+    assert lib.vf_weight_count(ctypes.byref(bad)) == 0 and b'multiples of 16' in lib.vf_last_error()
+
+
+def test_savp_weights_file_roundtrip(tmp_path):
+    from visual_foresight_amd.video_prediction import savp_arch
+    cfg = savp_arch.SavpConfig(height=32, width=32, adim=6)
+    w = cdna_arch.CdnaWeights.random(cfg, seed=5, bias_scale=0.1, ln_jitter=0.1)
+    assert w.tensors['lna/g'].std() > 0 and w.tensors['enc0/w'].shape == (5, 5, 16, 32)
+    w.save(str(tmp_path))
+    r = cdna_arch.CdnaWeights.load(str(tmp_path))
+    assert r.cfg.arch == 'savp' and list(r.tensors) == list(w.tensors)
+    for k in w.tensors:
+        np.testing.assert_array_equal(w.tensors[k], r.tensors[k])
+    with pytest.raises(ValueError):         # a CDNA engine must not swallow a SAVP checkpoint
+        cdna_arch.CdnaWeights.load(str(tmp_path), cdna_arch.CdnaConfig(height=32, width=32, adim=6))
 
 
 def test_survey_mac_count():

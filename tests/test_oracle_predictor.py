@@ -178,3 +178,121 @@ def test_rollout_context_semantics():
     assert a[0].shape == (3, 2, 1, 16, 16, 3) and a[1].shape == (3, 2, 1, 16, 16, 1) and a[2].shape == (3, 2, 5)
     np.testing.assert_allclose(a[1].sum(axis=(3, 4)), 1.0, atol=1e-12)
     assert a[0].min() >= 0 and a[0].max() <= 1
+
+
+# ---------------------------------------------------------------------------------------- SAVP-class generator
+def test_savp_step_wiring_and_compositing_rule():
+    """Pin oracle/savp_predictor.py's reading of savp_arch.py: the extra encoder / decoder scale around the core
+    (recomputed layer by layer from the oracle's own captured tensors with the naive loops above) and the
+    first-frame compositing rule."""
+    from oracle.savp_predictor import OracleSavp
+    from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
+    H = W = 32
+    cfg = SavpConfig(height=H, width=W, adim=6, ndesig=2, sequence_length=4)
+    w = CdnaWeights.random(cfg, seed=7, bias_scale=0.1, ln_jitter=0.2)
+    o = OracleSavp(w, torch.float64)
+    rs = np.random.RandomState(11)
+    B, K = 2, cfg.num_masks
+    frame = torch.from_numpy(rs.uniform(0, 1, (B, 3, H, W)))
+    first = torch.from_numpy(rs.uniform(0, 1, (B, 3, H, W)))
+    distrib = torch.from_numpy(rs.uniform(0, 1, (B, 2, H, W)))
+    distrib = distrib / distrib.sum(dim=(2, 3), keepdim=True)
+    dfirst = torch.from_numpy(rs.uniform(0, 1, (B, 2, H, W)))
+    dfirst = dfirst / dfirst.sum(dim=(2, 3), keepdim=True)
+    state, action = torch.from_numpy(rs.normal(size=(B, 5))), torch.from_numpy(rs.normal(size=(B, 6)))
+    lstm = [(torch.zeros(B, C, a, b, dtype=torch.float64),) * 2 for C, (a, b) in zip((32, 32, 64, 64, 128, 64, 32), o.core_sizes())]
+    assert o.core_sizes() == [(8, 8)] * 2 + [(4, 4)] * 2 + [(2, 2)] + [(4, 4)] + [(8, 8)]
+
+    cap = {}
+    orig_conv, orig_convt, orig_ln = o._conv, o._convt, o._ln
+
+    def spy_conv(x, name, stride=1):
+        y = orig_conv(x, name, stride)
+        cap[name] = (x, y)
+        return y
+
+    def spy_convt(x, name):
+        y = orig_convt(x, name)
+        cap[name] = (x, y)
+        return y
+
+    def spy_ln(x, name):
+        y = orig_ln(x, name)
+        cap[name] = (x, y)
+        return y
+    o._conv, o._convt, o._ln = spy_conv, spy_convt, spy_ln
+    nf, nd_, ns, _ = o.step(frame, distrib, state, action, lstm, first, dfirst)
+
+    T64 = lambda name: w.tensors[name].astype(np.float64)
+    relu = lambda v: np.maximum(v, 0)
+    # extra encoder scale: enc00 = relu(LNa(conv5x5/2(frame))) feeds enc0 = relu(LN1(conv5x5/2(enc00)))
+    x00 = naive_conv_same(_nhwc(frame), T64('enc00/w'), T64('enc00/b'), 2)
+    assert x00.shape == (B, H // 2, W // 2, 16)
+    np.testing.assert_allclose(_nhwc(cap['enc00'][1]), x00, atol=1e-12)
+    enc00 = relu(_nhwc(cap['lna'][1]))
+    np.testing.assert_allclose(_nhwc(cap['enc0'][0]), enc00, atol=1e-12)
+    np.testing.assert_allclose(_nhwc(cap['enc0'][1]), naive_conv_same(enc00, T64('enc0/w'), T64('enc0/b'), 2), atol=1e-11)
+    # extra decoder scale: enc7 = relu(LNb(convT(concat[enc6, enc00]))) with enc6 = relu(LN9(convT3(...)))
+    enc6 = relu(_nhwc(cap['ln9'][1]))
+    np.testing.assert_allclose(_nhwc(cap['convt4'][0]), np.concatenate([enc6, enc00], -1), atol=1e-12)
+    assert cap['convt4'][1].shape == (B, 32, H, W) and cap['convt3'][1].shape == (B, 32, H // 2, W // 2)
+    np.testing.assert_allclose(_nhwc(cap['rgb'][0]), relu(_nhwc(cap['lnb'][1])), atol=1e-12)
+    # the conditioning vector [action (+ latent), state] is tiled into enc3's input
+    np.testing.assert_allclose(_nhwc(cap['enc3'][0])[:, 1, 0, 64:], np.concatenate([action.numpy(), state.numpy()], 1), atol=0)
+
+    masks = torch.softmax(cap['masks'][1], dim=1).numpy()
+    scratch = torch.sigmoid(cap['rgb'][1]).numpy()
+    flat = cap['ln6'][1].permute(0, 2, 3, 1).reshape(B, -1).numpy()
+    kern = flat @ T64('cdna/w') + T64('cdna/b')
+    kern = np.maximum(kern - 1e-12, 0) + 1e-12
+    kern = kern.reshape(B, 25, K)
+    kern = kern / kern.sum(1, keepdims=True)
+
+    def warp(img, k):
+        pad = np.pad(img, ((0, 0), (0, 0), (2, 2), (2, 2)))
+        out = np.zeros_like(img)
+        for dy in range(5):
+            for dx in range(5):
+                out += pad[:, :, dy:dy + H, dx:dx + W] * kern[:, dy * 5 + dx, k][:, None, None, None]
+        return out
+
+    f, d = frame.numpy(), distrib.numpy()
+    want_f = masks[:, 0:1] * f + masks[:, 1:2] * scratch + masks[:, 2:3] * first.numpy()
+    want_d = masks[:, 0:1] * d + masks[:, 2:3] * dfirst.numpy()
+    for k in range(K - 2):
+        want_f += masks[:, k + 3:k + 4] * warp(f, k)
+        want_d += masks[:, k + 3:k + 4] * warp(d, k)
+    want_d /= want_d.sum(axis=(2, 3), keepdims=True)
+    np.testing.assert_allclose(nf.numpy(), want_f, atol=1e-12)
+    np.testing.assert_allclose(nd_.numpy(), want_d, atol=1e-12)
+
+
+def test_savp_rollout_uses_first_context_frame():
+    """The compositing's first-frame layer is context frame 0 of the last n_context frames, for every step."""
+    from oracle.savp_predictor import OracleSavp
+    from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
+    cfg = SavpConfig(height=32, width=32, adim=6, sequence_length=4)
+    w = CdnaWeights.random(cfg, seed=3, bias_scale=0.1, ln_jitter=0.2)
+    o = OracleSavp(w, torch.float64)
+    rs = np.random.RandomState(2)
+    frames = rs.randint(0, 256, (4, 1, 32, 32, 3)).astype(np.uint8)
+    d = np.zeros((2, 1, 32, 32, 1), np.float32)
+    d[0, 0, 3, 4, 0] = 1
+    d[1, 0, 20, 9, 0] = 1
+    args = (rs.normal(size=(3, 6)), d, rs.normal(size=(4, 5)), rs.normal(0, 0.1, (2, 2, 6)))
+    a = o.rollout(frames, *args)
+    b = o.rollout(frames[-2:], args[0][-1:], args[1], args[2][-2:], args[3])
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    seen = []
+    orig = o.step
+
+    def spy(*s_args):
+        seen.append((s_args[5], s_args[6]))
+        return orig(*s_args)
+    o.step = spy
+    o.rollout(frames, *args)
+    want_f = torch.from_numpy(frames[-2, 0].astype(np.float32) / 255.).to(torch.float64).permute(2, 0, 1)
+    for ff, dd in seen:
+        assert torch.equal(ff[1], want_f) and float(dd[0, 0, 3, 4]) == 1.0
+    np.testing.assert_allclose(a[1].sum(axis=(3, 4)), 1.0, atol=1e-12)

@@ -23,7 +23,7 @@ EXPORTS = ('vf_abi_version', 'vf_last_error', 'vf_weight_count', 'vf_create', 'v
            'vf_allgather_scores', 'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile',
            'vf_set_substreams', 'vf_set_dedup', 'vf_set_persistent', 'vf_set_xcd_queues', 'vf_set_lstm_tile', 'vf_device_status',
            'vf_set_phase_stats', 'vf_debug_phase_stats', 'vf_debug_poison_status')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class VfError(RuntimeError):
@@ -33,7 +33,7 @@ class VfError(RuntimeError):
 class VfConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ('height', 'width', 'adim', 'sdim', 'ndesig', 'n_context', 'sequence_length',
-                 'num_masks', 'max_batch', 'device', 'precision', 'ncam', 'n_draws')]
+                 'num_masks', 'max_batch', 'device', 'precision', 'ncam', 'n_draws', 'arch')]
 
 
 def _hipcc():

@@ -55,6 +55,8 @@ static int fail(int code, const std::string &msg) {
     } while (0)
 
 static const int kLstmSizes[7] = {32, 32, 64, 64, 128, 64, 32};
+static const int kEnc00Ch = 16;             // channels of the extra encoder scale of arch 1 (savp_arch.py)
+static const int kNumLn = 11;               // ln1..ln9, lna, lnb
 static const int kMaxSubBatches = 8;
 static const int kSchedRing = 4;            // pinned staging buffers for schedule uploads
 static const int kSyncHead = kQueues * kTicketStride;   // ints in front of the completion counters (ticket heads)
@@ -94,8 +96,12 @@ static std::vector<TensorDesc> tensor_table(const vf_config &c) {
     };
     const int *L = kLstmSizes;
     const int a = c.adim + c.sdim, K = c.num_masks;
-    const int fc_in = (c.height / 8) * (c.width / 8) * L[4];
-    conv("enc0", 5, 5, 3, 32);                 ln("ln1", 32);
+    // arch 1 (savp_arch.py): one more encoder / decoder scale around the three-scale core
+    const bool savp = c.arch == 1;
+    const int Hc = savp ? c.height / 2 : c.height, Wc = savp ? c.width / 2 : c.width;
+    const int fc_in = (Hc / 8) * (Wc / 8) * L[4];
+    if (savp) { conv("enc00", 5, 5, 3, kEnc00Ch); ln("lna", kEnc00Ch); }
+    conv("enc0", 5, 5, savp ? kEnc00Ch : 3, 32); ln("ln1", 32);
     conv("lstm1", 5, 5, 32 + L[0], 4 * L[0]);  ln("ln2", L[0]);
     conv("lstm2", 5, 5, L[0] + L[1], 4 * L[1]); ln("ln3", L[1]);
     conv("enc1", 3, 3, L[1], L[1]);
@@ -109,6 +115,7 @@ static std::vector<TensorDesc> tensor_table(const vf_config &c) {
     conv("convt2", 3, 3, L[5] + L[1], L[5]);
     conv("lstm7", 5, 5, L[5] + L[6], 4 * L[6]); ln("ln8", L[6]);
     conv("convt3", 3, 3, L[6] + 32, 32);        ln("ln9", 32);
+    if (savp) { conv("convt4", 3, 3, 32 + kEnc00Ch, 32); ln("lnb", 32); }
     conv("rgb", 1, 1, 32, 3);
     conv("masks", 1, 1, 32, K + 1);
     add("cdna/w", {fc_in, kTaps * K});
@@ -118,6 +125,9 @@ static std::vector<TensorDesc> tensor_table(const vf_config &c) {
     return t;
 }
 
+// LayerNorm parameter slot i of ViewData: ln1..ln9, then lna (enc00) and lnb (convt4) of arch 1
+static std::string ln_name(int i) { return i < 9 ? "ln" + std::to_string(i + 1) : (i == 9 ? "lna" : "lnb"); }
+
 static const TensorDesc *find_tensor(const std::vector<TensorDesc> &t, const std::string &name) {
     for (const auto &d : t)
         if (d.name == name) return &d;
@@ -126,7 +136,7 @@ static const TensorDesc *find_tensor(const std::vector<TensorDesc> &t, const std
 
 // ------------------------------------------------------------------ one dense layer
 enum PackMode { PACK_PLAIN, PACK_LSTM, PACK_CONVT };
-static const int kNumConvLayers = 15;
+static const int kNumConvLayers = 17;
 
 struct ConvLayer {          // geometry only: shared by every view; the packed weights are per view
     std::string name;
@@ -323,8 +333,9 @@ using namespace vf;
 // identical for every sample (see emit_rollout).
 struct BatchView {
     float *enc0_o, *enc1_o, *enc2_o, *enc3_o, *enc4_o, *enc5_o, *enc6_o;
+    float *enc00_o, *enc7_o;            // arch 1: extra encoder / decoder scale
     float *c_state[7], *h_state[7][2];
-    long long *st_enc0, *st_h[7], *st_enc6;
+    long long *st_enc0, *st_h[7], *st_enc6, *st_enc00, *st_enc7;
     float *sbias, *fc_part, *kern;
     float *frames_all, *distrib_all, *states_all;
     double *sums;
@@ -336,7 +347,7 @@ struct BatchView {
 struct LayerW { float *w = nullptr, *b = nullptr; unsigned short *w16 = nullptr; };
 struct ViewData {
     LayerW lw[kNumConvLayers];
-    float *ln_g[9] = {nullptr}, *ln_b[9] = {nullptr};
+    float *ln_g[kNumLn] = {nullptr}, *ln_b[kNumLn] = {nullptr};    // ln1..ln9, lna (enc00), lnb (convt4)
     float *w_rgb = nullptr, *b_rgb = nullptr, *w_mask = nullptr, *b_mask = nullptr;
     float *w_state = nullptr, *b_state = nullptr, *w_sa = nullptr, *b_fc = nullptr;
     float *ctx_frames = nullptr, *ctx_distrib = nullptr;
@@ -348,6 +359,8 @@ struct AllocRec { void *p; size_t bytes; };
 struct vf_handle {
     vf_config cfg;
     int H, W, T, S, ND, K;              // S = steps per rollout = T + n_context - 1
+    bool savp = false;                  // vf_config.arch == 1: four-scale SAVP-class generator (savp_arch.py)
+    int Hc, Wc;                         // input size of the three-scale conv-LSTM core (H, W; arch 1: H/2, W/2)
     int ncam = 1, n_draws = 1;
     int ntiles;                         // composite tiles per image
     std::vector<TensorDesc> table;
@@ -357,6 +370,7 @@ struct vf_handle {
 
     // layers (geometry)
     ConvLayer enc0, lstm[7], enc1, enc2, enc3, convt1, convt2, convt3, fc;
+    ConvLayer enc00, convt4;            // arch 1 only
     // Second tile plan of every conv-LSTM (256 GEMM rows per workgroup, weights read straight from L2 so that
     // the larger input tile fits the LDS with the SAME 32-channel chunks): fewer, longer items - better per
     // FLOP once a phase has far more items than workgroup slots, worse for the per-sample dependency chain of
@@ -380,9 +394,9 @@ struct vf_handle {
 
     // activations, [ncam][max_batch] samples each
     float *enc0_o = nullptr, *enc1_o = nullptr, *enc2_o = nullptr, *enc3_o = nullptr;
-    float *enc4_o = nullptr, *enc5_o = nullptr, *enc6_o = nullptr;
+    float *enc4_o = nullptr, *enc5_o = nullptr, *enc6_o = nullptr, *enc00_o = nullptr, *enc7_o = nullptr;
     float *c_state[7] = {nullptr}, *h_state[7][2] = {{nullptr}};
-    long long *st_enc0 = nullptr, *st_h[7] = {nullptr}, *st_enc6 = nullptr;
+    long long *st_enc0 = nullptr, *st_h[7] = {nullptr}, *st_enc6 = nullptr, *st_enc00 = nullptr, *st_enc7 = nullptr;
     float *sbias = nullptr, *fc_part = nullptr, *kern = nullptr;
 
     // predictions of the last rollout
@@ -504,6 +518,9 @@ static int validate(const vf_config *c) {
     if (c->n_draws < 0) return fail(VF_ERR_INVALID, "n_draws must be >= 1 (0 = 1)");
     if (c->n_draws > 1 && c->max_batch % c->n_draws)
         return fail(VF_ERR_INVALID, "max_batch must be a multiple of n_draws");
+    if (c->arch != 0 && c->arch != 1) return fail(VF_ERR_INVALID, "arch must be 0 (CDNA) or 1 (SAVP-class, four scales)");
+    if (c->arch == 1 && (c->height % 16 || c->width % 16))
+        return fail(VF_ERR_INVALID, "arch 1 needs height/width that are multiples of 16");
     return VF_OK;
 }
 
@@ -661,21 +678,25 @@ size_t vf_weight_count(const vf_config *cfg) {
 
 double vf_macs_per_sample_step(const vf_config *cfg) {
     if (validate(cfg)) return 0.0;
-    const int H = cfg->height, W = cfg->width;
+    const bool savp = cfg->arch == 1;
+    const int HF = cfg->height, WF = cfg->width;            // full resolution: heads and warps
+    const int H = savp ? HF / 2 : HF, W = savp ? WF / 2 : WF;   // core
     auto t = tensor_table(*cfg);
     struct { const char *n; int h, w; } res[] = {
         {"enc0", H / 2, W / 2}, {"lstm1", H / 2, W / 2}, {"lstm2", H / 2, W / 2}, {"enc1", H / 4, W / 4},
         {"lstm3", H / 4, W / 4}, {"lstm4", H / 4, W / 4}, {"enc2", H / 8, W / 8}, {"enc3", H / 8, W / 8},
         {"lstm5", H / 8, W / 8}, {"convt1", H / 8, W / 8}, {"lstm6", H / 4, W / 4}, {"convt2", H / 4, W / 4},
-        {"lstm7", H / 2, W / 2}, {"convt3", H / 2, W / 2}, {"rgb", H, W}, {"masks", H, W}};
+        {"lstm7", H / 2, W / 2}, {"convt3", H / 2, W / 2}, {"rgb", HF, WF}, {"masks", HF, WF},
+        {"enc00", HF / 2, WF / 2}, {"convt4", HF / 2, WF / 2}};
     double macs = 0;
     for (auto &r : res) {
         const TensorDesc *d = find_tensor(t, std::string(r.n) + "/w");
+        if (!d) continue;               // arch 0 has no enc00 / convt4
         macs += (double)r.h * r.w * d->shape[0] * d->shape[1] * d->shape[2] * d->shape[3];
     }
     const TensorDesc *fc = find_tensor(t, "cdna/w"), *sw = find_tensor(t, "state/w");
     macs += (double)fc->shape[0] * fc->shape[1] + (double)sw->shape[0] * sw->shape[1];
-    macs += (double)H * W * kTaps * (3 + cfg->ndesig) * cfg->num_masks;
+    macs += (double)HF * WF * kTaps * (3 + cfg->ndesig) * cfg->num_masks;
     return macs;
 }
 
@@ -697,9 +718,12 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     h->S = h->T + cfg->n_context - 1;
     h->table = tensor_table(*cfg);
     h->blob_floats = h->table.back().offset + h->table.back().size();
+    h->savp = cfg->arch == 1;
+    h->Hc = h->savp ? h->H / 2 : h->H; h->Wc = h->savp ? h->W / 2 : h->W;
     const int H = h->H, W = h->W, Bc = cfg->max_batch, ND = h->ND, NV = h->ncam;
     const size_t BV = (size_t)Bc * NV;          // samples x views: rows of every per-sample buffer
-    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+    const int Hc = h->Hc, Wc = h->Wc;           // the three-scale core works on Hc x Wc
+    const int H2 = Hc / 2, W2 = Wc / 2, H4 = Hc / 4, W4 = Wc / 4, H8 = Hc / 8, W8 = Wc / 8;
     const int *L = kLstmSizes;
     h->ntiles = ((H + kCompTile - 1) / kCompTile) * ((W + kCompTile - 1) / kCompTile);
 #ifdef VF_HOST_SELFTEST
@@ -717,7 +741,11 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         for (int k = 0; k < 7 && e[k]; ++k)         // per layer: h = 64 rows, 1 = 128, 2 = 256, anything else automatic
             h->mrep_override[k] = e[k] == '2' ? 2 : (e[k] == '1' ? 1 : (e[k] == 'h' ? 3 : (e[k] == 'q' ? 4 : 0)));
 #endif
-    init_layer(h->enc0, "enc0", PACK_PLAIN, H, W, H2, W2, 5, 5, 2, 1, 3, 0, 32, true);
+    if (h->savp) {
+        init_layer(h->enc00, "enc00", PACK_PLAIN, H, W, Hc, Wc, 5, 5, 2, 1, 3, 0, kEnc00Ch, true);
+        init_layer(h->convt4, "convt4", PACK_CONVT, Hc, Wc, Hc, Wc, 2, 2, 1, 1, 32, kEnc00Ch, 32, true);
+    }
+    init_layer(h->enc0, "enc0", PACK_PLAIN, Hc, Wc, H2, W2, 5, 5, 2, 1, h->savp ? kEnc00Ch : 3, 0, 32, true);
     init_layer(h->lstm[0], "lstm1", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, 32, L[0], L[0], true, false, lstm_mrep[0], cfg->precision);
     init_layer(h->lstm[1], "lstm2", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[0], L[1], L[1], true, false, lstm_mrep[1], cfg->precision);
     init_layer(h->enc1, "enc1", PACK_PLAIN, H2, W2, H4, W4, 3, 3, 2, 0, L[1], 0, L[1], false);
@@ -743,6 +771,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     }
     h->layers = {&h->enc0, &h->lstm[0], &h->lstm[1], &h->enc1, &h->lstm[2], &h->lstm[3], &h->enc2, &h->enc3,
                  &h->lstm[4], &h->convt1, &h->lstm[5], &h->convt2, &h->lstm[6], &h->convt3, &h->fc};
+    if (h->savp) { h->layers.push_back(&h->enc00); h->layers.push_back(&h->convt4); }
     h->have_big = cfg->precision == 0;      // the split-bf16 tile has 128 rows only
     for (int k = 0; k < 7; ++k) {
         h->st_rows[k] = h->lstm[k].stats_nparts;
@@ -792,8 +821,9 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
             VF_ALLOC(vd.lw[l->id].b, l->packed_b());
             if (l->prec == 1) VF_ALLOC(vd.lw[l->id].w16, l->packed_w16());
         }
-        for (int i = 0; i < 9; ++i) {
-            const TensorDesc *g = find_tensor(h->table, "ln" + std::to_string(i + 1) + "/g");
+        for (int i = 0; i < kNumLn; ++i) {
+            const TensorDesc *g = find_tensor(h->table, ln_name(i) + "/g");
+            if (!g) continue;           // lna / lnb exist in arch 1 only
             VF_ALLOC(vd.ln_g[i], g->size());
             VF_ALLOC(vd.ln_b[i], g->size());
         }
@@ -817,7 +847,13 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     VF_ALLOC(h->enc3_o, BV * H8 * W8 * L[3]);
     VF_ALLOC(h->enc4_o, BV * H4 * W4 * L[4]);
     VF_ALLOC(h->enc5_o, BV * H2 * W2 * L[5]);
-    VF_ALLOC(h->enc6_o, BV * H * W * 32);
+    VF_ALLOC(h->enc6_o, BV * Hc * Wc * 32);
+    if (h->savp) {
+        VF_ALLOC(h->enc00_o, BV * Hc * Wc * kEnc00Ch);
+        VF_ALLOC(h->enc7_o, BV * H * W * 32);
+        VF_ALLOC(h->st_enc00, BV * h->enc00.stats_nparts * 2);
+        VF_ALLOC(h->st_enc7, BV * h->convt4.stats_nparts * 2);
+    }
     const int lh[7] = {H2, H2, H4, H4, H8, H4, H2}, lw[7] = {W2, W2, W4, W4, W8, W4, W2};
     for (int k = 0; k < 7; ++k) {
         const size_t elems = BV * lh[k] * lw[k] * L[k];
@@ -838,8 +874,8 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     h->sums_step_stride = h->sums_view_stride * NV;
     VF_ALLOC(h->sums, (size_t)h->T * h->sums_step_stride);
     VF_ALLOC(h->actions_buf, (size_t)Bc * h->T * cfg->adim);
-    h->sched_capacity = ((size_t)h->S * 20 + 8) * NV;
-    h->counter_capacity = ((size_t)h->S * 20 + 8) * ((size_t)Bc + 1) * NV;
+    h->sched_capacity = ((size_t)h->S * 24 + 8) * NV;
+    h->counter_capacity = ((size_t)h->S * 24 + 8) * ((size_t)Bc + 1) * NV;
     VF_ALLOC(h->sched[0].d_phases, h->sched_capacity);
     VF_ALLOC(h->sched[1].d_phases, h->sched_capacity);
     VF_ALLOC(h->d_sync, kSyncHead + h->counter_capacity);
@@ -863,6 +899,10 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
             VF_ALLOC(sv.st_h[k], (size_t)h->st_rows[k] * 2);
         }
         VF_ALLOC(sv.st_enc0, (size_t)h->enc0.stats_nparts * 2);
+        if (h->savp) {
+            VF_ALLOC(sv.enc00_o, (size_t)Hc * Wc * kEnc00Ch);
+            VF_ALLOC(sv.st_enc00, (size_t)h->enc00.stats_nparts * 2);
+        }
         VF_ALLOC(sv.sbias, (size_t)L[3]);
         h->shared_views.push_back(sv);
     }
@@ -957,9 +997,10 @@ int vf_load_weights(vf_handle *h, const float *blob_all, size_t n_floats) {
                 if ((rc = dev_write(h, vd.lw[l.id].w16, w16.data(), w16.size() * sizeof(unsigned short)))) return rc;
             }
         }
-        for (int i = 0; i < 9; ++i) {
-            const std::string n = "ln" + std::to_string(i + 1);
+        for (int i = 0; i < kNumLn; ++i) {
+            const std::string n = ln_name(i);
             const TensorDesc *g = T(n + "/g"), *b = T(n + "/b");
+            if (!g) continue;
             if ((rc = dev_write(h, vd.ln_g[i], blob + g->offset, g->size() * sizeof(float)))) return rc;
             if ((rc = dev_write(h, vd.ln_b[i], blob + b->offset, b->size() * sizeof(float)))) return rc;
         }
@@ -1012,19 +1053,26 @@ int vf_set_context(vf_handle *h, const uint8_t *d_frames, const float *d_states,
 
 static BatchView make_view(vf_handle *h, int view, const float *d_actions, int b0) {
     const vf_config &c = h->cfg;
-    const int H = h->H, W = h->W, T = h->T, ND = h->ND;
-    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+    const int H = h->H, W = h->W, T = h->T, ND = h->ND, Hc = h->Hc, Wc = h->Wc;
+    const int H2 = Hc / 2, W2 = Wc / 2, H4 = Hc / 4, W4 = Wc / 4, H8 = Hc / 8, W8 = Wc / 8;
     const int *L = kLstmSizes;
     const int lh[7] = {H2, H2, H4, H4, H8, H4, H2}, lw[7] = {W2, W2, W4, W4, W8, W4, W2};
     const size_t b = (size_t)view * c.max_batch + (size_t)b0;      // row of every [ncam][max_batch] buffer
     BatchView v;
+    memset(&v, 0, sizeof(v));
+    if (h->savp) {
+        v.enc00_o = h->enc00_o + b * Hc * Wc * kEnc00Ch;
+        v.enc7_o = h->enc7_o + b * H * W * 32;
+        v.st_enc00 = h->st_enc00 + b * h->enc00.stats_nparts * 2;
+        v.st_enc7 = h->st_enc7 + b * h->convt4.stats_nparts * 2;
+    }
     v.enc0_o = h->enc0_o + b * H2 * W2 * 32;
     v.enc1_o = h->enc1_o + b * H4 * W4 * L[1];
     v.enc2_o = h->enc2_o + b * H8 * W8 * L[3];
     v.enc3_o = h->enc3_o + b * H8 * W8 * L[3];
     v.enc4_o = h->enc4_o + b * H4 * W4 * L[4];
     v.enc5_o = h->enc5_o + b * H2 * W2 * L[5];
-    v.enc6_o = h->enc6_o + b * H * W * 32;
+    v.enc6_o = h->enc6_o + b * Hc * Wc * 32;
     for (int k = 0; k < 7; ++k) {
         const size_t per = (size_t)lh[k] * lw[k] * L[k];
         v.c_state[k] = h->c_state[k] + b * per;
@@ -1190,8 +1238,8 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
                         const int32_t *goal_pix, Sink &sink, bool skip_shared) {
     const vf_config &c = h->cfg;
     const ViewData &vd = h->views[view];
-    const int H = h->H, W = h->W, T = h->T, ND = h->ND, nc = c.n_context;
-    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+    const int H = h->H, W = h->W, T = h->T, ND = h->ND, nc = c.n_context, Hc = h->Hc, Wc = h->Wc;
+    const int H2 = Hc / 2, W2 = Wc / 2, H4 = Hc / 4, W4 = Wc / 4, H8 = Hc / 8, W8 = Wc / 8;
     const int *L = kLstmSizes;
     const int lh[7] = {H2, H2, H4, H4, H8, H4, H2}, lw[7] = {W2, W2, W4, W4, W8, W4, W2};
     auto params = [&](const ConvLayer &l, int Bp, const SegArg &s0, const SegArg *s1) {
@@ -1206,7 +1254,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         // 64x64-samples on, the two widest layers from ~150); 64 rows while a layer's phase would not even fill
         // the 2 x n_cu slots once with 128-row items, 32 rows below half of that (measured:
         // profiles/r02_ab_experiments.log)
-        const double beff = (double)Bp * H * W / 4096.0;
+        const double beff = (double)Bp * Hc * Wc / 4096.0;
         const ConvLayer &mid = h->lstm[k];
         const long long n128 = (long long)(mid.NI == 1 ? Bp * mid.tilesY * mid.tilesX : (Bp + mid.NI - 1) / mid.NI) * mid.ncg;
         int want = beff >= 500.0 || (beff >= 150.0 && k < 2) ? 2
@@ -1267,9 +1315,21 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         if (s < nc) { frame_in = vd.ctx_frames + (size_t)s * H * W * 3; frame_bs = 0; }
         else { frame_in = v.frames_all + (size_t)(s - nc) * H * W * 3; frame_bs = (long long)T * H * W * 3; }
 
-        ConvParams p = params(h->enc0, BE, plain(frame_in, frame_bs), nullptr);
+        ConvParams p;
+        int u_enc00 = last;
+        SegArg enc00_n = plain(nullptr, 0);
+        if (h->savp) {      // extra encoder scale: enc00 = relu(LNa(conv5x5/2(frame))), applied on staging
+            p = params(h->enc00, BE, plain(frame_in, frame_bs), nullptr);
+            p.out = E.enc00_o; p.stats = E.st_enc00;
+            VF_EMIT_SH(u_e00, enc_sh, sink.conv(PH_CONV_RAW, h->enc00, p, {last}))
+            u_enc00 = u_e00;
+            enc00_n = normed(E.enc00_o, bs(enc_sh, (long long)Hc * Wc * kEnc00Ch), E.st_enc00, h->enc00.stats_nparts,
+                             h->enc00.stats_nparts, enc_sh, (long long)Hc * Wc * kEnc00Ch, vd.ln_g[9], vd.ln_b[9],
+                             kEnc00Ch, 1);
+        }
+        p = params(h->enc0, BE, h->savp ? enc00_n : plain(frame_in, frame_bs), nullptr);
         p.out = E.enc0_o; p.stats = E.st_enc0;
-        VF_EMIT_SH(u_enc0, enc_sh, sink.conv(PH_CONV_RAW, h->enc0, p, {last}))
+        VF_EMIT_SH(u_enc0, enc_sh, sink.conv(PH_CONV_RAW, h->enc0, p, {u_enc00}))
 
         SegArg enc0_n = normed(E.enc0_o, bs(enc_sh, (long long)H2 * W2 * 32), E.st_enc0, h->enc0.stats_nparts,
                                h->enc0.stats_nparts, enc_sh, (long long)H2 * W2 * 32, vd.ln_g[0], vd.ln_b[0], 32, 1);
@@ -1349,12 +1409,28 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
             p = params(h->convt3, B, h_normed(6), &enc0_n);
             p.out = v.enc6_o; p.stats = v.st_enc6;
             VF_EMIT(u_t3, sink.conv(PH_CONVT_RAW, h->convt3, p, {u_l7}))
+            int u_top = u_t3;
+            if (h->savp) {  // extra decoder scale: enc7 = convT(concat[relu(LN9(enc6)), relu(LNa(enc00))]), LNb on use
+                // (an encoder-shared enc00 of a context step is read with batch stride 0)
+                SegArg enc6_n = normed(v.enc6_o, (long long)Hc * Wc * 32, v.st_enc6, h->convt3.stats_nparts,
+                                       h->convt3.stats_nparts, false, (long long)Hc * Wc * 32, vd.ln_g[8], vd.ln_b[8], 32, 1);
+                p = params(h->convt4, B, enc6_n, &enc00_n);
+                p.out = v.enc7_o; p.stats = v.st_enc7;
+                VF_EMIT(u_t4, sink.conv(PH_CONVT_RAW, h->convt4, p, {u_t3, u_enc00}))
+                u_top = u_t4;
+            }
 
             CompositeParams cp; memset(&cp, 0, sizeof(cp));
             cp.B = B; cp.H = H; cp.W = W; cp.ND = ND; cp.K = h->K;
-            cp.enc6 = v.enc6_o; cp.ln_part = v.st_enc6; cp.ln_nparts = h->convt3.stats_nparts;
+            if (h->savp) {
+                cp.enc6 = v.enc7_o; cp.ln_part = v.st_enc7; cp.ln_nparts = h->convt4.stats_nparts;
+                cp.gamma = vd.ln_g[10]; cp.beta = vd.ln_b[10];
+                cp.first_frame = vd.ctx_frames; cp.first_distrib = vd.ctx_distrib;     // context frame 0
+            } else {
+                cp.enc6 = v.enc6_o; cp.ln_part = v.st_enc6; cp.ln_nparts = h->convt3.stats_nparts;
+                cp.gamma = vd.ln_g[8]; cp.beta = vd.ln_b[8];
+            }
             cp.ln_inv_n = (float)(1.0 / ((double)H * W * 32));
-            cp.gamma = vd.ln_g[8]; cp.beta = vd.ln_b[8];
             cp.w_rgb = vd.w_rgb; cp.b_rgb = vd.b_rgb; cp.w_mask = vd.w_mask; cp.b_mask = vd.b_mask;
             cp.kern = v.kern;
             cp.prev_frame = frame_in; cp.prev_frame_bstride = frame_bs;
@@ -1372,7 +1448,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
             cp.out_sums = v.sums + (long long)t_out * h->sums_step_stride;
             if (goal_pix)
                 for (int d = 0; d < ND; ++d) { cp.goal[d][0] = goal_pix[2 * d]; cp.goal[d][1] = goal_pix[2 * d + 1]; }
-            VF_EMIT(u_comp, sink.composite(cp, h->ntiles, view, {u_t3, u_fin}))
+            VF_EMIT(u_comp, sink.composite(cp, h->ntiles, view, {u_top, u_fin}))
             last = u_comp;
         }
     }
@@ -1500,6 +1576,7 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
             ok = ok && in_allocs(h, c.out_distrib, ((size_t)(P.B - 1) * c.out_distrib_bstride + hw * c.ND) * 4);
             ok = ok && in_allocs(h, c.out_sums, (size_t)P.B * c.ND * h->ntiles * 2 * 8);
             ok = ok && in_allocs(h, c.kern, (size_t)P.B * kTaps * c.K * 4);
+            ok = ok && in_allocs(h, c.first_frame, hw * 3 * 4) && in_allocs(h, c.first_distrib, hw * c.ND * 4);
         } else if (P.type == PH_SA) {
             ok = ok && in_allocs(h, P.sa.sbias, (size_t)P.B * P.sa.n_out * 4) && in_allocs(h, P.sa.action, 4) &&
                  in_allocs(h, P.sa.state, 4);
@@ -1547,7 +1624,7 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
 
 // the zero initial LSTM state is one shared image per layer
 static int zero_shared_state(vf_handle *h, const BatchView &sh, hipStream_t st) {
-    const int H = h->H, W = h->W;
+    const int H = h->Hc, W = h->Wc;
     const int *L = kLstmSizes;
     const int lh[7] = {H / 2, H / 2, H / 4, H / 4, H / 8, H / 4, H / 2};
     const int lw[7] = {W / 2, W / 2, W / 4, W / 4, W / 8, W / 4, W / 2};

@@ -122,6 +122,8 @@ struct CompositeParams {
     const float *prev_frame; long long prev_frame_bstride;      // [H][W][3]
     const float *prev_distrib; long long prev_distrib_bstride;  // [H][W][ND]
     const double *prev_sums;            // [B][ND][ntiles][2] partial sums of prev_distrib, or null
+    const float *first_frame;           // arch 1 (savp_arch.py): first context frame [H][W][3], shared by every
+    const float *first_distrib;         //   sample, and its distributions [H][W][ND]; null = CDNA compositing
     float *out_frame; long long out_frame_bstride;
     float *out_distrib; long long out_distrib_bstride;
     double *out_sums;                   // [B][ND][ntiles][2]: sum d, sum d * dist(goal)
@@ -230,6 +232,7 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
         for (int j = 0; j < NM; ++j) o_m[j] *= inv;
 
         // ---- per-pixel effective flow kernel: keff[tap] = sum_k mask[k+2] * kern[tap][k]
+        // (arch 1: mask 2 weighs the first context frame, the warps use masks 3.. and kernels 0..K-3)
         float of[3], od[ND];
         const int ctr = (ly + 2) * HS + (lx + 2);
 #pragma unroll
@@ -237,6 +240,18 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
             of[c] = fmaf(o_m[0], s_frame[ctr * 3 + c], o_m[1] * sigmoidf_(o_rgb[c]));
 #pragma unroll
         for (int d = 0; d < ND; ++d) od[d] = o_m[0] * s_dist[ctr * ND + d];
+        if (p.first_frame) {
+            const long long o1 = (long long)y * p.W + x;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) of[c] = fmaf(o_m[2], p.first_frame[o1 * 3 + c], of[c]);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) od[d] = fmaf(o_m[2], p.first_distrib[o1 * ND + d], od[d]);
+            // the warp loop below pairs kernel k with o_m[k + 2]: shift the warp masks down by one and
+            // retire the last kernel (its product with 0 leaves the sum unchanged)
+#pragma unroll
+            for (int j = 2; j < K; ++j) o_m[j] = o_m[j + 1];
+            o_m[K] = 0.f;
+        }
 #pragma unroll
         for (int dy = 0; dy < kDnaKern; ++dy) {
 #pragma unroll

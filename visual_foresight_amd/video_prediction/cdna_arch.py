@@ -75,10 +75,20 @@ class CdnaConfig(object):
         """Number of predicted frames T = sequence_length - n_context."""
         return self.sequence_length - self.n_context
 
+    arch = 'cdna'           # architecture tag (manifest, vf_config.arch): 'cdna' here, 'savp' in savp_arch.py
+    arch_id = 0
+
     def as_dict(self):
         return dict(height=self.height, width=self.width, adim=self.adim, sdim=self.sdim,
                     ndesig=self.ndesig, n_context=self.n_context,
                     sequence_length=self.sequence_length, num_masks=self.num_masks)
+
+    def tensor_shapes(self):
+        """Ordered name -> shape table of every learned tensor of this architecture."""
+        return tensor_shapes(self)
+
+    def macs_per_sample_step(self):
+        return macs_per_sample_step(self)
 
 
 def tensor_shapes(cfg):
@@ -150,7 +160,7 @@ class CdnaWeights(object):
 
     def __init__(self, cfg, tensors):
         self.cfg = cfg
-        want = tensor_shapes(cfg)
+        want = cfg.tensor_shapes()
         if list(tensors.keys()) != list(want.keys()):
             raise ValueError('tensor set does not match the architecture table')
         for name, shape in want.items():
@@ -169,7 +179,7 @@ class CdnaWeights(object):
         """
         rs = np.random.RandomState(seed)
         tensors = OrderedDict()
-        for name, shape in tensor_shapes(cfg).items():
+        for name, shape in cfg.tensor_shapes().items():
             kind = name.split('/')[1]
             if kind == 'w':
                 if len(shape) == 4:
@@ -182,7 +192,7 @@ class CdnaWeights(object):
             elif kind == 'g':
                 tensors[name] = (1.0 + ln_jitter * rs.uniform(-1, 1, shape)).astype(np.float32)
             else:   # conv / FC bias or LayerNorm offset
-                scale = ln_jitter if name.startswith('ln') else bias_scale
+                scale = ln_jitter if name.startswith('ln') else bias_scale     # ('lna'/'lnb' included)
                 tensors[name] = (scale * rs.uniform(-1, 1, shape)).astype(np.float32)
         return cls(cfg, tensors)
 
@@ -190,7 +200,7 @@ class CdnaWeights(object):
     def save(self, model_dir):
         """``model_dir/manifest.json`` + ``model_dir/weights.bin`` (flat little-endian float32)."""
         os.makedirs(model_dir, exist_ok=True)
-        manifest = {'format': 'vf-cdna-v1', 'config': self.cfg.as_dict(), 'tensors': []}
+        manifest = {'format': 'vf-cdna-v1', 'arch': self.cfg.arch, 'config': self.cfg.as_dict(), 'tensors': []}
         offset = 0
         with open(os.path.join(model_dir, 'weights.bin'), 'wb') as f:
             for name, arr in self.tensors.items():
@@ -207,7 +217,16 @@ class CdnaWeights(object):
             manifest = json.load(f)
         if manifest.get('format') != 'vf-cdna-v1':
             raise ValueError('unknown weight file format %r' % manifest.get('format'))
-        file_cfg = CdnaConfig(**manifest['config'])
+        arch = manifest.get('arch', 'cdna')
+        if arch == 'cdna':
+            file_cfg = CdnaConfig(**manifest['config'])
+        elif arch == 'savp':
+            from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
+            file_cfg = SavpConfig(**manifest['config'])
+        else:
+            raise ValueError('unknown architecture %r in %s' % (arch, model_dir))
+        if cfg is not None and cfg.arch != arch:
+            raise ValueError('checkpoint architecture %r does not match requested %r' % (arch, cfg.arch))
         if cfg is not None:
             mine, theirs = cfg.as_dict(), file_cfg.as_dict()
             for k in ('height', 'width', 'adim', 'sdim', 'num_masks'):

@@ -31,6 +31,7 @@ import numpy as np
 
 from visual_foresight_amd import _lib
 from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights
+from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
 from visual_foresight_amd.video_prediction.sharding import dist_info as _dist_info, shard_bounds, all_gather_rows
 
 
@@ -53,10 +54,15 @@ class HipVPredEvaluation(object):
         self.n_draws = int(hp.get('n_draws', 1))        # latent draws per action (stochastic_predictor.py)
         self.run_batch_size = int(hp.get('run_batch_size', 200)) * self.n_draws
         self.seed = int(hp.get('seed', 0))
-        self.cfg = CdnaConfig(height=hp.get('image_height', 64), width=hp.get('image_width', 64),
-                              adim=hp.get('adim', 4), sdim=hp.get('sdim', 5),
-                              ndesig=hp.get('designated_pixel_count', 1), n_context=self.n_context,
-                              sequence_length=self.sequence_length)
+        # 'arch': 'cdna' (cdna_arch.py, default) or 'savp' (savp_arch.py: four scales, first-frame compositing)
+        self.arch = str(hp.get('arch', 'cdna'))
+        if self.arch not in ('cdna', 'savp'):
+            raise ValueError("arch must be 'cdna' or 'savp', got %r" % (self.arch,))
+        cfg_cls = SavpConfig if self.arch == 'savp' else CdnaConfig
+        self.cfg = cfg_cls(height=hp.get('image_height', 64), width=hp.get('image_width', 64),
+                           adim=hp.get('adim', 4), sdim=hp.get('sdim', 5),
+                           ndesig=hp.get('designated_pixel_count', 1), n_context=self.n_context,
+                           sequence_length=self.sequence_length)
         if not torch.cuda.is_available():
             raise _lib.VfError('HipVPredEvaluation needs a ROCm GPU (no CPU fallback)')
         # one process drives one GPU; under torchrun LOCAL_RANK picks it
@@ -71,7 +77,7 @@ class HipVPredEvaluation(object):
         self.precision = {'fp32': 0, '0': 0, 0: 0, 'bf16x6': 1, '1': 1, 1: 1}[precision]
         self._c_cfg = _lib.VfConfig(c.height, c.width, c.adim, c.sdim, c.ndesig, c.n_context,
                                     c.sequence_length, c.num_masks, self.run_batch_size,
-                                    self.device_index, self.precision, self.n_cam, self.n_draws)
+                                    self.device_index, self.precision, self.n_cam, self.n_draws, c.arch_id)
         self._handle = ctypes.c_void_p()
         _lib.check(self._libh.vf_create(ctypes.byref(self._c_cfg), ctypes.byref(self._handle)))
         self.set_substreams(int(hp.get('substreams', os.environ.get('VF_SUBSTREAMS', 1))))

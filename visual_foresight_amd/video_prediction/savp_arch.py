@@ -1,0 +1,113 @@
+"""Architecture table of the SAVP-class stochastic generator (BASELINE config 5).
+
+The reference only *instantiates* ``SAVPVideoPredictionModel`` from the absent ``video_prediction``
+package (``visual_mpc/video_prediction/vpred_model_interface.py:52-58``); nothing of its arithmetic
+is in ``/root/reference``, so - exactly as for ``cdna_arch.py`` - this module is the *normative*
+description of what this repo implements, **parity unpinned**.  It restates the *deterministic
+generator* of Lee et al. 2018 (arXiv:1804.01523, appendix A: the SNA conv-LSTM generator of Ebert
+et al. 2017 conditioned on a per-step latent) with the building blocks this engine has:
+
+* **per-step latent injection**: ``z_t ~ N(0, I)`` (``zdim`` = 8), drawn per time step from the
+  prior at planning time, tiled and concatenated with the action and the state where the
+  conditioning enters the network (the bottleneck; SAVP tiles it into every layer);
+* **four spatial scales for 128x128** (SURVEY 8d "128x128 -> one extra encoder/decoder scale"): one
+  more stride-2 encoder conv in front of, and one more transposed conv behind, the three-scale
+  conv-LSTM core, with a skip connection between them, so the seven conv-LSTMs run at H/4, H/8 and
+  H/16 (32, 16, 8 pixels for a 128-pixel frame);
+* **first-frame skip in the compositing** (SNA / SAVP ``first_image_background``): the next frame is
+  composed from the previous frame, a scratch image, the FIRST context frame and the CDNA-warped
+  previous frames; designated-pixel distributions follow the same masks (the scratch image carries
+  no mass, the first frame carries its own context distribution).
+
+Per time step (NHWC, float32, TensorFlow "SAME" padding, H and W multiples of 16; ``a`` = executed
+or candidate action, ``z`` = latent, ``s`` = state)::
+
+    enc00 = relu(LNa(conv5x5/2(frame, 3->16)))                         H/2    (extra scale)
+    enc0  = relu(LN1(conv5x5/2(enc00, 16->32)))                        H/4
+    h1 = LN2(lstm1(enc0, 32)); h2 = LN3(lstm2(h1, 32))
+    enc1  = relu(conv3x3/2(h2, 32->32))                                H/8
+    h3 = LN4(lstm3(enc1, 64)); h4 = LN5(lstm4(h3, 64))
+    enc2  = relu(conv3x3/2(h4, 64->64))                                H/16
+    enc3  = relu(conv1x1(concat[enc2, tile(a, z, s)], ->64))
+    h5 = LN6(lstm5(enc3, 128))
+    enc4  = relu(convT3x3*2(h5, 128->128))                             H/8
+    h6 = LN7(lstm6(enc4, 64))
+    enc5  = relu(convT3x3*2(concat[h6, enc1], 96->64))                 H/4
+    h7 = LN8(lstm7(enc5, 32))
+    enc6  = relu(LN9(convT3x3*2(concat[h7, enc0], 64->32)))            H/2
+    enc7  = relu(LNb(convT3x3*2(concat[enc6, enc00], 48->32)))         H      (extra scale)
+    scratch = sigmoid(conv1x1(enc7, ->3));  masks = softmax_c(conv1x1(enc7, ->K+1))
+    kern    = normalise(relu(FC(flatten(h5), ->5*5*K) - 1e-12) + 1e-12)
+    frame'  = m_0 * frame + m_1 * scratch + m_2 * first + sum_{k=0..K-3} m_{k+3} * warp_k(frame)
+    distr'  = normalise_hw(m_0 * distr + m_2 * distr_first + sum_{k=0..K-3} m_{k+3} * warp_k(distr))
+    state'  = FC(concat[a, z, s], ->sdim)
+
+``first`` / ``distr_first`` are the first of the ``n_context`` context frames / distributions.  The
+conv-LSTM cell, LayerNorm, CDNA kernels and tensor layouts are those of ``cdna_arch.py``.
+
+Known departures from the published SAVP generator (none of them pinned by the reference): layer
+normalisation instead of instance normalisation, strided / transposed convolutions instead of
+conv + average-pool / bilinear-upsample + conv, ``K - 2 = 8`` warped images instead of 4, the
+conditioning vector enters at the bottleneck only, and the channel widths are those of the CDNA
+core.  The encoder of the latent (posterior network) and the discriminators are training-time
+components and have no role in planning.
+
+The engine sees the latent as extra action channels (``vf_config.adim = adim + zdim``,
+``vf_config.arch = 1``); ``StochasticHipPredictor`` draws ``z`` and folds the draws into the sample axis.
+"""
+from collections import OrderedDict
+
+from visual_foresight_amd.video_prediction import cdna_arch
+from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights, LSTM_SIZES, DNA_KERN  # noqa: F401
+
+ENC00_CH = 16       # channels of the extra encoder scale
+TOP_CH = 32         # channels of the extra decoder scale (input of the 1x1 heads)
+
+
+class SavpConfig(CdnaConfig):
+    """Static shape of one SAVP-class predictor: ``adim`` already includes the latent channels."""
+    arch = 'savp'
+    arch_id = 1
+
+    def __init__(self, height=128, width=128, adim=12, sdim=5, ndesig=1, n_context=2,
+                 sequence_length=17, num_masks=10, ncam=1):
+        if height % 16 or width % 16:
+            raise ValueError('image size must be a multiple of 16, got %dx%d' % (height, width))
+        super(SavpConfig, self).__init__(height, width, adim, sdim, ndesig, n_context, sequence_length,
+                                         num_masks, ncam)
+
+    @property
+    def core(self):
+        """The three-scale conv-LSTM core sees half-resolution features."""
+        return CdnaConfig(self.height // 2, self.width // 2, self.adim, self.sdim, self.ndesig,
+                          self.n_context, self.sequence_length, self.num_masks)
+
+    def tensor_shapes(self):
+        t = OrderedDict()
+        t['enc00/w'] = (5, 5, 3, ENC00_CH); t['enc00/b'] = (ENC00_CH,)
+        t['lna/g'] = (ENC00_CH,); t['lna/b'] = (ENC00_CH,)
+        for name, shape in cdna_arch.tensor_shapes(self.core).items():
+            if name == 'enc0/w':
+                shape = (5, 5, ENC00_CH, 32)
+            t[name] = shape
+            if name == 'ln9/b':
+                t['convt4/w'] = (3, 3, 32 + ENC00_CH, TOP_CH); t['convt4/b'] = (TOP_CH,)
+                t['lnb/g'] = (TOP_CH,); t['lnb/b'] = (TOP_CH,)
+        return t
+
+    def macs_per_sample_step(self):
+        H, W = self.height, self.width
+        core = self.core
+        out = OrderedDict()
+        out['enc00'] = (H // 2) * (W // 2) * 25 * 3 * ENC00_CH
+        for name, v in cdna_arch.macs_per_sample_step(core).items():
+            if name == 'enc0':
+                v = (H // 4) * (W // 4) * 25 * ENC00_CH * 32
+            elif name in ('rgb', 'masks'):
+                v *= 4                      # the heads run at full resolution
+            elif name.startswith('warp_'):
+                v *= 4
+            out[name] = v
+            if name == 'convt3':
+                out['convt4'] = (H // 2) * (W // 2) * 9 * (32 + ENC00_CH) * TOP_CH
+        return out

@@ -4,9 +4,11 @@ BASELINE config 5 asks for a stochastic predictor evaluated with several latent 
 sequence ("n_latent = 5 z-draws ~ N(0, I) per action ... latent draws fold into
 the sample axis; per-action cost = mean over its draws").  The SAVP architecture is external to
 the reference (``visual_mpc/video_prediction/vpred_model_interface.py:52-58`` only instantiates
-it), so this module implements the conditioning scheme on the network this repo defines: the
-latent ``z_t`` enters exactly where the action does (tiled and concatenated at the bottleneck,
-``cdna_arch.py`` enc3), i.e. the engine is built for ``adim + zdim`` "action" channels.
+it); the generator this repo implements for it is specified in ``savp_arch.py`` (``arch='savp'``, the
+default here: four scales, first-frame compositing, per-step latent; parity unpinned) and
+``arch='cdna'`` conditions the plain CDNA network of ``cdna_arch.py`` the same way.  In both, the latent
+``z_t`` enters exactly where the action does (tiled and concatenated at the bottleneck, enc3), i.e. the
+engine is built for ``adim + zdim`` "action" channels.
 
 Every action sequence is rolled ``n_latent`` times with common random numbers (draw ``d`` uses the
 same ``z[d, t]`` for every action, redrawn per planning call from ``latent_seed``), which keeps the
@@ -39,7 +41,7 @@ class StochasticHipPredictor(HipVPredEvaluation):
         self.adim = int(hp.get('adim', 4))
         self._calls = 0
         self._z = None
-        inner = dict(hp, adim=self.adim + self.zdim, n_draws=self.n_latent)
+        inner = dict(hp, adim=self.adim + self.zdim, n_draws=self.n_latent, arch=hp.get('arch', 'savp'))
         super(StochasticHipPredictor, self).__init__(model_path, inner, n_gpus=n_gpus, first_gpu=first_gpu)
 
     def draw_latents(self, T):
