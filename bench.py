@@ -338,13 +338,12 @@ class Bench(object):
     def survey_rate(self, m):
         """SURVEY.md 8(d) accounting: every sample charged with all seq_len - 1 cell evaluations at the layer
         table's MAC count, including the context step the engine runs once and shares (so >= `achieved`)."""
-        from visual_foresight_amd.video_prediction.cdna_arch import macs_per_sample_step
         pred = m['pred']
         steps = pred.sequence_length - 1
         if not m['launches'] or m['kernel_ms'] <= 0:
             return None
         rollouts_per_launch = m['rollouts'] / m['launches']
-        macs = float(sum(macs_per_sample_step(pred.cfg).values()))
+        macs = float(sum(pred.cfg.macs_per_sample_step().values()))
         flops = 2.0 * macs * steps * rollouts_per_launch
         tf = flops / (1e-3 * m['kernel_ms'] / m['launches']) / 1e12
         return {'flops_per_launch': flops, 'tflops': tf, 'frac_of_fp32_mfma_peak': tf / PEAK_FP32_MFMA_TFLOPS,
@@ -410,6 +409,7 @@ class Bench(object):
                        'horizon': T, 'iterations': iters, 'views': self.ncam,
                        'designated_pixels_per_view': self.ndesig, 'precision': primary,
                        'latent_draws_per_action': self.draws,
+                       'network': getattr(m['pred'], 'arch', 'cdna'),
                        'sharding': 'samples over %d rank(s), one all-gather of score rows per CEM iteration%s' %
                                    (self.world, ' (gloo dry run: ranks share a GPU, not a scaling measurement)'
                                     if shared_gpus else ' over RCCL' if self.world > 1 else '')},
