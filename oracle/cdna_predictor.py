@@ -21,8 +21,12 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from visual_foresight_amd.video_prediction.cdna_arch import (
-    LSTM_SIZES, RELU_SHIFT, LN_EPS, DNA_KERN)
+# The oracle states its constants itself (a typo in the product's table must show up as a test failure,
+# not be inherited); tests/test_oracle_predictor.py checks they agree with cdna_arch.py.
+LSTM_SIZES = (32, 32, 64, 64, 128, 64, 32)     # hidden channels of lstm1..lstm7 (arXiv:1605.07157 fig. 3)
+RELU_SHIFT = 1e-12                              # CDNA kernels: relu(x - shift) + shift before normalising
+LN_EPS = 1e-12                                  # layer-norm variance epsilon
+DNA_KERN = 5                                    # CDNA kernel size
 
 
 def _same_pad(x, k, stride):
@@ -33,10 +37,35 @@ def _same_pad(x, k, stride):
     return F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
 
 
+def expected_shapes(cfg):
+    """The oracle's OWN reading of the layer table (arXiv:1605.07157 section 3 / SURVEY row a14): name -> shape.
+    A network handed to the oracle must have exactly these tensors, so a wrong layer size in the product's
+    table (cdna_arch.py) cannot hide behind weights generated from that same table."""
+    a, K = cfg.adim + cfg.sdim, cfg.num_masks
+    h8, w8 = cfg.height // 8, cfg.width // 8
+    t = {'enc0/w': (5, 5, 3, 32), 'lstm1/w': (5, 5, 64, 128), 'lstm2/w': (5, 5, 64, 128), 'enc1/w': (3, 3, 32, 32),
+         'lstm3/w': (5, 5, 96, 256), 'lstm4/w': (5, 5, 128, 256), 'enc2/w': (3, 3, 64, 64), 'enc3/w': (1, 1, 64 + a, 64),
+         'lstm5/w': (5, 5, 192, 512), 'convt1/w': (3, 3, 128, 128), 'lstm6/w': (5, 5, 192, 256),
+         'convt2/w': (3, 3, 96, 64), 'lstm7/w': (5, 5, 96, 128), 'convt3/w': (3, 3, 64, 32), 'rgb/w': (1, 1, 32, 3),
+         'masks/w': (1, 1, 32, K + 1), 'cdna/w': (h8 * w8 * 128, 25 * K), 'state/w': (a, cfg.sdim)}
+    for name in list(t):
+        t[name[:-2] + '/b'] = (t[name][-1],)
+    for i, c in enumerate((32, 32, 32, 64, 64, 128, 64, 32, 32)):
+        t['ln%d/g' % (i + 1)] = t['ln%d/b' % (i + 1)] = (c,)
+    return t
+
+
 class OracleCdna(object):
+    expected_shapes = staticmethod(expected_shapes)
+
     def __init__(self, weights, dtype=torch.float32, threads=None):
         self.cfg = weights.cfg
         self.dtype = dtype
+        want = self.expected_shapes(self.cfg)
+        got = {k: tuple(v.shape) for k, v in weights.tensors.items()}
+        if got != want:
+            diff = sorted(k for k in set(got) | set(want) if got.get(k) != want.get(k))
+            raise ValueError('network does not match the oracle\'s layer table: %s' % diff[:6])
         if threads:
             torch.set_num_threads(threads)
         self.p = {k: torch.from_numpy(np.array(v)).to(dtype) for k, v in weights.tensors.items()}

@@ -23,7 +23,24 @@ RELU_SHIFT = 1e-12
 DNA_KERN = 5
 
 
+def expected_shapes(cfg):
+    """The oracle's own layer table of the SAVP-class generator (savp_arch.py): the CDNA table at half the
+    resolution with a 16-channel enc0 input, plus the extra encoder / decoder scale."""
+    from oracle.cdna_predictor import expected_shapes as core_shapes
+
+    class _Core(object):
+        adim, sdim, num_masks = cfg.adim, cfg.sdim, cfg.num_masks
+        height, width = cfg.height // 2, cfg.width // 2
+    t = core_shapes(_Core)
+    t['enc0/w'] = (5, 5, 16, 32)
+    t.update({'enc00/w': (5, 5, 3, 16), 'enc00/b': (16,), 'lna/g': (16,), 'lna/b': (16,),
+              'convt4/w': (3, 3, 48, 32), 'convt4/b': (32,), 'lnb/g': (32,), 'lnb/b': (32,)})
+    return t
+
+
 class OracleSavp(OracleCdna):
+    expected_shapes = staticmethod(expected_shapes)
+
     def core_sizes(self):
         H, W = self.cfg.height // 2, self.cfg.width // 2
         return [(H // 2, W // 2)] * 2 + [(H // 4, W // 4)] * 2 + [(H // 8, W // 8)] + \
