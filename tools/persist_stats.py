@@ -8,17 +8,23 @@ from visual_foresight_amd import _lib
 from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
 from oracle import pixel_cost
 
-M, T = int(sys.argv[1]) if len(sys.argv) > 1 else 200, 13
-pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2)).restore()
+# usage: persist_stats.py [M [H [arch [T]]]]   (arch: cdna | savp; savp runs with 12 action channels)
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+arch = sys.argv[3] if len(sys.argv) > 3 else 'cdna'
+T = int(sys.argv[4]) if len(sys.argv) > 4 else 13
+adim = 12 if arch == 'savp' else 4
+pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2, image_height=H,
+                                   image_width=H, arch=arch, adim=adim)).restore()
 lib = _lib.load_library()
 _lib.check(lib.vf_set_phase_stats(pred._handle, 1))
 rs = np.random.RandomState(0)
-ctx = {'context_frames': rs.randint(0, 256, (2, 1, 64, 64, 3)).astype(np.uint8), 'context_actions': np.zeros((1, 4)),
-       'context_states': np.zeros((2, 5)), 'context_pixel_distributions': pixel_cost.one_hot_distrib([[[32, 32]]], 2, 1, 64, 64, 1)}
-acts = rs.normal(0, 0.05, (M, T, 4))
+ctx = {'context_frames': rs.randint(0, 256, (2, 1, H, H, 3)).astype(np.uint8), 'context_actions': np.zeros((1, adim)),
+       'context_states': np.zeros((2, 5)), 'context_pixel_distributions': pixel_cost.one_hot_distrib([[[32, 32]]], 2, 1, H, H, 1)}
+acts = rs.normal(0, 0.05, (M, T, adim))
 for _ in range(2):
     pred.score(ctx, {'actions': acts}, [[[16, 48]]])
-N = 400
+N = 500
 types, items, wr = (ctypes.c_int32 * N)(), (ctypes.c_int32 * N)(), (ctypes.c_uint64 * (2 * N))()
 n = lib.vf_debug_phase_stats(pred._handle, N, types, items, wr)
 names = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE']
@@ -27,7 +33,7 @@ agg = {}
 print('phase type items  wait_ms(sum over items)  run_ms(sum)  run_us/item')
 for i in range(n):
     w, r = wr[2 * i] * tick * 1e3, wr[2 * i + 1] * tick * 1e3
-    if i < 14 or 140 <= i < 160:
+    if i < 16 or n - 44 <= i < n - 22:
         print('%3d %-10s %5d %10.2f %10.2f %10.1f' % (i, names[types[i]], items[i], w, r, 1e3 * r / max(items[i], 1)))
     a = agg.setdefault(names[types[i]], [0, 0., 0.])
     a[0] += items[i]; a[1] += w; a[2] += r

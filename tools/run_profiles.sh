@@ -1,0 +1,34 @@
+#!/bin/bash
+# GPU box: every measurement profiles/ quotes for the current tree, written to gpurun_out/prof_<tag>/ (copy the
+# summaries into profiles/ afterwards).  usage: tools/run_profiles.sh <tag>
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+tag=${1:-r02}
+O=$R/gpurun_out/prof_$tag
+mkdir -p $O
+cd $R
+# 1. the default bench line (fp32 primary, split-bf16 alt, CPU legs)
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python tools/bench_line.py $O/bench_default.json default
+# 2. kernel trace of the same workload
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/ktrace -o k -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt > $O/ktrace_bench.json 2> $O/ktrace.err
+cd $R
+db=$(ls $O/ktrace/*.db 2>/dev/null | head -1)
+[ -n "$db" ] && python3 tools/rocprof_summary.py $db > $O/kernel_stats_fp32.txt && head -6 $O/kernel_stats_fp32.txt
+# 3. counters (separate runs, --kernel-trace only)
+bash tools/pmc_mfma.sh > $O/mfma_pmc.txt 2>&1; tail -4 $O/mfma_pmc.txt
+bash tools/pmc_hbm.sh > $O/pmc_hbm.log 2>&1; cp gpurun_out/r02_hbm_traffic.json $O/hbm_traffic.json; tail -3 $O/pmc_hbm.log
+# 4. the other BASELINE shapes
+python bench.py --workload c1 --no-alt --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c1.json; python tools/bench_line.py $O/bench_c1.json c1
+python bench.py --workload c3 --no-alt --no-cpu-baseline --steps 4 --warmup 1 2>/dev/null | tail -1 > $O/bench_c3.json; python tools/bench_line.py $O/bench_c3.json c3
+python bench.py --workload c4 --samples 125 --no-alt --no-cpu-baseline --steps 8 --warmup 2 2>/dev/null | tail -1 > $O/bench_c4_shard125.json; python tools/bench_line.py $O/bench_c4_shard125.json c4-shard
+python bench.py --workload c4 --no-alt --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_c4_1gpu.json; python tools/bench_line.py $O/bench_c4_1gpu.json c4-1gpu
+python bench.py --samples 25 --no-alt --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | tail -1 > $O/bench_c2_shard25.json; python tools/bench_line.py $O/bench_c2_shard25.json c2-shard25
+python bench.py --workload c5 --samples 125 --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_c5_shard125.json; python tools/bench_line.py $O/bench_c5_shard125.json c5-shard
+# 5. phase statistics, two-rank dry run
+python tools/persist_stats.py 200 > $O/phase_stats_200.txt 2>&1
+python tools/persist_stats.py 25 > $O/phase_stats_25.txt 2>&1
+python tools/persist_stats.py 625 128 savp 15 > $O/phase_stats_c5_shard.txt 2>&1
+python bench.py --gpus 2 --no-alt --no-cpu-baseline --steps 4 --warmup 1 2>/dev/null | tail -1 > $O/bench_2ranks_gloo_dryrun.json; python tools/bench_line.py $O/bench_2ranks_gloo_dryrun.json 2ranks-gloo
+rm -rf $O/ktrace gpurun_out/hbm_FETCH_SIZE gpurun_out/hbm_WRITE_SIZE gpurun_out/mfma_pmc
