@@ -68,20 +68,7 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx,
         bimg0 = bx * p.NI; ty0 = 0; tx0 = 0;
     }
 
-    for (int i = tid; i < p.nseg * p.NI; i += kConvThreads) {
-        const int s = i / p.NI, img = i % p.NI;
-        const auto &sg = p.seg[s];
-        float mean = 0.f, rstd = 1.f;
-        const int b = bimg0 + img;
-        if (sg.ln_part && b < p.B) {
-            long long su = 0, sq = 0;
-            const long long *pp = sg.ln_part + (long long)b * sg.ln_bstride;
-            for (int k = 0; k < sg.ln_nparts; ++k) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
-            ln_from_totals(su, sq, sg.ln_inv_n, mean, rstd);
-        }
-        lnTab[2 * i] = mean;
-        lnTab[2 * i + 1] = rstd;
-    }
+    ln_table(p, bimg0, lnTab);
 
     const int px_per_img = p.TH * p.TW;
     int abase[MREP];                    // 16-B unit of this lane's row inside a plane (+ k-half)

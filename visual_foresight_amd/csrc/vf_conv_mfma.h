@@ -152,6 +152,47 @@ __device__ __forceinline__ void ln_from_totals(const long long su, const long lo
     rstd = (float)(1.0 / sqrt(var + (double)kLnEps));
 }
 
+// mean / rstd of every (input segment, image) of a tile from the producers' partial sums -> lnTab[nseg * NI][2].
+// Few entries (conv tiles: 1-8): one WAVE per entry, lanes over the partials (up to 32 per sample at 128x128), so the
+// prologue costs one load latency instead of a serial chain; many entries (the FC: one per GEMM row): one thread
+// each.  The partials are integers: any summation order gives the same bits.
+template <class PT>
+__device__ __forceinline__ void ln_table(const PT &p, const int bimg0, float *lnTab) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.nseg * p.NI;
+    if (n <= 8) {
+        for (int i = wave; i < n; i += kConvThreads / 64) {
+            const int s = i / p.NI, img = i - s * p.NI;
+            const auto &sg = p.seg[s];
+            float mean = 0.f, rstd = 1.f;
+            const int b = bimg0 + img;
+            if (sg.ln_part && b < p.B) {
+                long long su = 0, sq = 0;
+                const long long *pp = sg.ln_part + (long long)b * sg.ln_bstride;
+                for (int k = lane; k < sg.ln_nparts; k += 64) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
+                su = wave_sum(su); sq = wave_sum(sq);
+                ln_from_totals(su, sq, sg.ln_inv_n, mean, rstd);
+            }
+            if (lane == 0) { lnTab[2 * i] = mean; lnTab[2 * i + 1] = rstd; }
+        }
+    } else {
+        for (int i = tid; i < n; i += kConvThreads) {
+            const int s = i / p.NI, img = i % p.NI;
+            const auto &sg = p.seg[s];
+            float mean = 0.f, rstd = 1.f;
+            const int b = bimg0 + img;
+            if (sg.ln_part && b < p.B) {
+                long long su = 0, sq = 0;
+                const long long *pp = sg.ln_part + (long long)b * sg.ln_bstride;
+                for (int k = 0; k < sg.ln_nparts; ++k) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
+                ln_from_totals(su, sq, sg.ln_inv_n, mean, rstd);
+            }
+            lnTab[2 * i] = mean;
+            lnTab[2 * i + 1] = rstd;
+        }
+    }
+}
+
 // Shared epilogue of the fp32 and the split-bf16 tiles: accumulators (MFMA 32x32 C layout) ->
 // bias / activation / cell update / stores + deterministic LayerNorm partial sums.
 template <int G, int EPI, int MREP, class PT>
@@ -382,20 +423,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     [[maybe_unused]] unsigned long long ts1 = 0, ts_stage = 0;
     [[maybe_unused]] const int ts_key = (((p.seg[0].C + (p.nseg > 1 ? p.seg[1].C : 0)) >> 5) & 7) + (p.Hout >= 32 ? 0 : 8);
     // ---- LayerNorm statistics of the producing layers (this workgroup's samples only)
-    for (int i = tid; i < p.nseg * p.NI; i += kConvThreads) {
-        const int s = i / p.NI, img = i % p.NI;
-        const auto &sg = p.seg[s];
-        float mean = 0.f, rstd = 1.f;
-        const int b = bimg0 + img;
-        if (sg.ln_part && b < p.B) {
-            long long su = 0, sq = 0;
-            const long long *pp = sg.ln_part + (long long)b * sg.ln_bstride;
-            for (int k = 0; k < sg.ln_nparts; ++k) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
-            ln_from_totals(su, sq, sg.ln_inv_n, mean, rstd);
-        }
-        lnTab[2 * i] = mean;
-        lnTab[2 * i + 1] = rstd;
-    }
+    ln_table(p, bimg0, lnTab);
 
     // ---- this lane's A rows (GEMM rows wave*WROWS + m*32 + n)
     const int px_per_img = p.TH * p.TW;
@@ -426,6 +454,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     const long long wstep = (long long)2 * Ntot * 4;        // floats per (chunk, tap, k8) block
 
     const int q4 = KC >> 2;
+    const int q4_log2 = 31 - __builtin_clz((unsigned)q4);
+    const unsigned magic_px = 0xFFFFFFFFu / (unsigned)tile_px + 1u, magic_lw = 0xFFFFFFFFu / (unsigned)LW + 1u;
     const int items = p.NI * tile_px * q4;
 
     // ---- G == 4 (conv-LSTM, transposed conv): the B operand goes through LDS.  Per tap the
@@ -456,9 +486,11 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
         __syncthreads();        // previous chunk fully consumed (and lnTab visible on entry)
         [[maybe_unused]] const unsigned long long ts_s0 = VF_TS_NOW();
         for (int it = tid; it < items; it += kConvThreads) {
-            const int pix = it / q4, q = it - pix * q4;
-            const int img = pix / tile_px, r = pix - img * tile_px;
-            const int ly = r / LW, lx = r - ly * LW;
+            // q4 is a power of two; tile_px and LW divide through a multiply-high (exact for every index a tile
+            // can hold: checked exhaustively for dividends < 70000, divisors 2..600; divisor 1 - the FC - bypasses it)
+            const int pix = it >> q4_log2, q = it & (q4 - 1);
+            const int img = tile_px == 1 ? pix : (int)__umulhi((unsigned)pix, magic_px), r = pix - img * tile_px;
+            const int ly = LW == 1 ? r : (int)__umulhi((unsigned)r, magic_lw), lx = r - ly * LW;
             const int iy = ty0 * p.stride - p.pad + ly, ix = tx0 * p.stride - p.pad + lx;
             const int b = bimg0 + img;
             const int c = c0 + 4 * q;
@@ -663,20 +695,7 @@ __device__ __forceinline__ void conv_lstm_dma_tile(const PT &p, const int bx, co
     }
 
     // ---- LayerNorm statistics of the producing layers (this workgroup's samples only)
-    for (int i = tid; i < p.nseg * p.NI; i += kConvThreads) {
-        const int s = i / p.NI, img = i % p.NI;
-        const auto &sg = p.seg[s];
-        float mean = 0.f, rstd = 1.f;
-        const int b = bimg0 + img;
-        if (sg.ln_part && b < p.B) {
-            long long su = 0, sq = 0;
-            const long long *pp = sg.ln_part + (long long)b * sg.ln_bstride;
-            for (int k = 0; k < sg.ln_nparts; ++k) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
-            ln_from_totals(su, sq, sg.ln_inv_n, mean, rstd);
-        }
-        lnTab[2 * i] = mean;
-        lnTab[2 * i + 1] = rstd;
-    }
+    ln_table(p, bimg0, lnTab);
 
     // ---- this lane's A rows: halo-tile pixel index of GEMM row wave*WROWS + m*32 + n at tap (0, 0)
     const int px_per_img = p.TH * p.TW;

@@ -158,22 +158,29 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
     const int ntiles = tilesX * ((p.H + TS - 1) / TS);
     const int ty0 = (tile / tilesX) * TS, tx0 = (tile % tilesX) * TS;
 
-    if (tid == 0) {
-        long long su = 0, sq = 0;
-        const long long *pp = p.ln_part + (long long)b * p.ln_nparts * 2;
-        for (int k = 0; k < p.ln_nparts; ++k) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
-        ln_from_totals(su, sq, p.ln_inv_n, s_ln[0], s_ln[1]);
-    }
-    if (tid >= 64 && tid < 64 + ND) {
-        const int d = tid - 64;
-        float sc = 1.0f;
-        if (p.prev_sums) {
-            double su = 0.0;
-            const double *pp = p.prev_sums + ((long long)b * ND + d) * ntiles * 2;
-            for (int k = 0; k < ntiles; ++k) su += pp[2 * k];
-            sc = (float)(1.0 / su);
+    // prologue reductions, lanes over the partials (32 LayerNorm partials and 64 tiles per sample at 128x128):
+    // wave 0 the exact LayerNorm statistics, wave (d + 1) & 3 the mass of distribution d (fixed order: lanes
+    // stride the tiles, then the xor butterfly - deterministic)
+    {
+        const int lane_ = tid & 63, wave_ = tid >> 6;
+        if (wave_ == 0) {
+            long long su = 0, sq = 0;
+            const long long *pp = p.ln_part + (long long)b * p.ln_nparts * 2;
+            for (int k = lane_; k < p.ln_nparts; k += 64) { su += pp[2 * k]; sq += pp[2 * k + 1]; }
+            su = wave_sum(su); sq = wave_sum(sq);
+            if (lane_ == 0) ln_from_totals(su, sq, p.ln_inv_n, s_ln[0], s_ln[1]);
         }
-        s_dscale[d] = sc;
+        for (int d = (wave_ + 3) & 3; d < ND; d += 4) {
+            float sc = 1.0f;
+            if (p.prev_sums) {
+                double su = 0.0;
+                const double *pp = p.prev_sums + ((long long)b * ND + d) * ntiles * 2;
+                for (int k = lane_; k < ntiles; k += 64) su += pp[2 * k];
+                su = wave_sum(su);
+                sc = (float)(1.0 / su);
+            }
+            if (lane_ == 0) s_dscale[d] = sc;
+        }
     }
     for (int i = tid; i < kTaps * K; i += 256) s_kern[i] = p.kern[(long long)b * kTaps * K + i];
     __syncthreads();
