@@ -195,6 +195,16 @@ int vf_device_status(vf_handle *h, int32_t *status);
  * are bit-identical with one queue (enable = 0), which is the plain phase order. */
 int vf_set_xcd_queues(vf_handle *h, int32_t enable);
 
+/* Role mode of the persistent rollout (no reference counterpart).  Three resident workgroups per CU instead
+ * of two: the first two to arrive on a CU serve the conv-LSTM items, the third one the light phases (encoder /
+ * decoder convolutions, CDNA FC, compositing), which then run under the matrix work instead of taking turns in
+ * the same slots.  Needs exact fp32, tiles within a third of the LDS (the 128-row conv-LSTM tile then reads its
+ * weights straight from L2) and a launch large enough to fill the chip; otherwise the plain schedule is used.
+ * Placement only: results are bit-identical.  vf_debug_role_census reports whether the last launch ran in role
+ * mode and the histogram of workgroups per CU it saw (hist8[k] = CUs with k arrivals). */
+int vf_set_role_mode(vf_handle *h, int32_t enable);
+int vf_debug_role_census(vf_handle *h, int32_t *active, int32_t *hist8);
+
 /* conv-LSTM tile selection (no reference counterpart): 0 (default) = single input buffer, weights
  * staged through LDS, one barrier per tap; 2 = double-buffered LDS-DMA input staging
  * (global_load_lds_dwordx4) with the weight operand read straight from L2 and one barrier per

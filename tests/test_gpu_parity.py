@@ -474,3 +474,35 @@ def test_legacy_boundary_get_context_rollout_predictions():
     with pytest.raises(ValueError):
         pred.predictor_func()(input_images=frames_ctx, input_state=states_ctx, input_actions=bad[:bs],
                               input_one_hot_images=one_hot)
+
+
+def test_role_mode_is_invisible_in_the_results():
+    """Three workgroups per CU with a dedicated light-phase workgroup (vf_set_role_mode): the same bits as the plain
+    schedule, and the launch really ran that way (every CU saw three workgroups arrive)."""
+    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+    H = W = 64
+    T, M = 4, 96
+    rs = np.random.RandomState(21)
+    ctx = _context(H, W, 2, rs)
+    actions = rs.normal(0, 0.1, (M, T, 4))
+    goal = np.array([[[12, 40], [50, 9]]])
+    pred, weights = _predictor(H, W, T, 2, bs=M)
+    base, base_pt = pred.score(ctx, {'actions': actions}, goal)
+    assert pred.role_census()[0] is False
+    hp = dict(designated_pixel_count=2, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,
+              sequence_length=T + 2, role_mode=1)
+    other = HipVPredEvaluation('', hp).restore(weights)
+    got, got_pt = other.score(ctx, {'actions': actions}, goal)
+    active, hist = other.role_census()
+    assert active, 'the launch did not qualify for the role mode'
+    assert hist[3] >= 200 and sum(hist[4:]) == 0, hist          # three arrivals on (nearly) every CU, never more
+    np.testing.assert_array_equal(got, base)
+    np.testing.assert_array_equal(got_pt, base_pt)
+    out, ref = other(ctx, {'actions': actions}), pred(ctx, {'actions': actions})
+    np.testing.assert_array_equal(out['predicted_frames'], ref['predicted_frames'])
+    np.testing.assert_array_equal(out['predicted_pixel_distributions'], ref['predicted_pixel_distributions'])
+    assert other.device_status() == 0
+    # a launch too small to fill the chip falls back to the plain schedule
+    got_small, _ = other.score(ctx, {'actions': actions[:1]}, goal)
+    np.testing.assert_array_equal(got_small, base[:1])
+    assert other.role_census()[0] is False

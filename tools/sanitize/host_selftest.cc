@@ -16,6 +16,7 @@
 
 #include "../../include/vf_hip.h"
 
+extern "C" int vf_set_role_mode(vf_handle *h, int32_t enable);
 extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared, int64_t *out_items,
                                     uint64_t *out_upload_checksum);
 
@@ -36,16 +37,20 @@ static int run_case(int H, int W, int adim, int sdim, int nd, int nctx, int T, i
     }
     if (vf_load_weights(h, blob.data(), blob.size() - 1) == 0) { std::fprintf(stderr, "short blob accepted\n"); return 1; }
     uint64_t sum = 0;
-    for (int i = 0; i < n_batches; ++i)
+    for (int role = 0; role < 2; ++role) {
+      vf_set_role_mode(h, role);       // role mode: used where the launch qualifies, the plain schedule elsewhere
+      for (int i = 0; i < n_batches; ++i)
         for (int skip = 0; skip < 2; ++skip) {
             int64_t items = 0;
             if (vf_selftest_schedule(h, batches[i], skip, &items, &sum)) {
                 std::fprintf(stderr, "schedule B=%d skip=%d: %s\n", batches[i], skip, vf_last_error());
                 return 1;
             }
-            std::printf("  %dx%d adim %d nd %d ncam %d prec %d  B=%-4d %s: %lld items\n", H, W, adim, nd, ncam,
-                        precision, batches[i], skip ? "cached-context" : "full", (long long)items);
+            std::printf("  %dx%d adim %d nd %d ncam %d prec %d  B=%-4d %s%s: %lld items\n", H, W, adim, nd, ncam,
+                        precision, batches[i], skip ? "cached-context" : "full", role ? " (role mode asked)" : "",
+                        (long long)items);
         }
+    }
     std::printf("  packed-weight checksum %016llx\n", (unsigned long long)sum);
     vf_destroy(h);
     return 0;

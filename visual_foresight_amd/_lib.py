@@ -21,7 +21,7 @@ SOURCES = [os.path.join(_HERE, 'csrc', f) for f in
 EXPORTS = ('vf_abi_version', 'vf_last_error', 'vf_weight_count', 'vf_create', 'vf_destroy',
            'vf_load_weights', 'vf_set_context', 'vf_rollout', 'vf_export', 'vf_register',
            'vf_allgather_scores', 'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile',
-           'vf_set_substreams', 'vf_set_dedup', 'vf_set_persistent', 'vf_set_xcd_queues', 'vf_set_lstm_tile', 'vf_device_status',
+           'vf_set_substreams', 'vf_set_dedup', 'vf_set_persistent', 'vf_set_xcd_queues', 'vf_set_role_mode', 'vf_debug_role_census', 'vf_set_lstm_tile', 'vf_device_status',
            'vf_set_phase_stats', 'vf_debug_phase_stats', 'vf_debug_poison_status')
 ABI_VERSION = 4
 
@@ -109,6 +109,10 @@ def load_library():
     lib.vf_set_persistent.argtypes = [P, ctypes.c_int32]
     lib.vf_set_lstm_tile.argtypes = [P, ctypes.c_int32]
     lib.vf_set_xcd_queues.argtypes = [P, ctypes.c_int32]
+    lib.vf_set_role_mode.argtypes = [P, ctypes.c_int32]
+    lib.vf_set_role_mode.restype = ctypes.c_int
+    lib.vf_debug_role_census.argtypes = [P, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    lib.vf_debug_role_census.restype = ctypes.c_int
     lib.vf_set_xcd_queues.restype = ctypes.c_int
     lib.vf_set_lstm_tile.restype = ctypes.c_int
     lib.vf_device_status.argtypes = [P, ctypes.POINTER(ctypes.c_int32)]

@@ -382,7 +382,10 @@ __device__ __forceinline__ void lstm_split_epilogue(const PT &p, f32x16 (&acc)[1
 // RB < 4 (conv-LSTM, B through LDS only): the workgroup covers RB row blocks of 32 - 64 or 32 rows instead of
 // 128 - and wave w takes row block w % RB and RB of the four gates, for batches so small that the per-sample
 // dependency chain, not the throughput, bounds a rollout; same chunking and K order, i.e. the same bits.
-template <int G, int EPI, int MREP, class PT, int RB = 4>
+// BD (conv-LSTM, 128 rows): read the weight operand straight from L1/L2 instead of staging it through LDS - the
+// same K order, hence the same bits, measured equally fast, and 32 KiB less LDS per workgroup: the tile of the
+// three-workgroups-per-CU role mode of the persistent launch (vf_persistent.h).
+template <int G, int EPI, int MREP, class PT, int RB = 4, bool BD = false>
 __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int by, const int bz,
                                           float *smem) {
     constexpr bool SPLIT = RB < 4;
@@ -394,7 +397,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     // lose more to its per-tap barrier than they gain, so they read B straight from L1/L2
     // (the 256-row conv-LSTM tile reads B directly as well: its input tile needs the LDS, and it must keep the
     // 32-channel chunks of the 128-row tile so that both plans accumulate every output in the same K order)
-    constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1 && !VF_LSTM_B_DIRECT;
+    constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1 && !VF_LSTM_B_DIRECT && !BD;
+    static_assert(!BD || (EPI == EPI_LSTM && MREP == 1 && !SPLIT), "BD is a variant of the 128-row conv-LSTM tile");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     const int wrow0 = SPLIT ? (wave % RB) * 32 : wave * WROWS;     // first GEMM row of this wave

@@ -59,7 +59,13 @@ static const int kEnc00Ch = 16;             // channels of the extra encoder sca
 static const int kNumLn = 11;               // ln1..ln9, lna, lnb
 static const int kMaxSubBatches = 8;
 static const int kSchedRing = 4;            // pinned staging buffers for schedule uploads
-static const int kSyncHead = kQueues * kTicketStride;   // ints in front of the completion counters (ticket heads)
+// ints in front of the completion counters: the ticket heads and the per-CU arrival counters of the role mode
+static const int kSyncHead = kRoles * kQueues * kTicketStride + kCuSlots;
+// Role mode: three resident workgroups per CU must share its 160 KiB of LDS (512-byte granules): what one
+// workgroup's tile workspace may use next to the control block
+// (48 KiB per workgroup: with the full third - 53 KiB - the occupancy query still answers 3, but the third
+// workgroup of most CUs is not placed until another one exits)
+static const size_t kRoleLdsLimit = 48 * 1024 - kCtlWords * sizeof(int) - 16;
 
 // ------------------------------------------------------------------ canonical tensor table
 struct TensorDesc {
@@ -151,6 +157,7 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
                                     // 0 / -1 = the 64- / 32-row conv-LSTM tiles (waves split rows x gates)
     int prec = 0;                   // 1: split-bf16 tile (conv-LSTM only)
     size_t lds_dma = 0;             // conv-LSTM, fp32: LDS bytes of the DMA tile (0: tile not applicable)
+    size_t lds_bd = 0;              // conv-LSTM, fp32, 128 rows: LDS bytes with the weights read from L2 (0: n/a)
     int NI, TH, TW, RPI, tilesY, tilesX;
     int ncg, Cout;
     int nsplit, chunks_per_split, n_valid;
@@ -213,6 +220,7 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
     l.stats_nparts = (l.NI == 1 ? l.tilesY * l.tilesX : 1) * l.ncg;
     // second-generation conv-LSTM tile (vf_conv_mfma.h, conv_lstm_dma_tile): same packing, needs 32-channel chunks
     l.lds_dma = 0;
+    l.lds_bd = (l.mode == PACK_LSTM && l.prec == 0 && l.mrep == 1) ? l.lds_bytes - (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
     if (l.mode == PACK_LSTM && l.prec == 0 && KC == 32 && l.mrep == 1 && l.stride == 1) {   // (128-row plan only)
         const int LH = l.TH - 1 + l.KH, LW = l.TW - 1 + l.KW;
         const size_t need = lstm_dma_lds_bytes(l.NI, LH, LW);
@@ -418,7 +426,8 @@ struct vf_handle {
         PhaseDesc *d_phases = nullptr;
         int B = -1, items = 0, counters = 0, phases = 0;
         bool dedup = true, lstm_dma = false;
-        int xcd_queues = 0, nq = 1, total_q[kQueues] = {0};
+        int xcd_queues = 0, nq = 1, total_q[kRoles][kQueues] = {{0}};
+        bool role_mode = false, roles2 = false;
         double flops = 0.0;
         size_t lds = 0;
         std::vector<int> types, nitems;
@@ -431,6 +440,8 @@ struct vf_handle {
     int stage_next = 0;
     int *d_sync = nullptr;              // [kQueues ticket heads, one cache line each | counters...]
     int xcd_queues = kQueues;           // ticket queues of the persistent launch (vf_set_xcd_queues): kQueues or 1
+    // role mode (vf_set_role_mode, vf_persistent.h): three workgroups per CU, the third one serving the light phases
+    bool role_mode = false, role_ok = false, role_active = false;
     int *d_status = nullptr;            // sticky failure word of the persistent kernel
     unsigned long long *d_stats = nullptr;  // per-phase wait/run ticks (vf_set_phase_stats)
     bool phase_stats = false;
@@ -635,7 +646,7 @@ struct SegArg {
 };
 
 static ConvParams make_params(const ConvLayer &l, const LayerW &w, int B, const SegArg &s0, const SegArg *s1,
-                              const float *zeros = nullptr, bool lstm_dma = false) {
+                              const float *zeros = nullptr, bool lstm_dma = false, bool b_direct = false) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
     const SegArg *sa[2] = {&s0, s1};
@@ -657,7 +668,7 @@ static ConvParams make_params(const ConvLayer &l, const LayerW &w, int B, const 
     p.chunks_per_split = l.chunks_per_split; p.n_valid = l.n_valid;
     p.stats_nparts = l.stats_nparts;    // row stride of p.stats; the conv-LSTM plans overwrite it with st_rows[k]
     p.zeros = zeros;
-    p.tile_variant = l.prec == 1 ? 1 : (lstm_dma && l.lds_dma ? 2 : 0);
+    p.tile_variant = l.prec == 1 ? 1 : (b_direct && l.lds_bd ? 3 : (lstm_dma && l.lds_dma ? 2 : 0));
     return p;
 }
 
@@ -804,6 +815,13 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
             if (h->quarter_ok[k]) h->max_lds = std::max(h->max_lds, h->lstm_quarter[k].lds_bytes);
         }
     h->max_lds += 16;
+    // role mode (three workgroups per CU): exact fp32 only (the split-bf16 tile needs more LDS), every light layer and
+    // the weights-from-L2 conv-LSTM tile within a third of the LDS; the occupancy of the 168-VGPR kernel is checked below
+    h->role_ok = cfg->precision == 0;
+    for (const ConvLayer *l : h->layers) {
+        if (l->mode == PACK_LSTM) h->role_ok = h->role_ok && l->lds_bd > 0 && l->lds_bd <= kRoleLdsLimit;
+        else h->role_ok = h->role_ok && l->lds_bytes <= kRoleLdsLimit;
+    }
 
 #define VF_ALLOC(ptr, n)                           \
     do {                                           \
@@ -928,6 +946,18 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
             h->n_cu = prop.multiProcessorCount;
     }
     if ((rc = configure_kernels(h))) { vf_destroy(h); return rc; }
+    if (h->role_ok) {       // do three workgroups of the 168-VGPR kernel really fit one CU?
+        int nb = 0;
+        const size_t lds3 = kRoleLdsLimit + 16 + kCtlWords * sizeof(int);
+        hipError_t e;
+        switch (h->ND) {
+            case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_persistent_kernel<1, 3>, kConvThreads, lds3); break;
+            case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_persistent_kernel<2, 3>, kConvThreads, lds3); break;
+            case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_persistent_kernel<3, 3>, kConvThreads, lds3); break;
+            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_persistent_kernel<4, 3>, kConvThreads, lds3); break;
+        }
+        h->role_ok = e == hipSuccess && nb >= 3;
+    }
 #endif
     *out = h;
     return VF_OK;
@@ -1153,6 +1183,7 @@ struct LaunchSink {
 #endif
 
 struct ScheduleSink {
+    bool role_mode = false;     // light phases get role 1 (vf_persistent.h)
     std::vector<PhaseDesc> phases;
     int next_ticket = 0, next_counter = 0;      // tickets are re-assigned when the views are merged
     double flops = 0.0;         // algorithmic FLOPs of all MFMA (conv / FC) phases
@@ -1191,7 +1222,8 @@ struct ScheduleSink {
         P.whole = type == PH_FC_PARTIAL;
         P.mrep = l.mrep;
         P.prec = p.tile_variant;
-        max_lds = std::max(max_lds, p.tile_variant == 2 ? l.lds_dma : l.lds_bytes);
+        max_lds = std::max(max_lds, p.tile_variant == 2 ? l.lds_dma : (p.tile_variant == 3 ? l.lds_bd : l.lds_bytes));
+        P.role = (role_mode && type != PH_LSTM) ? 1 : 0;
         const double rows = (double)p.B * l.Hout * l.Wout;
         const double taps = l.mode == PACK_CONVT ? 9.0 / 4.0 * 4.0 : (double)l.KH * l.KW;   // real taps
         flops += 2.0 * rows * taps * (l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0)) *
@@ -1201,19 +1233,19 @@ struct ScheduleSink {
     int sa(const SaParams &p, std::initializer_list<int> deps) {
         PhaseDesc P;
         memset(&P, 0, sizeof(P));
-        P.type = PH_SA; P.sa = p; P.B = p.B;
+        P.type = PH_SA; P.sa = p; P.B = p.B; P.role = role_mode ? 1 : 0;
         return add(P, (p.B + kSaPerItem - 1) / kSaPerItem, p.B, deps);
     }
     int fin(const FinParams &p, std::initializer_list<int> deps) {
         PhaseDesc P;
         memset(&P, 0, sizeof(P));
-        P.type = PH_CDNA_FIN; P.fin = p; P.B = p.B;
+        P.type = PH_CDNA_FIN; P.fin = p; P.B = p.B; P.role = role_mode ? 1 : 0;
         return add(P, p.B, p.B, deps);
     }
     int composite(const CompositeParams &p, int ntiles, int view, std::initializer_list<int> deps) {
         PhaseDesc P;
         memset(&P, 0, sizeof(P));
-        P.type = PH_COMPOSITE; P.comp = p; P.B = p.B; P.gx = ntiles; P.view = view;
+        P.type = PH_COMPOSITE; P.comp = p; P.B = p.B; P.gx = ntiles; P.view = view; P.role = role_mode ? 1 : 0;
         return add(P, ntiles * p.B, p.B, deps);
     }
     static bool failed(int rc) { return rc < 0; }
@@ -1243,7 +1275,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
     const int *L = kLstmSizes;
     const int lh[7] = {H2, H2, H4, H4, H8, H4, H2}, lw[7] = {W2, W2, W4, W4, W8, W4, W2};
     auto params = [&](const ConvLayer &l, int Bp, const SegArg &s0, const SegArg *s1) {
-        return make_params(l, vd.lw[l.id], Bp, s0, s1, h->d_zeros, h->lstm_dma);
+        return make_params(l, vd.lw[l.id], Bp, s0, s1, h->d_zeros, h->lstm_dma, h->role_active);
     };
 
     // tile plan of conv-LSTM k for a phase of Bp samples: the 256-row plan once the phase has many more items than
@@ -1260,6 +1292,10 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         int want = beff >= 500.0 || (beff >= 150.0 && k < 2) ? 2
                    : (n128 <= h->n_cu ? 4 : (n128 <= 2 * h->n_cu ? 3 : 1));
         if (h->mrep_override[k]) want = h->mrep_override[k];
+        if (h->role_active) {       // three workgroups per CU: only tiles that fit a third of the LDS and 168 VGPRs
+            if (want >= 3 && h->half_ok[k] && h->lstm_half[k].lds_bytes <= kRoleLdsLimit) return h->lstm_half[k];
+            return h->lstm[k];
+        }
         if (want == 2 && h->big_ok[k]) return h->lstm_big[k];
         if (want == 4 && h->quarter_ok[k]) return h->lstm_quarter[k];
         if (want >= 3 && h->half_ok[k]) return h->lstm_half[k];
@@ -1461,23 +1497,28 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
 struct BuiltSchedule {
     std::vector<PhaseDesc> phases;
     int items = 0, counters = 0;
-    int nq = 1, total_q[kQueues] = {0};
+    int nq = 1, total_q[kRoles][kQueues] = {{0}};
+    bool roles2 = false;
     double flops = 0.0;
     size_t lds = 0;
 };
 
 // One phase list per view (own weights, own buffers, own counters), merged phase by phase so that
 // the views advance together and a phase's items of both views are neighbours in ticket order.
-static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &out) {
+static int build_schedule_as(vf_handle *h, int B, bool skip_shared, BuiltSchedule &out, bool roles2) {
     std::vector<ScheduleSink> sinks(h->ncam);
     int counters = 0, rc;
     out.flops = 0.0;
+    out.roles2 = roles2;
     size_t max_lds = 0;
     for (int v = 0; v < h->ncam; ++v) {
         sinks[v].next_counter = counters;
-        if ((rc = emit_rollout(h, v, make_view(h, v, h->actions_buf, 0), h->shared_views[(size_t)v * kMaxSubBatches],
-                               B, nullptr, sinks[v], skip_shared)) < 0)
-            return rc;
+        sinks[v].role_mode = roles2;
+        h->role_active = roles2;        // tile plans and variants of the emission below
+        rc = emit_rollout(h, v, make_view(h, v, h->actions_buf, 0), h->shared_views[(size_t)v * kMaxSubBatches],
+                          B, nullptr, sinks[v], skip_shared);
+        h->role_active = false;
+        if (rc < 0) return rc;
         counters = sinks[v].next_counter;
         out.flops += sinks[v].flops;
         max_lds = std::max(max_lds, sinks[v].max_lds);
@@ -1494,7 +1535,8 @@ static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &
     // tile within the sample, cg = output-channel group.  Launches too small to occupy every XCD keep one queue.
     const int nq = (h->xcd_queues > 1 && ticket >= 4 * h->n_cu) ? kQueues : 1;
     out.nq = nq;
-    for (int q = 0; q < kQueues; ++q) out.total_q[q] = 0;
+    for (int r = 0; r < kRoles; ++r)
+        for (int q = 0; q < kQueues; ++q) out.total_q[r][q] = 0;
     for (PhaseDesc &P : out.phases) {
         P.q_gy = 1; P.q_inner = 1;
         if (nq > 1) {
@@ -1507,18 +1549,32 @@ static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &
             }
         }
         const int units = P.n_items / (P.q_gy * P.q_inner), per = nq / P.q_gy;
-        for (int q = 0; q < kQueues; ++q) {
-            const int qb = q / P.q_gy;
-            P.first_q[q] = out.total_q[q < nq ? q : 0];
-            P.n_q[q] = (q < nq && qb < units) ? ((units - qb + per - 1) / per) * P.q_inner : 0;
-            if (q < nq) out.total_q[q] += P.n_q[q];
-        }
+        // the phase lives in the queues of its role; in the other role's queues it is an empty range at their
+        // running total, so a workgroup scanning those queues walks straight past it
+        for (int r = 0; r < kRoles; ++r)
+            for (int q = 0; q < kQueues; ++q) {
+                const int qb = q / P.q_gy;
+                P.first_q[r][q] = out.total_q[r][q < nq ? q : 0];
+                P.n_q[r][q] = (r == P.role && q < nq && qb < units) ? ((units - qb + per - 1) / per) * P.q_inner : 0;
+                if (q < nq) out.total_q[r][q] += P.n_q[r][q];
+            }
     }
     out.counters = counters;
     out.lds = std::max(max_lds, (size_t)composite_lds_floats<kMaxDesig, 10>() * 4) + 16;
     if (out.phases.size() > h->sched_capacity || (size_t)counters > h->counter_capacity)
         return fail(VF_ERR_INVALID, "persistent schedule exceeds its preallocated capacity");
     return VF_OK;
+}
+
+// Role mode is used when it is asked for (vf_set_role_mode), the engine can run three workgroups per CU (exact
+// fp32, occupancy checked at vf_create) and this launch's tiles fit a third of the LDS; otherwise the plain schedule.
+static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &out) {
+    if (h->role_mode && h->role_ok) {
+        int rc = build_schedule_as(h, B, skip_shared, out, true);
+        if (rc) return rc;
+        if (out.lds <= kRoleLdsLimit + 16 && out.items >= 6 * h->n_cu && out.nq == kQueues) return VF_OK;
+    }
+    return build_schedule_as(h, B, skip_shared, out, false);
 }
 
 #ifdef VF_HOST_SELFTEST
@@ -1587,37 +1643,52 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
         if (!ok) return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + " points outside the handle's buffers");
     }
     if (ticket != bs.items) return fail(VF_ERR_INVALID, "item count mismatch");
-    // the queue dealing must be a bijection: walking every queue position with the device's formula
-    // (rollout_persistent_kernel) visits each item of each phase exactly once, queues in phase order
+    // the queue dealing must be a bijection: walking every queue position of a phase's role with the device's
+    // formula (rollout_persistent_kernel) visits each item of each phase exactly once, queues in phase order; in the
+    // other role's queues the phase is an empty range at their running total
     {
-        int head[kQueues] = {0}, total = 0;
+        int head[kRoles][kQueues] = {{0}}, total = 0;
         std::vector<char> seen;
         for (size_t i = 0; i < bs.phases.size(); ++i) {
             const PhaseDesc &P = bs.phases[i];
             if (P.q_gy < 1 || P.q_inner < 1 || bs.nq % P.q_gy) return fail(VF_ERR_INVALID, "bad dealing rule");
+            if (P.role < 0 || P.role >= kRoles || (!bs.roles2 && P.role)) return fail(VF_ERR_INVALID, "bad role");
+            if (bs.roles2 && (P.role == 0) != (P.type == PH_LSTM)) return fail(VF_ERR_INVALID, "role does not match the phase type");
             seen.assign((size_t)P.n_items, 0);
-            for (int q = 0; q < bs.nq; ++q) {
-                if (P.first_q[q] != head[q]) return fail(VF_ERR_INVALID, "queue ranges are not contiguous");
-                for (int lq = 0; lq < P.n_q[q]; ++lq) {
-                    const int per = bs.nq / P.q_gy, qb = q / P.q_gy, cg = q - qb * P.q_gy;
-                    const int grp = lq / P.q_inner, inner = lq - grp * P.q_inner;
-                    const int local = ((grp * per + qb) * P.q_inner + inner) * P.q_gy + cg;
-                    if (local < 0 || local >= P.n_items || seen[(size_t)local])
-                        return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": dealing is not a bijection");
-                    seen[(size_t)local] = 1;
+            for (int r = 0; r < kRoles; ++r)
+                for (int q = 0; q < bs.nq; ++q) {
+                    if (P.first_q[r][q] != head[r][q]) return fail(VF_ERR_INVALID, "queue ranges are not contiguous");
+                    if (r != P.role && P.n_q[r][q]) return fail(VF_ERR_INVALID, "items in a queue of the other role");
+                    for (int lq = 0; lq < P.n_q[r][q]; ++lq) {
+                        const int per = bs.nq / P.q_gy, qb = q / P.q_gy, cg = q - qb * P.q_gy;
+                        const int grp = lq / P.q_inner, inner = lq - grp * P.q_inner;
+                        const int local = ((grp * per + qb) * P.q_inner + inner) * P.q_gy + cg;
+                        if (local < 0 || local >= P.n_items || seen[(size_t)local])
+                            return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": dealing is not a bijection");
+                        seen[(size_t)local] = 1;
+                    }
+                    head[r][q] += P.n_q[r][q];
+                    total += P.n_q[r][q];
                 }
-                head[q] += P.n_q[q];
-                total += P.n_q[q];
-            }
-            for (int q = bs.nq; q < kQueues; ++q)
-                if (P.n_q[q]) return fail(VF_ERR_INVALID, "items in an unused queue");
+            for (int r = 0; r < kRoles; ++r)
+                for (int q = bs.nq; q < kQueues; ++q)
+                    if (P.n_q[r][q]) return fail(VF_ERR_INVALID, "items in an unused queue");
+            if (bs.roles2 && P.type == PH_LSTM && P.prec != 3 && P.mrep != 0)
+                return fail(VF_ERR_INVALID, "role mode with a conv-LSTM tile that needs more than a third of the LDS");
         }
-        for (int q = 0; q < kQueues; ++q)
-            if (head[q] != bs.total_q[q] && q < bs.nq) return fail(VF_ERR_INVALID, "queue totals mismatch");
+        for (int r = 0; r < kRoles; ++r)
+            for (int q = 0; q < bs.nq; ++q)
+                if (head[r][q] != bs.total_q[r][q]) return fail(VF_ERR_INVALID, "queue totals mismatch");
         if (total != bs.items) return fail(VF_ERR_INVALID, "dealt item count mismatch");
+        if (bs.roles2 && bs.lds > kRoleLdsLimit + 16) return fail(VF_ERR_INVALID, "role mode beyond its LDS budget");
     }
     if (out_items) *out_items = bs.items;
     if (out_upload_checksum) *out_upload_checksum = h->upload_checksum;
+    return VF_OK;
+}
+extern "C" int vf_set_role_mode(vf_handle *h, int32_t enable) {     // (the device build defines it further down)
+    if (!h) return fail(VF_ERR_INVALID, "null handle");
+    h->role_mode = enable != 0;
     return VF_OK;
 }
 #else   // ------------------------------------------------------------------ device execution
@@ -1680,7 +1751,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     const bool skip_shared = shared_cache_hit(h, cfg);
     vf_handle::SchedCache &sc_host = h->sched[skip_shared ? 1 : 0];
     if (sc_host.B != B || sc_host.dedup != h->dedup || sc_host.lstm_dma != h->lstm_dma ||
-        sc_host.xcd_queues != h->xcd_queues) {
+        sc_host.xcd_queues != h->xcd_queues || sc_host.role_mode != h->role_mode) {
         BuiltSchedule bs;
         if ((rc = build_schedule(h, B, skip_shared, bs))) return rc;
         // Upload without synchronising the caller's stream: the copy is stream-ordered behind the
@@ -1696,10 +1767,11 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         VF_HIP_CHECK(hipEventRecord(h->stage_done[slot], st));
         h->stage_used[slot] = true;
         sc_host.B = B; sc_host.dedup = h->dedup; sc_host.lstm_dma = h->lstm_dma;
-        sc_host.xcd_queues = h->xcd_queues;
+        sc_host.xcd_queues = h->xcd_queues; sc_host.role_mode = h->role_mode; sc_host.roles2 = bs.roles2;
         sc_host.items = bs.items; sc_host.counters = bs.counters;
         sc_host.nq = bs.nq;
-        for (int q = 0; q < kQueues; ++q) sc_host.total_q[q] = bs.total_q[q];
+        for (int r = 0; r < kRoles; ++r)
+            for (int q = 0; q < kQueues; ++q) sc_host.total_q[r][q] = bs.total_q[r][q];
         sc_host.phases = (int)bs.phases.size();
         sc_host.types.clear(); sc_host.nitems.clear();
         for (const PhaseDesc &P : bs.phases) { sc_host.types.push_back(P.type); sc_host.nitems.push_back(P.n_items); }
@@ -1716,7 +1788,10 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     sc.phases = sc_host.d_phases; sc.n_phases = sc_host.phases; sc.total_items = sc_host.items;
     sc.ticket = h->d_sync; sc.counters = h->d_sync + kSyncHead; sc.status = h->d_status;
     sc.nq = sc_host.nq;
-    for (int q = 0; q < kQueues; ++q) sc.total_q[q] = sc_host.total_q[q];
+    sc.roles = sc_host.roles2 ? kRoles : 1;
+    sc.cu_arrivals = h->d_sync + kRoles * kQueues * kTicketStride;
+    for (int r = 0; r < kRoles; ++r)
+        for (int q = 0; q < kQueues; ++q) sc.total_q[r][q] = sc_host.total_q[r][q];
     sc.stats = nullptr;
     sc.nd = h->ND;
     for (int i = 0; i < h->ncam * h->ND * 2; ++i) sc.goal[i] = goal_pix[i];
@@ -1724,10 +1799,12 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         VF_HIP_CHECK(hipMemsetAsync(h->d_stats, 0, h->sched_capacity * 2 * sizeof(unsigned long long), st));
         sc.stats = h->d_stats;
     }
+
     // resident workgroups per CU: bounded by the LDS a workgroup needs (160 KiB per CU)
     const size_t lds = sc_host.lds + kCtlWords * sizeof(int);
     const int by_lds = (int)std::max<size_t>(1, (160 * 1024) / lds);
-    const int grid = std::min(sc_host.items, h->n_cu * std::min(h->persist_wgs_per_cu, by_lds));
+    const int wgs_per_cu = sc_host.roles2 ? 3 : std::min(h->persist_wgs_per_cu, by_lds);
+    const int grid = std::min(sc_host.items, h->n_cu * wgs_per_cu);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) {
         while (h->ev_pool.size() < h->ev_used + 2) {
@@ -1738,11 +1815,20 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         e0 = h->ev_pool[h->ev_used]; e1 = h->ev_pool[h->ev_used + 1];
         VF_HIP_CHECK(hipEventRecord(e0, st));
     }
-    switch (h->ND) {
-        case 1: rc = launch_persistent_t<1>(h, sc, grid, lds, st); break;
-        case 2: rc = launch_persistent_t<2>(h, sc, grid, lds, st); break;
-        case 3: rc = launch_persistent_t<3>(h, sc, grid, lds, st); break;
-        default: rc = launch_persistent_t<4>(h, sc, grid, lds, st); break;
+    if (sc_host.roles2) {
+        switch (h->ND) {
+            case 1: rc = launch_persistent_w<1, 3>(sc, grid, lds, st); break;
+            case 2: rc = launch_persistent_w<2, 3>(sc, grid, lds, st); break;
+            case 3: rc = launch_persistent_w<3, 3>(sc, grid, lds, st); break;
+            default: rc = launch_persistent_w<4, 3>(sc, grid, lds, st); break;
+        }
+    } else {
+        switch (h->ND) {
+            case 1: rc = launch_persistent_t<1>(h, sc, grid, lds, st); break;
+            case 2: rc = launch_persistent_t<2>(h, sc, grid, lds, st); break;
+            case 3: rc = launch_persistent_t<3>(h, sc, grid, lds, st); break;
+            default: rc = launch_persistent_t<4>(h, sc, grid, lds, st); break;
+        }
     }
     if (rc) return rc;
     if (h->profiling) {
@@ -1823,6 +1909,27 @@ int vf_set_persistent(vf_handle *h, int32_t enable) {
 #ifdef VF_DEBUG_KNOBS
     if (const char *e = getenv("VF_PERSIST_WGS_PER_CU")) h->persist_wgs_per_cu = std::max(1, std::min(4, atoi(e)));
 #endif
+    return VF_OK;
+}
+
+int vf_set_role_mode(vf_handle *h, int32_t enable) {
+    if (!h) return fail(VF_ERR_INVALID, "null handle");
+    h->role_mode = enable != 0;
+    return VF_OK;
+}
+
+int vf_debug_role_census(vf_handle *h, int32_t *active, int32_t *hist8) {
+    if (!h || !active || !hist8) return fail(VF_ERR_INVALID, "null argument");
+#ifndef VF_HOST_SELFTEST
+    VF_HIP_CHECK(hipSetDevice(h->cfg.device));
+    VF_HIP_CHECK(hipDeviceSynchronize());
+    std::vector<int> arr(kCuSlots);
+    VF_HIP_CHECK(hipMemcpy(arr.data(), h->d_sync + kRoles * kQueues * kTicketStride, kCuSlots * sizeof(int),
+                           hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) hist8[i] = 0;
+    for (int v : arr) ++hist8[std::min(std::max(v, 0), 7)];
+#endif
+    *active = h->sched[h->last_sched].roles2 ? 1 : 0;
     return VF_OK;
 }
 

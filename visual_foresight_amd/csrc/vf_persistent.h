@@ -31,6 +31,8 @@ enum PhaseType {
 constexpr int kMaxDeps = 3;
 constexpr int kQueues = 8;                  // one ticket queue per XCD
 constexpr int kTicketStride = 32;           // ints between ticket heads (128 B)
+constexpr int kRoles = 2;                   // workgroup roles of the role mode: 0 conv-LSTM items, 1 everything else
+constexpr int kCuSlots = kQueues * 256;     // per-CU arrival counters of the role mode, indexed by (XCC_ID, HW_ID[15:8])
 constexpr int kSaPerItem = 4;               // samples per PH_SA item (one per wave)
 constexpr unsigned kSpinLimit = 1u << 26;   // polls before a waiting item gives up (~ seconds)
 
@@ -43,7 +45,9 @@ struct PhaseDep {
 struct PhaseDesc {
     int type;
     int first_ticket, n_items;          // position in the global phase order (bookkeeping, statistics)
-    int first_q[kQueues], n_q[kQueues]; // ticket range of this phase in each XCD's queue
+    int role;                           // which workgroups serve this phase (0 unless the launch runs in role mode)
+    int first_q[kRoles][kQueues], n_q[kRoles][kQueues];    // ticket range of this phase in each XCD's queue of its
+                                        // role; in the other role's queues it is empty and sits at their running total
     int q_gy, q_inner;                  // dealing rule: item = (unit * q_inner + inner) * q_gy + cg  ->  queue
                                         // (unit % (nq / q_gy)) * q_gy + cg, so a channel group's weight slice and a
                                         // sample's tiles stay inside one XCD's L2
@@ -52,7 +56,7 @@ struct PhaseDesc {
     int NI, tiles_per_img;  // conv phases: how an item maps to samples
     int whole;              // 1: completion is counted once per item on counter 0
     int mrep;               // MFMA row blocks per wave of this conv phase (1 or 2; 0 / -1: the 64- / 32-row conv-LSTM tiles)
-    int prec;               // conv-LSTM tile: 0 fp32 (B through LDS), 1 split-bf16, 2 fp32 DMA tile
+    int prec;               // conv-LSTM tile: 0 fp32 (B through LDS), 1 split-bf16, 2 fp32 DMA tile, 3 fp32 with B from L2
     int view;               // camera view this phase belongs to (selects the goal pixels of PH_COMPOSITE)
     int cnt_base;
     int ndep;
@@ -70,9 +74,12 @@ struct Schedule {
     const PhaseDesc *phases;
     int n_phases;
     int total_items;
-    int *ticket;            // [kQueues][kTicketStride] ticket heads, one per XCD queue (own cache lines)
-    int total_q[kQueues];   // items per queue
-    int nq;                 // queues in use: kQueues, or 1 (plain phase order)
+    int *ticket;            // [kRoles][kQueues][kTicketStride] ticket heads, one per role and XCD (own cache lines)
+    int total_q[kRoles][kQueues];   // items per queue
+    int nq;                 // XCD queues in use: kQueues, or 1 (plain phase order)
+    int roles;              // 1: every workgroup serves every phase; 2: role mode (three workgroups per CU: the first
+                            //    two to arrive on a CU take conv-LSTM items, the third everything else)
+    int *cu_arrivals;       // [kCuSlots] role mode: workgroups that have started on each CU (zeroed per launch)
     int *counters;          // completion counters
     int *status;            // [1] sticky: set non-zero when an item gave up waiting; cleared by the host
                             //     only after it has been read (vf_device_status)
@@ -129,6 +136,9 @@ template <int G, int EPI, int MREP>
 __device__ __noinline__ void conv_tile_call(const ConvParams *p, int bx, int by, int bz) {
     conv_tile<G, EPI, MREP>(const_params(p), bx, by, bz, tile_lds());
 }
+__device__ __noinline__ void lstm_bd_tile_call(const ConvParams *p, int bx, int by) {
+    conv_tile<4, EPI_LSTM, 1, const VF_CONST_AS ConvParams, 4, true>(const_params(p), bx, by, 0, tile_lds());
+}
 template <int RB>
 __device__ __noinline__ void lstm_split_tile_call(const ConvParams *p, int bx, int by) {
     conv_tile<4, EPI_LSTM, 1, const VF_CONST_AS ConvParams, RB>(const_params(p), bx, by, 0, tile_lds());
@@ -180,32 +190,56 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
     const int nq = sched.nq;
     const int q_own = (int)(xcc & (unsigned)(nq - 1));
 
+    // Role mode (three resident workgroups per CU): the light phases - encoder / decoder convs, FC, compositing:
+    // 4 % of the FLOPs but 13 % of the slot time, all staging and latency - get their own workgroup on every CU, which
+    // runs them under the matrix work of the two conv-LSTM workgroups instead of taking a turn in their slots.  The
+    // role follows the order of arrival on the CU (the first workgroup of a CU is its light one) and only decides
+    // which queues a workgroup prefers: once they are empty it serves the other role's, so any placement is correct.
+    int role_own = 0;
+    if (sched.roles > 1) {
+        if (tid == 0) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            const int slot = (int)((xcc & (kQueues - 1)) * 256u + ((hwid >> 8) & 255u));
+            // the FIRST workgroup of a CU is its light one: every CU that runs anything has one, so a launch whose
+            // third workgroups are placed late (or never) still makes progress
+            s_ctl[3] = (atomicAdd(sched.cu_arrivals + slot, 1) % 3 == 0) ? 1 : 0;
+        }
+        __syncthreads();
+        role_own = s_ctl[3];
+    }
+
     for (;;) {
         [[maybe_unused]] const unsigned long long ts_top = VF_TS_NOW();
         __syncthreads();                    // previous item fully retired (LDS reusable)
         if (tid == 0) {
-            int qq = q_own, t = 0, tries = 0;
-            for (; tries < nq; ++tries) {
-                t = atomicAdd(sched.ticket + qq * kTicketStride, 1);
-                if (t < sched.total_q[qq]) break;
-                qq = (qq + 1) & (nq - 1);
+            int t = -1, qq = q_own, rr = role_own;
+            for (int ro = 0; ro < sched.roles && t < 0; ++ro) {
+                rr = role_own ^ ro;
+                qq = q_own;
+                for (int tries = 0; tries < nq; ++tries) {
+                    const int cand = atomicAdd(sched.ticket + (rr * kQueues + qq) * kTicketStride, 1);
+                    if (cand < sched.total_q[rr][qq]) { t = cand; break; }
+                    qq = (qq + 1) & (nq - 1);
+                }
             }
-            s_ctl[0] = tries < nq ? t : -1;
-            s_ctl[2] = qq;
+            s_ctl[0] = t;
+            s_ctl[2] = rr * kQueues + qq;
         }
         __syncthreads();
         const int t = s_ctl[0];
         if (t < 0) break;
-        const int qq = s_ctl[2];
-        if (qq != q_own) ph = 0;            // stolen ticket (tail of the launch): look its phase up from the start
-        while (t >= phases[ph].first_q[qq] + phases[ph].n_q[qq]) ++ph;
+        const int rq = s_ctl[2], rr = rq / kQueues, qq = rq - rr * kQueues;
+        const bool own = rq == role_own * kQueues + q_own;
+        if (!own) ph = 0;                   // stolen ticket (tail of the launch): look its phase up from the start
+        while (t >= phases[ph].first_q[rr][qq] + phases[ph].n_q[rr][qq]) ++ph;
         const int ph_run = ph;
         const PhaseDesc &P = phases[ph_run];
-        if (qq != q_own) ph = 0;            // the cursor is only monotone within one queue
+        if (!own) ph = 0;                   // the cursor is only monotone within one queue
         // queue position -> item of the phase
         int local;
         {
-            const int lq = t - P.first_q[qq];
+            const int lq = t - P.first_q[rr][qq];
             const int per = nq / P.q_gy, qb = qq / P.q_gy, cg = qq - qb * P.q_gy;
             const int grp = lq / P.q_inner, inner = lq - grp * P.q_inner;
             local = ((grp * per + qb) * P.q_inner + inner) * P.q_gy + cg;
@@ -265,6 +299,8 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
                         lstm_split_tile_call<2>(&P.conv, bx, by);
                     } else if (P.mrep < 0) {
                         lstm_split_tile_call<1>(&P.conv, bx, by);
+                    } else if (P.prec == 3) {
+                        lstm_bd_tile_call(&P.conv, bx, by);
                     } else if (P.prec == 2) {
                         lstm_dma_tile_call(&P.conv, bx, by);
                     } else if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);

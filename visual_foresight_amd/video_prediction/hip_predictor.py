@@ -85,6 +85,7 @@ class HipVPredEvaluation(object):
         self.set_persistent(int(hp.get('persistent', os.environ.get('VF_PERSISTENT', 1))))
         self.set_lstm_tile(int(hp.get('lstm_tile', os.environ.get('VF_LSTM_TILE', 0))))
         self.set_xcd_queues(int(hp.get('xcd_queues', os.environ.get('VF_XCD_QUEUES', 1))))
+        self.set_role_mode(int(hp.get('role_mode', os.environ.get('VF_ROLE_MODE', 0))))
         self.weights = None
         self._ctx_key = None
         self._last_M = 0
@@ -119,6 +120,17 @@ class HipVPredEvaluation(object):
         """One ticket queue per XCD (default) or plain phase order; placement only, bit-identical results."""
         _lib.check(self._libh.vf_set_xcd_queues(self._handle, int(bool(enable))))
         self.xcd_queues = bool(enable)
+
+    def set_role_mode(self, enable):
+        """Three workgroups per CU, the third one serving the light phases (vf_set_role_mode); bit-identical results."""
+        _lib.check(self._libh.vf_set_role_mode(self._handle, int(bool(enable))))
+        self.role_mode = bool(enable)
+
+    def role_census(self):
+        """-> (role mode active in the last launch, [CUs with k workgroup arrivals for k = 0..7])."""
+        active, hist = ctypes.c_int32(), (ctypes.c_int32 * 8)()
+        _lib.check(self._libh.vf_debug_role_census(self._handle, ctypes.byref(active), hist))
+        return bool(active.value), list(hist)
 
     def set_lstm_tile(self, variant):
         """conv-LSTM tile: 0 = weights through LDS, barrier per tap (default); 2 = LDS-DMA double-buffered input
