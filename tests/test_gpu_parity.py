@@ -506,3 +506,12 @@ def test_role_mode_is_invisible_in_the_results():
     got_small, _ = other.score(ctx, {'actions': actions[:1]}, goal)
     np.testing.assert_array_equal(got_small, base[:1])
     assert other.role_census()[0] is False
+
+
+def test_float16_conf_key_selects_the_reduced_precision_mode():
+    """The reference's `'float16' in conf` switch (setup_predictor.py:92-95) maps to the split-bf16 mode."""
+    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+    hp = dict(designated_pixel_count=1, run_batch_size=4, image_height=32, image_width=32, sequence_length=4)
+    assert HipVPredEvaluation('', dict(hp, float16='')).precision == 1
+    assert HipVPredEvaluation('', dict(hp, float16='', precision='fp32')).precision == 0
+    assert HipVPredEvaluation('', hp).precision == (1 if __import__('os').environ.get('VF_PRECISION') == 'bf16x6' else 0)

@@ -73,7 +73,11 @@ class HipVPredEvaluation(object):
         c = self.cfg
         # 'fp32' (default): exact fp32 MFMA.  'bf16x6': fp32 emulated by six bf16 MFMA products in the
         # conv-LSTM gate GEMMs (fp32-class accuracy, not bit-identical to 'fp32').
-        precision = hp.get('precision', os.environ.get('VF_PRECISION', 'fp32'))
+        # The reference's reduced-precision switch is the bare key 'float16' in the predictor conf
+        # (video_prediction/setup_predictor.py:92-95: placeholders and model in tf.float16).  Its counterpart here is
+        # the split-bf16 mode: the same kind of opt-in for speed, but with fp32-class accuracy.
+        default_precision = 'bf16x6' if 'float16' in hp else os.environ.get('VF_PRECISION', 'fp32')
+        precision = hp.get('precision', default_precision)
         self.precision = {'fp32': 0, '0': 0, 0: 0, 'bf16x6': 1, '1': 1, 1: 1}[precision]
         self._c_cfg = _lib.VfConfig(c.height, c.width, c.adim, c.sdim, c.ndesig, c.n_context,
                                     c.sequence_length, c.num_masks, self.run_batch_size,
