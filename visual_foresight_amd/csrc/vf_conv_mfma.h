@@ -489,20 +489,36 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 
         __syncthreads();        // previous chunk fully consumed (and lnTab visible on entry)
         [[maybe_unused]] const unsigned long long ts_s0 = VF_TS_NOW();
+        // kConvThreads is a multiple of q4, so a thread stages the same channel quad of every pixel it visits: its
+        // channel range and LayerNorm gain / offset are loop invariants.  The light layers load them once per chunk
+        // (no per-element modulo and loads: -1.5 % at the C5 shard); in the conv-LSTM tiles the up-front loads cost
+        // more than they save (+1.2 % at C2, measured), so those keep fetching them per element.
+        constexpr bool kHoistLn = EPI != EPI_LSTM || MREP > 1;
+        const int q = tid & (q4 - 1);
+        const int c = c0 + 4 * q;
+        const int nvalid = min(4, sg.C - c);
+        [[maybe_unused]] float gam[4] = {1.f, 1.f, 1.f, 1.f}, bet[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (kHoistLn) {
+            if (sg.ln_part && c < sg.C) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cc = (c + j) % sg.gamma_mod;
+                    gam[j] = sg.gamma[cc]; bet[j] = sg.beta[cc];
+                }
+            }
+        }
         for (int it = tid; it < items; it += kConvThreads) {
             // q4 is a power of two; tile_px and LW divide through a multiply-high (exact for every index a tile
             // can hold: checked exhaustively for dividends < 70000, divisors 2..600; divisor 1 - the FC - bypasses it)
-            const int pix = it >> q4_log2, q = it & (q4 - 1);
+            const int pix = it >> q4_log2;
             const int img = tile_px == 1 ? pix : (int)__umulhi((unsigned)pix, magic_px), r = pix - img * tile_px;
             const int ly = LW == 1 ? r : (int)__umulhi((unsigned)r, magic_lw), lx = r - ly * LW;
             const int iy = ty0 * p.stride - p.pad + ly, ix = tx0 * p.stride - p.pad + lx;
             const int b = bimg0 + img;
-            const int c = c0 + 4 * q;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && c < sg.C) {
                 const float *src = sg.ptr + (long long)b * sg.bstride +
                                    ((long long)iy * p.Win + ix) * sg.C + c;
-                const int nvalid = min(4, sg.C - c);
                 if (vec_ok) {
                     v = *reinterpret_cast<const f32x4 *>(src);
                 } else {
@@ -514,8 +530,12 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
                     const float rstd = lnTab[2 * (s * p.NI + img) + 1];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int cc = (c + j) % sg.gamma_mod;
-                        v[j] = fmaf((v[j] - mean) * rstd, sg.gamma[cc], sg.beta[cc]);
+                        if constexpr (kHoistLn) {
+                            v[j] = fmaf((v[j] - mean) * rstd, gam[j], bet[j]);
+                        } else {
+                            const int cc = (c + j) % sg.gamma_mod;
+                            v[j] = fmaf((v[j] - mean) * rstd, sg.gamma[cc], sg.beta[cc]);
+                        }
                     }
                 }
                 if (sg.relu) {
