@@ -152,6 +152,15 @@ __device__ __forceinline__ void ln_from_totals(const long long su, const long lo
     rstd = (float)(1.0 / sqrt(var + (double)kLnEps));
 }
 
+// n / d for the small non-negative indices of a tile (GEMM rows, halo pixels) through a multiply-high: exact for
+// n < 70000 and d in 2..600 (checked exhaustively); d == 1 bypasses the multiply.  The divisors are per-layer
+// constants that live in scalar registers, so this replaces a ~30-instruction division by one v_mul_hi_u32.
+struct TileDiv {
+    unsigned magic; int d;
+    __device__ __forceinline__ explicit TileDiv(const int d_) : magic(0xFFFFFFFFu / (unsigned)d_ + 1u), d(d_) {}
+    __device__ __forceinline__ int div(const int n) const { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
+};
+
 // mean / rstd of every (input segment, image) of a tile from the producers' partial sums -> lnTab[nseg * NI][2].
 // Few entries (conv tiles: 1-8): one WAVE per entry, lanes over the partials (up to 32 per sample at 128x128), so the
 // prologue costs one load latency instead of a serial chain; many entries (the FC: one per GEMM row): one thread
@@ -220,14 +229,16 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
     for (int g = 0; g < G; ++g) bias_g[g] = (EPI == EPI_PARTIAL) ? 0.f : p.bias[(cg * G + g) * 32 + n];
 
     long long ssum = 0, ssq = 0;            // exact LayerNorm partials over this lane's outputs
+    const TileDiv div_rpi(p.RPI), div_tw(p.TW);
 
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wave * WROWS + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int img = row / p.RPI, rem = row % p.RPI;
-            const int y = ty0 + rem / p.TW, x = tx0 + rem % p.TW;
+            const int img = div_rpi.div(row), rem = row - img * p.RPI;
+            const int yy = div_tw.div(rem);
+            const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
             const int b = bimg0 + img;
             const bool ok = img < p.NI && rem < px_per_img && b < p.B && y < p.Hout && x < p.Wout;
             if (!ok) continue;
@@ -338,12 +349,14 @@ __device__ __forceinline__ void lstm_split_epilogue(const PT &p, f32x16 (&acc)[1
     }
     __syncthreads();
     long long ssum = 0, ssq = 0;
+    const TileDiv div_rpi(p.RPI), div_tw(p.TW);
 #pragma unroll
     for (int rr = 0; rr < RSTEP; ++rr) {
         const int r = gg * RSTEP + rr;
         const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const int img = row / p.RPI, rem = row % p.RPI;
-        const int y = ty0 + rem / p.TW, x = tx0 + rem % p.TW;
+        const int img = div_rpi.div(row), rem = row - img * p.RPI;
+        const int yy = div_tw.div(rem);
+        const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
         const int b = bimg0 + img;
         const bool ok = img < p.NI && rem < px_per_img && b < p.B && y < p.Hout && x < p.Wout;
         if (!ok) continue;
