@@ -1,0 +1,18 @@
+#!/bin/bash
+# copy the summaries of a tools/run_profiles.sh pass (gpurun_out/prof_<tag>/) into profiles/r02_*
+O=gpurun_out/prof_$1
+cp $O/bench_default.json profiles/r02_bench_default.json
+cp $O/kernel_stats_fp32.txt profiles/r02_kernel_stats_fp32.txt
+cp $O/mfma_pmc.txt profiles/r02_mfma_pmc.txt
+cp $O/hbm_traffic.json profiles/r02_hbm_traffic.json
+for n in 200 25 c5_shard; do cp $O/phase_stats_$n.txt profiles/r02_phase_stats_$n.txt; done
+for f in c1 c3 c4_shard125 c4_1gpu c2_shard25 c5_shard125 2ranks_gloo_dryrun; do cp $O/bench_$f.json profiles/r02_bench_$f.json; done
+python3 - <<PY
+import json,glob
+for f in sorted(glob.glob('$O/bench_*.json')):
+    d=json.load(open(f)); r=d['roofline']; s=r.get('survey_8d') or {}
+    print('%-34s ms/step %.1f frames/s %.0f it/s %.2f launch %.2f ms frac %.3f s8d %.3f traffic %s' % (f.split('/')[-1], d['ms_per_step'], d['value'], d['cem_iters_per_sec'], r['avg_launch_us']/1e3, r['frac'], s.get('frac_of_fp32_mfma_peak',0), r.get('traffic')))
+    if 'alt_precision' in d:
+        a=d['alt_precision']; print('    alt %.0f frames/s %.1f ms/step launch %.2f ms bf16 frac %s' % (a['value'], a['ms_per_step'], a['roofline']['avg_launch_us']/1e3, a['roofline'].get('bf16_mfma_frac_of_peak')))
+    if d.get('cpu_baseline'): print('    cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('at_all_physical_cores',{}).get('value'))
+PY
