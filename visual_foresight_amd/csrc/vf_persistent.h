@@ -150,11 +150,11 @@ template <int MREP>
 __device__ __noinline__ void lstm_bf16x6_tile_call(const ConvParams *p, int bx, int by) {
     conv_lstm_bf16x6_tile<MREP>(const_params(p), bx, by, tile_lds());
 }
-template <int ND>
+template <int ND, bool FIRST>
 __device__ __noinline__ void composite_tile_call(const CompositeParams *p, int tile, int b, int view) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
-    composite_tile<ND, 10>(const_params(p), tile, b, goal, tile_lds());
+    composite_tile<ND, 10, FIRST>(const_params(p), tile, b, goal, tile_lds());
 }
 __device__ __noinline__ void small_item_call(const PhaseDesc *P, int type, int b0, int b1) {
     float *smem = tile_lds();
@@ -313,7 +313,10 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
                 case PH_FC_PARTIAL:
                     conv_tile_call<1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx);
                     break;
-                case PH_COMPOSITE: composite_tile_call<ND>(&P.comp, local % P.gx, b0, P.view); break;
+                case PH_COMPOSITE:
+                    if (P.comp.first_frame) composite_tile_call<ND, true>(&P.comp, local % P.gx, b0, P.view);
+                    else composite_tile_call<ND, false>(&P.comp, local % P.gx, b0, P.view);
+                    break;
                 default: small_item_call(&P, P.type, b0, b1); break;
             }
         }

@@ -138,8 +138,10 @@ __host__ __device__ constexpr int composite_lds_floats() {
     return (kCompTile + 4) * (kCompTile + 4) * (3 + ND) + kTaps * K + 2 + ND + 2 /*pad*/ + 2 * 4 * 2 * ND;
 }
 
-// one 16x16 pixel tile of one sample
-template <int ND, int K, class PT>
+// one 16x16 pixel tile of one sample.  FIRST (arch 1, savp_arch.py): the first context frame is one more compositing
+// layer - a template parameter, because a run-time branch around the mask bookkeeping costs the CDNA path 3.5 us per
+// tile (measured).
+template <int ND, int K, bool FIRST, class PT>
 __device__ __forceinline__ void composite_tile(const PT &p, const int tile, const int b, const int *goal,
                                                float *smem) {
     constexpr int TS = kCompTile, HS = TS + 4;
@@ -247,7 +249,7 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
             of[c] = fmaf(o_m[0], s_frame[ctr * 3 + c], o_m[1] * sigmoidf_(o_rgb[c]));
 #pragma unroll
         for (int d = 0; d < ND; ++d) od[d] = o_m[0] * s_dist[ctr * ND + d];
-        if (p.first_frame) {
+        if constexpr (FIRST) {
             const long long o1 = (long long)y * p.W + x;
 #pragma unroll
             for (int c = 0; c < 3; ++c) of[c] = fmaf(o_m[2], p.first_frame[o1 * 3 + c], of[c]);
@@ -307,7 +309,8 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
 template <int ND, int K>
 VF_GLOBAL VF_LAUNCH_BOUNDS(256) void composite_kernel(const CompositeParams p) {
     __shared__ __attribute__((aligned(16))) float smem[composite_lds_floats<ND, K>()];
-    composite_tile<ND, K>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
+    if (p.first_frame) composite_tile<ND, K, true>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
+    else composite_tile<ND, K, false>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
 }
 
 // ------------------------------------------------------------------------------------------
