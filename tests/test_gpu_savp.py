@@ -103,3 +103,42 @@ def test_savp_split_bf16_mode_matches_oracle():
     assert np.abs(got['predicted_frames'] - f).max() <= 1e-5
     want, _ = pixel_cost.eval_pixel_cost(d, goal, 10.)
     np.testing.assert_allclose(scores, want, rtol=1e-5)
+
+
+def test_savp_two_views_one_launch():
+    """Two views of the SAVP-class network in one engine (own weights per view, one launch), against the per-view
+    oracle; persistent and per-layer launches agree bit for bit."""
+    from visual_foresight_amd.video_prediction.multiview_predictor import MultiViewHipPredictor
+    H, W = 32, 48
+    T, M, nd, ncam, adim = 2, 5, 2, 2, 6
+    hp = dict(designated_pixel_count=nd, run_batch_size=M, adim=adim, sdim=5, image_height=H, image_width=W,
+              sequence_length=T + 2, ncam=ncam, arch='savp')
+    pred = MultiViewHipPredictor('', hp)
+    cfg = SavpConfig(height=H, width=W, adim=adim, ndesig=nd, sequence_length=T + 2)
+    weights = [CdnaWeights.random(cfg, seed=20 + c, bias_scale=0.05, ln_jitter=0.1) for c in range(ncam)]
+    pred.restore(weights)
+    rs = np.random.RandomState(31)
+    desig = rs.randint(0, H, (ncam, nd, 2))
+    ctx = {'context_frames': rs.randint(0, 256, (3, ncam, H, W, 3)).astype(np.uint8),
+           'context_actions': rs.normal(0, 0.05, (2, adim)), 'context_states': rs.normal(0, 0.1, (3, 5)),
+           'context_pixel_distributions': pixel_cost.one_hot_distrib(desig, 2, ncam, H, W, nd)}
+    actions = rs.normal(0, 0.1, (M, T, adim))
+    goal = rs.randint(0, H, (ncam, nd, 2))
+    want_d = np.concatenate([_oracle(weights[c], MultiViewHipPredictor.view_context(ctx, c), actions)[1]
+                             for c in range(ncam)], axis=2)
+    want, want_pt = pixel_cost.eval_pixel_cost(want_d, goal, 10.)
+    first = None
+    for persistent in (1, 0):
+        pred.set_persistent(persistent)
+        scores, per_task = pred.score(ctx, {'actions': actions}, goal)
+        got = pred(ctx, {'actions': actions})
+        dmax = want_d.max(axis=(3, 4), keepdims=True)
+        assert (np.abs(got['predicted_pixel_distributions'] - want_d) / dmax).max() <= 2e-5
+        np.testing.assert_allclose(per_task, want_pt, rtol=1e-5)
+        np.testing.assert_allclose(scores, want, rtol=1e-5)
+        if first is None:
+            first = (scores, got['predicted_frames'])
+        else:
+            np.testing.assert_array_equal(scores, first[0])
+            np.testing.assert_array_equal(got['predicted_frames'], first[1])
+    assert pred.device_status() == 0
