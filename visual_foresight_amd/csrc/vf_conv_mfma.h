@@ -494,6 +494,10 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
         if (gt0 < gtN) { VF_LOADB(gt0) }
     }
 
+    // Wave priority: everything that is NOT a conv-LSTM K loop - the light tiles, the prologues and epilogues - is a
+    // latency chain that others wait for; it runs at priority 2 (set by the persistent kernel) and the long matrix
+    // loops step down to 0, so a co-resident light item or epilogue gets its few instructions issued first.
+    if constexpr (EPI == EPI_LSTM) __builtin_amdgcn_s_setprio(0);
     for (int ci = ch_begin; ci < ch_end; ++ci) {
         const int s = (ci < p.seg[0].nchunk) ? 0 : 1;
         const auto &sg = p.seg[s];
@@ -673,6 +677,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #undef VF_LOADB
 #undef VF_WRITEB
 
+    if constexpr (EPI == EPI_LSTM) __builtin_amdgcn_s_setprio(2);
     [[maybe_unused]] const unsigned long long ts2 = VF_TS_NOW();
     // (xch = the double-buffered B area: 32 KiB at 32-channel chunks, disjoint from lnTab / red)
     if constexpr (SPLIT) lstm_split_epilogue<RB>(p, acc, bx, by, red, reinterpret_cast<float *>(bsm));

@@ -176,6 +176,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
     int *s_ctl = reinterpret_cast<int *>(smem_all);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ph = 0;
+    __builtin_amdgcn_s_setprio(2);      // default priority of this launch; conv-LSTM K loops step down to 0 (vf_conv_mfma.h)
     if (tid < kMaxCam * kMaxDesig * 2) s_ctl[kCtlGoal + tid] = sched.goal[tid];    // visible after the first barrier
 
     // XCD-aware ticketing.  A phase's items are dealt to sched.nq queues so that all items of one output-channel
