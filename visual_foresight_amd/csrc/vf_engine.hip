@@ -1418,16 +1418,10 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         VF_EMIT_SH(u_l6, lstm_shared(5, s), sink.conv(PH_LSTM, lstm_plan(5, lstm_shared(5, s) ? 1 : B),
                                 lstm_params(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))), {u_t1}))
 
-        SegArg enc1_s = plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]));
-        p = params(h->convt2, BD, h_normed(5), &enc1_s);
-        p.out = D.enc5_o;
-        VF_EMIT_SH(u_t2, all_sh, sink.conv(PH_CONVT_RELU, h->convt2, p, {u_l6}))
-        VF_EMIT_SH(u_l7, lstm_shared(6, s), sink.conv(PH_LSTM, lstm_plan(6, lstm_shared(6, s) ? 1 : B),
-                                lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))), {u_t2}))
-        last = u_l7;
-
-        // ---- CDNA kernels (only needed when this step's prediction is used).  Emitted late: the FC
-        // needs lstm5 of EVERY sample, and its only consumer is the compositing at the end of the step.
+        // ---- CDNA kernels (only needed when this step's prediction is used).  The FC needs lstm5 of EVERY sample
+        // and its only consumer is the compositing at the end of the step: it is emitted here, behind lstm6, where
+        // its ready-to-run items fill the slots that would otherwise draw transposed-conv items still waiting for
+        // the second round of lstm6 tiles.
         int u_fin = -1;
         if (produce) {
             SegArg flat = h5n;      // same LayerNorm, viewed as [B][1][1][H8*W8*128]
@@ -1440,6 +1434,14 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
             u_fin = sink.fin(fp, {u_fc});
             if (Sink::failed(u_fin)) return u_fin;
         }
+
+        SegArg enc1_s = plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]));
+        p = params(h->convt2, BD, h_normed(5), &enc1_s);
+        p.out = D.enc5_o;
+        VF_EMIT_SH(u_t2, all_sh, sink.conv(PH_CONVT_RELU, h->convt2, p, {u_l6}))
+        VF_EMIT_SH(u_l7, lstm_shared(6, s), sink.conv(PH_LSTM, lstm_plan(6, lstm_shared(6, s) ? 1 : B),
+                                lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))), {u_t2}))
+        last = u_l7;
 
         if (produce) {      // never an all-shared step
             p = params(h->convt3, B, h_normed(6), &enc0_n);
