@@ -1422,17 +1422,13 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         // and its only consumer is the compositing at the end of the step: it is emitted here, behind lstm6, where
         // its ready-to-run items fill the slots that would otherwise draw transposed-conv items still waiting for
         // the second round of lstm6 tiles.
-        int u_fin = -1;
+        int u_fin = -1, u_fc = -1;
         if (produce) {
             SegArg flat = h5n;      // same LayerNorm, viewed as [B][1][1][H8*W8*128]
             p = params(h->fc, B, flat, nullptr);
             p.out = v.fc_part;
-            VF_EMIT(u_fc, sink.conv(PH_FC_PARTIAL, h->fc, p, {u_l5}))
-            FinParams fp;
-            fp.partial = v.fc_part; fp.nsplit = h->fc.nsplit; fp.B = B; fp.K = h->K;
-            fp.bias = vd.b_fc; fp.kern = v.kern;
-            u_fin = sink.fin(fp, {u_fc});
-            if (Sink::failed(u_fin)) return u_fin;
+            VF_EMIT(u_fc_, sink.conv(PH_FC_PARTIAL, h->fc, p, {u_l5}))
+            u_fc = u_fc_;
         }
 
         SegArg enc1_s = plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]));
@@ -1442,6 +1438,13 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         VF_EMIT_SH(u_l7, lstm_shared(6, s), sink.conv(PH_LSTM, lstm_plan(6, lstm_shared(6, s) ? 1 : B),
                                 lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))), {u_t2}))
         last = u_l7;
+        if (produce) {      // the (tiny) finalise step of the CDNA kernels: behind lstm7, by when the FC has long finished
+            FinParams fp;
+            fp.partial = v.fc_part; fp.nsplit = h->fc.nsplit; fp.B = B; fp.K = h->K;
+            fp.bias = vd.b_fc; fp.kern = v.kern;
+            u_fin = sink.fin(fp, {u_fc});
+            if (Sink::failed(u_fin)) return u_fin;
+        }
 
         if (produce) {      // never an all-shared step
             p = params(h->convt3, B, h_normed(6), &enc0_n);
