@@ -159,6 +159,7 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
     size_t lds_dma = 0;             // conv-LSTM, fp32: LDS bytes of the DMA tile (0: tile not applicable)
     size_t lds_bd = 0;              // conv-LSTM, fp32, 128 rows: LDS bytes with the weights read from L2 (0: n/a)
     int NI, TH, TW, RPI, tilesY, tilesX;
+    int ni_cap = 0;                 // > 0: at most this many whole images per workgroup (plans for narrow phases)
     int ncg, Cout;
     int nsplit, chunks_per_split, n_valid;
     int stats_nparts;               // partial sums this layer's epilogue writes per sample
@@ -200,6 +201,7 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
             // several whole images per workgroup; with statistics every wave must sit inside one image
             l.RPI = needs_stats ? round_up(px, wrows) : px;
             l.NI = rows / l.RPI;
+            if (l.ni_cap > 0) l.NI = std::min(l.NI, l.ni_cap);
         } else {
             l.RPI = rows; l.NI = 1;
         }
@@ -379,6 +381,10 @@ struct vf_handle {
     // layers (geometry)
     ConvLayer enc0, lstm[7], enc1, enc2, enc3, convt1, convt2, convt3, fc;
     ConvLayer enc00, convt4;            // arch 1 only
+    // One-image-per-workgroup plans of the bottleneck's light layers (8x8 images: two fit a 128-row tile): twice the
+    // items, each shorter - for batches whose phases do not fill the workgroup slots anyway (same packed weights,
+    // same arithmetic per output)
+    ConvLayer enc2_one, enc3_one, convt1_one;
     // Second tile plan of every conv-LSTM (256 GEMM rows per workgroup, weights read straight from L2 so that
     // the larger input tile fits the LDS with the SAME 32-channel chunks): fewer, longer items - better per
     // FLOP once a phase has far more items than workgroup slots, worse for the per-sample dependency chain of
@@ -766,6 +772,10 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     init_layer(h->enc3, "enc3", PACK_PLAIN, H8, W8, H8, W8, 1, 1, 1, 0, L[3], 0, L[3], false);
     init_layer(h->lstm[4], "lstm5", PACK_LSTM, H8, W8, H8, W8, 5, 5, 1, 2, L[3], L[4], L[4], true, false, lstm_mrep[4], cfg->precision);
     init_layer(h->convt1, "convt1", PACK_CONVT, H8, W8, H8, W8, 2, 2, 1, 1, L[4], 0, L[4], false);
+    h->enc2_one.ni_cap = h->enc3_one.ni_cap = h->convt1_one.ni_cap = 1;
+    init_layer(h->enc2_one, "enc2", PACK_PLAIN, H4, W4, H8, W8, 3, 3, 2, 0, L[3], 0, L[3], false);
+    init_layer(h->enc3_one, "enc3", PACK_PLAIN, H8, W8, H8, W8, 1, 1, 1, 0, L[3], 0, L[3], false);
+    init_layer(h->convt1_one, "convt1", PACK_CONVT, H8, W8, H8, W8, 2, 2, 1, 1, L[4], 0, L[4], false);
     init_layer(h->lstm[5], "lstm6", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[4], L[5], L[5], true, false, lstm_mrep[5], cfg->precision);
     init_layer(h->convt2, "convt2", PACK_CONVT, H4, W4, H4, W4, 2, 2, 1, 1, L[5], L[1], L[5], false);
     init_layer(h->lstm[6], "lstm7", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[5], L[6], L[6], true, false, lstm_mrep[6], cfg->precision);
@@ -807,6 +817,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         h->layers[i]->id = (int)i;
         h->max_lds = std::max(h->max_lds, std::max(h->layers[i]->lds_bytes, h->layers[i]->lds_dma));
     }
+    h->enc2_one.id = h->enc2.id; h->enc3_one.id = h->enc3.id; h->convt1_one.id = h->convt1.id;   // shared packed weights
     for (int k = 0; k < 7; ++k)
         if (h->have_big) {
             h->lstm_big[k].id = h->lstm_half[k].id = h->lstm_quarter[k].id = h->lstm[k].id;    // shared packed weights
@@ -1301,6 +1312,12 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         if (want >= 3 && h->half_ok[k]) return h->lstm_half[k];
         return h->lstm[k];
     };
+    // light layers of the bottleneck: one image per workgroup for small batches (measured: -2.1 % at 25 samples, 0 at 50, +0.3 % at 100, +1.1 % at 200)
+    auto light_plan = [&](const ConvLayer &reg, const ConvLayer &one, int Bp) -> const ConvLayer & {
+        if (reg.NI <= 1 || one.NI != 1 || one.KC != reg.KC) return reg;
+        const long long items = (long long)((Bp + reg.NI - 1) / reg.NI) * reg.ncg;
+        return items <= h->n_cu / 8 ? one : reg;
+    };
     auto all_shared = [&](int s) { return h->dedup && s < nc - 1; };
     auto enc_shared = [&](int s) { return h->dedup && s < nc; };
     // is the output of lstm k at step s one shared image?  (s < 0: the shared zero state)
@@ -1399,22 +1416,25 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
                                 lstm_params(2, plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]))), {u_enc1}))
         VF_EMIT_SH(u_l4, lstm_shared(3, s), sink.conv(PH_LSTM, lstm_plan(3, lstm_shared(3, s) ? 1 : B), lstm_params(3, h_normed(2)), {u_l3}))
 
-        p = params(h->enc2, BE, h_normed(3), nullptr);
+        const ConvLayer &enc2_l = light_plan(h->enc2, h->enc2_one, BE);
+        p = params(enc2_l, BE, h_normed(3), nullptr);
         p.out = E.enc2_o;
-        VF_EMIT_SH(u_enc2, enc_sh, sink.conv(PH_CONV_RELU, h->enc2, p, {u_l4}))
+        VF_EMIT_SH(u_enc2, enc_sh, sink.conv(PH_CONV_RELU, enc2_l, p, {u_l4}))
 
-        p = params(h->enc3, BD, plain(E.enc2_o, bs(enc_sh, (long long)H8 * W8 * L[3])), nullptr);
+        const ConvLayer &enc3_l = light_plan(h->enc3, h->enc3_one, BD);
+        p = params(enc3_l, BD, plain(E.enc2_o, bs(enc_sh, (long long)H8 * W8 * L[3])), nullptr);
         p.out = D.enc3_o; p.sbias = D.sbias; p.sbias_ld = L[3];
-        VF_EMIT_SH(u_enc3, all_sh, sink.conv(PH_CONV_RELU, h->enc3, p, {u_enc2, u_sa}))
+        VF_EMIT_SH(u_enc3, all_sh, sink.conv(PH_CONV_RELU, enc3_l, p, {u_enc2, u_sa}))
 
         VF_EMIT_SH(u_l5, lstm_shared(4, s), sink.conv(PH_LSTM, lstm_plan(4, lstm_shared(4, s) ? 1 : B),
                                 lstm_params(4, plain(D.enc3_o, bs(all_sh, (long long)H8 * W8 * L[3]))), {u_enc3}))
         SegArg h5n = h_normed(4);
 
         // ---- decoder
-        p = params(h->convt1, BD, h5n, nullptr);
+        const ConvLayer &convt1_l = light_plan(h->convt1, h->convt1_one, BD);
+        p = params(convt1_l, BD, h5n, nullptr);
         p.out = D.enc4_o;
-        VF_EMIT_SH(u_t1, all_sh, sink.conv(PH_CONVT_RELU, h->convt1, p, {u_l5}))
+        VF_EMIT_SH(u_t1, all_sh, sink.conv(PH_CONVT_RELU, convt1_l, p, {u_l5}))
         VF_EMIT_SH(u_l6, lstm_shared(5, s), sink.conv(PH_LSTM, lstm_plan(5, lstm_shared(5, s) ? 1 : B),
                                 lstm_params(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))), {u_t1}))
 
