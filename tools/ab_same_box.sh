@@ -1,3 +1,6 @@
+# GPU box: same-box A/B of two library builds (build/libvf_prev.so = the previous build, copied there before rebuilding)
+# over the C2 bench in both precision modes, the 25-sample share and the C5 shard.  Boxes of the pool differ by 1-3 %,
+# so only pairs measured by one call of this script are compared (profiles/r02_ab_experiments.log).
 cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
 for v in prev new; do
