@@ -1585,7 +1585,9 @@ static int build_schedule_as(vf_handle *h, int B, bool skip_shared, BuiltSchedul
             }
     }
     out.counters = counters;
-    out.lds = std::max(max_lds, (size_t)composite_lds_floats<kMaxDesig, 10>() * 4) + 16;
+    const size_t comp_lds[kMaxDesig] = {(size_t)composite_lds_floats<1, 10>() * 4, (size_t)composite_lds_floats<2, 10>() * 4,
+                                        (size_t)composite_lds_floats<3, 10>() * 4, (size_t)composite_lds_floats<4, 10>() * 4};
+    out.lds = std::max(max_lds, comp_lds[h->ND - 1]) + 16;
     if (out.phases.size() > h->sched_capacity || (size_t)counters > h->counter_capacity)
         return fail(VF_ERR_INVALID, "persistent schedule exceeds its preallocated capacity");
     return VF_OK;

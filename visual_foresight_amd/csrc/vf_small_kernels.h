@@ -133,9 +133,14 @@ struct CompositeParams {
 };
 
 // LDS floats needed by composite_tile<ND, K>
+constexpr int kCompEncPad = 36;         // floats per pixel row of the staged feature tile (32 + 4: conflict-free b128 reads)
+template <int ND, int K>
+__host__ __device__ constexpr int composite_small_floats() {
+    return (kCompTile + 4) * (kCompTile + 4) * (3 + ND) + kTaps * K + 2 + ND + 2 /*pad*/ + 2 * 4 * 2 * ND;
+}
 template <int ND, int K>
 __host__ __device__ constexpr int composite_lds_floats() {
-    return (kCompTile + 4) * (kCompTile + 4) * (3 + ND) + kTaps * K + 2 + ND + 2 /*pad*/ + 2 * 4 * 2 * ND;
+    return ((composite_small_floats<ND, K>() + 3) & ~3) + kCompTile * kCompTile * kCompEncPad;
 }
 
 // one 16x16 pixel tile of one sample.  FIRST (arch 1, savp_arch.py): the first context frame is one more compositing
@@ -155,10 +160,25 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
     double (*s_red)[2 * ND] = reinterpret_cast<double (*)[2 * ND]>(
         smem + ((HS * HS * (3 + ND) + kTaps * K + 2 + ND + 1) & ~1));
 
+    float *s_enc = smem + ((composite_small_floats<ND, K>() + 3) & ~3);     // [TS*TS][kCompEncPad]
+
     const int tid = threadIdx.x;
     const int tilesX = (p.W + TS - 1) / TS;
     const int ntiles = tilesX * ((p.H + TS - 1) / TS);
     const int ty0 = (tile / tilesX) * TS, tx0 = (tile % tilesX) * TS;
+
+    // The tile's 32-channel features are fetched cooperatively - a wave instruction reads 1 KiB of consecutive
+    // pixels - and transposed through LDS; one thread reading the 128 bytes of "its" pixel straight from memory
+    // touches 64 cache lines per load instruction.  Issued first: the loads fly during the prologue below.
+    f32x4 ev[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = tid + 256 * k, px = i >> 3, q = i & 7;
+        const int yy = ty0 + (px >> 4), xx = tx0 + (px & 15);
+        ev[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (yy < p.H && xx < p.W)
+            ev[k] = *reinterpret_cast<const f32x4 *>(p.enc6 + (((long long)b * p.H + yy) * p.W + xx) * 32 + q * 4);
+    }
 
     // prologue reductions, lanes over the partials (32 LayerNorm partials and 64 tiles per sample at 128x128):
     // wave 0 the exact LayerNorm statistics, wave (d + 1) & 3 the mass of distribution d (fixed order: lanes
@@ -199,6 +219,11 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
 #pragma unroll
         for (int d = 0; d < ND; ++d) s_dist[i * ND + d] = in ? pd[o * ND + d] * s_dscale[d] : 0.f;
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = tid + 256 * k;
+        *reinterpret_cast<f32x4 *>(&s_enc[(i >> 3) * kCompEncPad + (i & 7) * 4]) = ev[k];
+    }
     __syncthreads();
 
     const int ly = tid / TS, lx = tid % TS;
@@ -210,7 +235,7 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
 
     if (valid) {
         // ---- LN9 + relu of this pixel's 32 features, then the two 1x1 heads
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.enc6 + (((long long)b * p.H + y) * p.W + x) * 32);
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(&s_enc[tid * kCompEncPad]);
         float o_rgb[3], o_m[NM];
 #pragma unroll
         for (int j = 0; j < 3; ++j) o_rgb[j] = p.b_rgb[j];
