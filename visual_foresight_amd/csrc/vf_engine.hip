@@ -1558,7 +1558,11 @@ static int build_schedule_as(vf_handle *h, int B, bool skip_shared, BuiltSchedul
     // Deal every phase's items to the XCD queues (vf_persistent.h): item = (unit * q_inner + inner) * q_gy + cg
     // goes to queue (unit % (nq / q_gy)) * q_gy + cg.  unit = sample (or sample group) of the item, inner = its
     // tile within the sample, cg = output-channel group.  Launches too small to occupy every XCD keep one queue.
-    const int nq = (h->xcd_queues > 1 && ticket >= 4 * h->n_cu) ? kQueues : 1;
+    // one queue per XCD the device exposes: 8 on the whole chip (256 CUs), fewer in a partitioned mode (a queue
+    // that no workgroup calls its own would only be served by thieves - too late for the items that wait on it)
+    int n_xcd = 1;
+    while (n_xcd < kQueues && n_xcd * 2 * 32 <= h->n_cu) n_xcd *= 2;
+    const int nq = (h->xcd_queues > 1 && ticket >= 4 * h->n_cu) ? n_xcd : 1;
     out.nq = nq;
     for (int r = 0; r < kRoles; ++r)
         for (int q = 0; q < kQueues; ++q) out.total_q[r][q] = 0;
@@ -1599,7 +1603,7 @@ static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &
     if (h->role_mode && h->role_ok) {
         int rc = build_schedule_as(h, B, skip_shared, out, true);
         if (rc) return rc;
-        if (out.lds <= kRoleLdsLimit + 16 && out.items >= 6 * h->n_cu && out.nq == kQueues) return VF_OK;
+        if (out.lds <= kRoleLdsLimit + 16 && out.items >= 6 * h->n_cu && out.nq > 1) return VF_OK;
     }
     return build_schedule_as(h, B, skip_shared, out, false);
 }
