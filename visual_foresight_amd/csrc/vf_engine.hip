@@ -373,6 +373,7 @@ struct vf_handle {
     int Hc, Wc;                         // input size of the three-scale conv-LSTM core (H, W; arch 1: H/2, W/2)
     int ncam = 1, n_draws = 1;
     int ntiles;                         // composite tiles per image
+    int nblocks;                        // cost-sum blocks per image (4 x 16 pixels, vf_small_kernels.h)
     std::vector<TensorDesc> table;
     size_t blob_floats = 0;             // canonical floats per view
     bool have_weights = false, have_context = false;
@@ -743,6 +744,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     const int H2 = Hc / 2, W2 = Wc / 2, H4 = Hc / 4, W4 = Wc / 4, H8 = Hc / 8, W8 = Wc / 8;
     const int *L = kLstmSizes;
     h->ntiles = ((H + kCompTile - 1) / kCompTile) * ((W + kCompTile - 1) / kCompTile);
+    h->nblocks = sum_blocks(H, W);
 #ifdef VF_HOST_SELFTEST
     h->fake_size = (size_t)1 << 40;
     void *base = mmap(nullptr, h->fake_size, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
@@ -899,7 +901,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     VF_ALLOC(h->frames_all, BV * h->T * H * W * 3);
     VF_ALLOC(h->distrib_all, BV * h->T * H * W * ND);
     VF_ALLOC(h->states_all, BV * h->T * cfg->sdim);
-    h->sums_view_stride = (long long)Bc * ND * h->ntiles * 2;
+    h->sums_view_stride = (long long)Bc * ND * h->nblocks * 2;
     h->sums_step_stride = h->sums_view_stride * NV;
     VF_ALLOC(h->sums, (size_t)h->T * h->sums_step_stride);
     VF_ALLOC(h->actions_buf, (size_t)Bc * h->T * cfg->adim);
@@ -1129,7 +1131,7 @@ static BatchView make_view(vf_handle *h, int view, const float *d_actions, int b
     v.frames_all = h->frames_all + b * T * H * W * 3;
     v.distrib_all = h->distrib_all + b * T * H * W * ND;
     v.states_all = h->states_all + b * T * c.sdim;
-    v.sums = h->sums + (long long)view * h->sums_view_stride + (size_t)b0 * ND * h->ntiles * 2;
+    v.sums = h->sums + (long long)view * h->sums_view_stride + (size_t)b0 * ND * h->nblocks * 2;
     v.actions = d_actions + (size_t)b0 * T * c.adim;       // the views share the action sequences
     return v;
 }
@@ -1661,7 +1663,7 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
             ok = ok && in_allocs(h, c.prev_distrib, ((size_t)(P.B - 1) * c.prev_distrib_bstride + hw * c.ND) * 4);
             ok = ok && in_allocs(h, c.out_frame, ((size_t)(P.B - 1) * c.out_frame_bstride + hw * 3) * 4);
             ok = ok && in_allocs(h, c.out_distrib, ((size_t)(P.B - 1) * c.out_distrib_bstride + hw * c.ND) * 4);
-            ok = ok && in_allocs(h, c.out_sums, (size_t)P.B * c.ND * h->ntiles * 2 * 8);
+            ok = ok && in_allocs(h, c.out_sums, (size_t)P.B * c.ND * h->nblocks * 2 * 8);
             ok = ok && in_allocs(h, c.kern, (size_t)P.B * kTaps * c.K * 4);
             ok = ok && in_allocs(h, c.first_frame, hw * 3 * 4) && in_allocs(h, c.first_distrib, hw * c.ND * 4);
         } else if (P.type == PH_SA) {
@@ -1926,8 +1928,8 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
         for (int i = 0; i < h->ncam * h->ND; ++i) tw.w[i] = task_weights[i];
     }
     const int n_actions = B / h->n_draws;
-    hipLaunchKernelGGL(scores_kernel, dim3((n_actions + 63) / 64), dim3(64), 0, st, h->sums, h->sums_step_stride,
-                       h->sums_view_stride, n_actions, h->n_draws, h->T, h->ND, h->ncam, h->ntiles, finalweight, tw,
+    hipLaunchKernelGGL(scores_kernel, dim3(n_actions), dim3(64), 0, st, h->sums, h->sums_step_stride,
+                       h->sums_view_stride, n_actions, h->n_draws, h->T, h->ND, h->ncam, h->nblocks, finalweight, tw,
                        h->d_status, d_scores, d_scores_per_task);
     VF_HIP_CHECK(hipGetLastError());
     h->last_B = B;
@@ -2078,7 +2080,7 @@ int vf_export(vf_handle *h, int32_t first, int32_t count, float *d_frames, float
         const long long n = (long long)count * h->T * h->ncam * HW * h->ND;
         hipLaunchKernelGGL(export_distrib_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                            h->distrib_all, view_rows * (long long)HW * h->ND, h->sums, h->sums_step_stride,
-                           h->sums_view_stride, first, count, h->T, h->ncam, (int)HW, h->ND, h->ntiles, d_distrib);
+                           h->sums_view_stride, first, count, h->T, h->ncam, (int)HW, h->ND, h->nblocks, d_distrib);
         VF_HIP_CHECK(hipGetLastError());
     }
     return VF_OK;

@@ -18,6 +18,12 @@ constexpr int kMaxDesig = 4;
 constexpr int kDnaKern = 5;
 constexpr int kTaps = kDnaKern * kDnaKern;
 constexpr int kCompTile = 16;           // composite: 16x16 pixels per workgroup
+// Cost sums are kept per BLOCK of 4 rows x 16 columns - the pixels one wave of a compositing tile handles - and
+// added up in block order by their readers, so the decomposition of an image into workgroup tiles does not show
+// in the sums (any tiling whose waves cover whole blocks gives the same bits).
+constexpr int kSumBlockH = 4, kSumBlockW = 16;
+__host__ __device__ constexpr int sum_blocks_x(int W) { return (W + kSumBlockW - 1) / kSumBlockW; }
+__host__ __device__ constexpr int sum_blocks(int H, int W) { return ((H + kSumBlockH - 1) / kSumBlockH) * sum_blocks_x(W); }
 constexpr float kReluShift = 1e-12f;
 
 // ------------------------------------------------------------------------------------------
@@ -121,12 +127,12 @@ struct CompositeParams {
     const float *kern;                  // [B][25][K]
     const float *prev_frame; long long prev_frame_bstride;      // [H][W][3]
     const float *prev_distrib; long long prev_distrib_bstride;  // [H][W][ND]
-    const double *prev_sums;            // [B][ND][ntiles][2] partial sums of prev_distrib, or null
+    const double *prev_sums;            // [B][ND][blocks][2] partial sums of prev_distrib, or null
     const float *first_frame;           // arch 1 (savp_arch.py): first context frame [H][W][3], shared by every
     const float *first_distrib;         //   sample, and its distributions [H][W][ND]; null = CDNA compositing
     float *out_frame; long long out_frame_bstride;
     float *out_distrib; long long out_distrib_bstride;
-    double *out_sums;                   // [B][ND][ntiles][2]: sum d, sum d * dist(goal)
+    double *out_sums;                   // [B][ND][blocks][2]: sum d, sum d * dist(goal) per 4x16-pixel block
     int goal[kMaxDesig][2];             // (row, col); read by the per-layer kernel only - the persistent
                                         // kernel takes the goals from its launch arguments, so a schedule
                                         // does not depend on them
@@ -156,15 +162,11 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
     float *s_kern = s_dist + HS * HS * ND;              // [kTaps*K]
     float *s_ln = s_kern + kTaps * K;                   // [2]
     float *s_dscale = s_ln + 2;                         // [ND]
-    // doubles: keep 8-byte alignment (all counts above are even except possibly ND)
-    double (*s_red)[2 * ND] = reinterpret_cast<double (*)[2 * ND]>(
-        smem + ((HS * HS * (3 + ND) + kTaps * K + 2 + ND + 1) & ~1));
-
     float *s_enc = smem + ((composite_small_floats<ND, K>() + 3) & ~3);     // [TS*TS][kCompEncPad]
 
     const int tid = threadIdx.x;
     const int tilesX = (p.W + TS - 1) / TS;
-    const int ntiles = tilesX * ((p.H + TS - 1) / TS);
+    const int nblocks = sum_blocks(p.H, p.W);
     const int ty0 = (tile / tilesX) * TS, tx0 = (tile % tilesX) * TS;
 
     // The tile's 32-channel features are fetched cooperatively - a wave instruction reads 1 KiB of consecutive
@@ -196,8 +198,8 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
             float sc = 1.0f;
             if (p.prev_sums) {
                 double su = 0.0;
-                const double *pp = p.prev_sums + ((long long)b * ND + d) * ntiles * 2;
-                for (int k = lane_; k < ntiles; k += 64) su += pp[2 * k];
+                const double *pp = p.prev_sums + ((long long)b * ND + d) * nblocks * 2;
+                for (int k = lane_; k < nblocks; k += 64) su += pp[2 * k];
                 su = wave_sum(su);
                 sc = (float)(1.0 / su);
             }
@@ -315,19 +317,18 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
             cost[2 * d + 1] = (double)od[d] * (double)dist;
         }
     }
-    // ---- deterministic workgroup reduction of the cost sums
+    // ---- cost sums of this wave's block (4 rows x 16 columns): lanes in a fixed butterfly, one entry per block
 #pragma unroll
     for (int i = 0; i < 2 * ND; ++i) cost[i] = wave_sum(cost[i]);
     const int lane = tid & 63, wave = tid >> 6;
-    if (lane == 0) {
+    const int by = ty0 / kSumBlockH + wave, bxk = tx0 / kSumBlockW;
+    if (lane == 0 && by * kSumBlockH < p.H && tx0 < p.W) {
+        const int blk = by * sum_blocks_x(p.W) + bxk;
 #pragma unroll
-        for (int i = 0; i < 2 * ND; ++i) s_red[wave][i] = cost[i];
-    }
-    __syncthreads();
-    if (tid < 2 * ND) {
-        const double s = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
-        const int d = tid >> 1;
-        p.out_sums[(((long long)b * ND + d) * ntiles + tile) * 2 + (tid & 1)] = s;
+        for (int d = 0; d < ND; ++d) {
+            double *dst = p.out_sums + (((long long)b * ND + d) * nblocks + blk) * 2;
+            dst[0] = cost[2 * d]; dst[1] = cost[2 * d + 1];
+        }
     }
 }
 
@@ -346,15 +347,17 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(256) void composite_kernel(const CompositeParams p) {
 // or, with use_weights, the trade-off weighted sum (register_gtruth_controller.py:88-94).
 // Scores leave the device in float64 (the reference's host cost is float64 under NumPy >= 2,
 // SURVEY section 7): no fp32 rounding can merge two distinct costs into a tie before the argsort.
-// sums[t]: [ncam][Bcap][ND][ntiles][2].  A non-zero *status (a tile of the rollout gave up
+// sums[t]: [ncam][Bcap][ND][blocks][2] (ntiles below = 4x16-pixel blocks per image).  A non-zero *status (a tile of the rollout gave up
 // waiting for its producers) poisons every score with NaN, so a failed rollout cannot feed CEM.
 constexpr int kMaxCam = 4;
 struct TaskWeights { int use; float w[kMaxCam * kMaxDesig]; };
 
+// One WAVE per action: the lanes stride the blocks of a (step, task, draw) and a fixed butterfly adds them up
+// (deterministic; every reader of the sums uses this order).
 VF_GLOBAL void scores_kernel(const double *sums, long long step_stride, long long view_stride, int n_actions,
                               int n_draws, int T, int ND, int ncam, int ntiles, float finalweight,
                               const TaskWeights tw, const int *status, double *scores, double *scores_per_task) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = blockIdx.x, lane = threadIdx.x;
     if (a >= n_actions) return;
     const int ntask = ncam * ND;
     const bool poisoned = status && *status != 0;
@@ -369,7 +372,8 @@ VF_GLOBAL void scores_kernel(const double *sums, long long step_stride, long lon
                     const double *pp = sums + (long long)t * step_stride + (long long)v * view_stride +
                                        (b * ND + d) * ntiles * 2;
                     double s0 = 0.0, s1 = 0.0;
-                    for (int k = 0; k < ntiles; ++k) { s0 += pp[2 * k]; s1 += pp[2 * k + 1]; }
+                    for (int k = lane; k < ntiles; k += 64) { s0 += pp[2 * k]; s1 += pp[2 * k + 1]; }
+                    s0 = wave_sum(s0); s1 = wave_sum(s1);
                     const double w = (t == T - 1) ? (double)finalweight : 1.0;
                     acc += w * (s1 / s0);
                     wsum += w;
@@ -378,12 +382,12 @@ VF_GLOBAL void scores_kernel(const double *sums, long long step_stride, long lon
             }
             const double sc = over_draws / n_draws;
             const int col = v * ND + d;
-            if (scores_per_task)
+            if (scores_per_task && lane == 0)
                 scores_per_task[(long long)a * ntask + col] = poisoned ? __builtin_nan("") : sc;
             total += tw.use ? (double)tw.w[col] * sc : sc;
         }
     const double out = tw.use ? total : total / ntask;
-    scores[a] = poisoned ? __builtin_nan("") : out;
+    if (lane == 0) scores[a] = poisoned ? __builtin_nan("") : out;
 }
 
 // predictions out in the reference layout: dst[bb][t][view][hw][C] <- src[view][Bcap][t][hw][C]
