@@ -205,6 +205,13 @@ int vf_set_xcd_queues(vf_handle *h, int32_t enable);
 int vf_set_role_mode(vf_handle *h, int32_t enable);
 int vf_debug_role_census(vf_handle *h, int32_t *active, int32_t *hist8);
 
+/* Fused decoder top of the persistent rollout (no reference counterpart).  The last transposed convolution and the
+ * compositing of the next frame become ONE item per tile: the tile stays in registers / LDS, its LayerNorm partial
+ * is published, the item waits for the sample's other tiles and composes its pixels itself - the full-resolution
+ * decoder tensor is never written to memory (visual_foresight_amd/csrc/vf_fused_top.h).  Same arithmetic on the same
+ * values: results are bit-identical to the two-phase schedule and to the per-layer launches. */
+int vf_set_fuse_top(vf_handle *h, int32_t enable);
+
 /* conv-LSTM tile selection (no reference counterpart): 0 (default) = single input buffer, weights
  * staged through LDS, one barrier per tap; 2 = double-buffered LDS-DMA input staging
  * (global_load_lds_dwordx4) with the weight operand read straight from L2 and one barrier per

@@ -515,3 +515,32 @@ def test_float16_conf_key_selects_the_reduced_precision_mode():
     assert HipVPredEvaluation('', dict(hp, float16='')).precision == 1
     assert HipVPredEvaluation('', dict(hp, float16='', precision='fp32')).precision == 0
     assert HipVPredEvaluation('', hp).precision == (1 if __import__('os').environ.get('VF_PRECISION') == 'bf16x6' else 0)
+
+
+@pytest.mark.parametrize('H,W,nd,M', [(64, 64, 1, 21), (64, 64, 4, 6), (32, 32, 2, 9), (48, 64, 1, 7), (40, 56, 2, 5)])
+def test_fused_decoder_top_is_invisible_in_the_results(H, W, nd, M):
+    """vf_set_fuse_top: the last transposed conv and the compositing as one item per tile (the decoder's top tensor
+    never reaches memory) - same bits as the two-phase schedule and as the per-layer launches, several tile
+    geometries (40x56 cannot be fused and falls back)."""
+    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+    T = 3
+    rs = np.random.RandomState(H + W + nd)
+    ctx = _context(H, W, nd, rs)
+    actions = rs.normal(0, 0.1, (M, T, 4))
+    goal = rs.randint(0, min(H, W), (1, nd, 2))
+    pred, weights = _predictor(H, W, T, nd, bs=M)
+    base, base_pt = pred.score(ctx, {'actions': actions}, goal)
+    ref = pred(ctx, {'actions': actions})
+    hp = dict(designated_pixel_count=nd, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,
+              sequence_length=T + 2, fuse_top=1)
+    other = HipVPredEvaluation('', hp).restore(weights)
+    for _ in range(2):              # the second call runs the cached-context schedule
+        got, got_pt = other.score(ctx, {'actions': actions}, goal)
+        np.testing.assert_array_equal(got, base)
+        np.testing.assert_array_equal(got_pt, base_pt)
+    out = other(ctx, {'actions': actions})
+    np.testing.assert_array_equal(out['predicted_frames'], ref['predicted_frames'])
+    np.testing.assert_array_equal(out['predicted_pixel_distributions'], ref['predicted_pixel_distributions'])
+    other.set_persistent(0)         # per-layer launches (never fused)
+    np.testing.assert_array_equal(other.score(ctx, {'actions': actions}, goal)[0], base)
+    assert other.device_status() == 0

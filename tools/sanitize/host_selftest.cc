@@ -17,6 +17,7 @@
 #include "../../include/vf_hip.h"
 
 extern "C" int vf_set_role_mode(vf_handle *h, int32_t enable);
+extern "C" int vf_set_fuse_top(vf_handle *h, int32_t enable);
 extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared, int64_t *out_items,
                                     uint64_t *out_upload_checksum);
 
@@ -39,6 +40,7 @@ static int run_case(int H, int W, int adim, int sdim, int nd, int nctx, int T, i
     uint64_t sum = 0;
     for (int role = 0; role < 2; ++role) {
       vf_set_role_mode(h, role);       // role mode: used where the launch qualifies, the plain schedule elsewhere
+      vf_set_fuse_top(h, !role);       // fused decoder top with the plain schedule
       for (int i = 0; i < n_batches; ++i)
         for (int skip = 0; skip < 2; ++skip) {
             int64_t items = 0;

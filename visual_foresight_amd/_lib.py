@@ -14,14 +14,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get('VF_LIBRARY') or os.path.join(_HERE, 'libvf_hip.so')     # override: experiments only
 SOURCES = [os.path.join(_HERE, 'csrc', f) for f in
-           ('vf_engine.hip', 'vf_conv_mfma.h', 'vf_small_kernels.h', 'vf_persistent.h', 'vf_conv_bf16x6.h')] + \
+           ('vf_engine.hip', 'vf_conv_mfma.h', 'vf_small_kernels.h', 'vf_persistent.h', 'vf_conv_bf16x6.h',
+            'vf_fused_top.h')] + \
           [os.path.join(REPO, 'include', 'vf_hip.h')]
 
 # every symbol include/vf_hip.h declares
 EXPORTS = ('vf_abi_version', 'vf_last_error', 'vf_weight_count', 'vf_create', 'vf_destroy',
            'vf_load_weights', 'vf_set_context', 'vf_rollout', 'vf_export', 'vf_register',
            'vf_allgather_scores', 'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile',
-           'vf_set_substreams', 'vf_set_dedup', 'vf_set_persistent', 'vf_set_xcd_queues', 'vf_set_role_mode', 'vf_debug_role_census', 'vf_set_lstm_tile', 'vf_device_status',
+           'vf_set_substreams', 'vf_set_dedup', 'vf_set_persistent', 'vf_set_xcd_queues', 'vf_set_role_mode', 'vf_set_fuse_top', 'vf_debug_role_census', 'vf_set_lstm_tile', 'vf_device_status',
            'vf_set_phase_stats', 'vf_debug_phase_stats', 'vf_debug_poison_status')
 ABI_VERSION = 4
 
@@ -110,6 +111,8 @@ def load_library():
     lib.vf_set_lstm_tile.argtypes = [P, ctypes.c_int32]
     lib.vf_set_xcd_queues.argtypes = [P, ctypes.c_int32]
     lib.vf_set_role_mode.argtypes = [P, ctypes.c_int32]
+    lib.vf_set_fuse_top.argtypes = [P, ctypes.c_int32]
+    lib.vf_set_fuse_top.restype = ctypes.c_int
     lib.vf_set_role_mode.restype = ctypes.c_int
     lib.vf_debug_role_census.argtypes = [P, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.vf_debug_role_census.restype = ctypes.c_int

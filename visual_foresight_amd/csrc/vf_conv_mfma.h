@@ -67,8 +67,11 @@ enum Epilogue {
     EPI_RAW_STATS = 2,        // acc + bias, + LayerNorm partial sums
     EPI_CONVT_RELU = 3,       // depth-to-space, relu(acc + bias)
     EPI_CONVT_RAW_STATS = 4,  // depth-to-space, acc + bias, + LayerNorm partial sums
-    EPI_PARTIAL = 5           // raw accumulators of one K split
+    EPI_PARTIAL = 5,          // raw accumulators of one K split
+    EPI_CONVT_FUSED = 6       // top transposed conv whose tile is composed into the next frame right away
+                              // (vf_fused_top.h); 6 + 2 * (designated pixels - 1) + (arch 1 first-frame layer)
 };
+__host__ __device__ constexpr int fused_epi(int nd, bool first) { return EPI_CONVT_FUSED + 2 * (nd - 1) + (first ? 1 : 0); }
 
 struct ConvSeg {
     const float *ptr;       // NHWC activations of this input segment
@@ -112,6 +115,12 @@ struct ConvParams {
     int n_valid;            // EPI_PARTIAL: valid output columns
     const float *zeros;     // >= 16 bytes of zeros (LDS-DMA source of out-of-image / out-of-batch positions)
     int tile_variant;       // EPI_LSTM: 0 = conv_tile (B through LDS), 1 = split-bf16, 2 = conv_lstm_dma_tile
+    // EPI_CONVT_FUSED only (vf_fused_top.h): the compositing parameters of the same step (device address inside the
+    // schedule), the per-sample "LayerNorm partials published" counters, the launch's failure word, view, pixels
+    const void *fuse_comp;
+    int *fuse_ready;
+    const int *fuse_status;
+    int fuse_view, fuse_nd;
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -398,6 +407,10 @@ __device__ __forceinline__ void lstm_split_epilogue(const PT &p, f32x16 (&acc)[1
 // BD (conv-LSTM, 128 rows): read the weight operand straight from L1/L2 instead of staging it through LDS - the
 // same K order, hence the same bits, measured equally fast, and 32 KiB less LDS per workgroup: the tile of the
 // three-workgroups-per-CU role mode of the persistent launch (vf_persistent.h).
+// epilogue of EPI_CONVT_FUSED, defined in vf_fused_top.h (it needs the compositing code)
+template <int ND, bool FIRST, class PT>
+__device__ __forceinline__ void convt_fused_epilogue(const PT &p, f32x16 (&acc)[1][4], int bx, long long *red, float *smem);
+
 template <int G, int EPI, int MREP, class PT, int RB = 4, bool BD = false>
 __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int by, const int bz,
                                           float *smem) {
@@ -623,7 +636,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
             // input row tap 0 only reaches even output rows, column tap 0 only even output columns - so a step
             // fetches and multiplies only its tap's live parities (LIVE_: bit g = parity g).  Skipped products are
             // exact zeros: the sums are unchanged.
-            constexpr bool kConvT = (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS);
+            constexpr bool kConvT = (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS || EPI >= EPI_CONVT_FUSED);
             const float *wchunk = wlane + (long long)ci * ntaps * K8 * wstep;
             const int nit = ntaps * K8;
             int ky = 0, kx = 0, k8 = 0;
@@ -681,6 +694,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     [[maybe_unused]] const unsigned long long ts2 = VF_TS_NOW();
     // (xch = the double-buffered B area: 32 KiB at 32-channel chunks, disjoint from lnTab / red)
     if constexpr (SPLIT) lstm_split_epilogue<RB>(p, acc, bx, by, red, reinterpret_cast<float *>(bsm));
+    else if constexpr (EPI >= EPI_CONVT_FUSED)
+        convt_fused_epilogue<(EPI - EPI_CONVT_FUSED) / 2 + 1, ((EPI - EPI_CONVT_FUSED) & 1) != 0>(p, acc, bx, red, smem);
     else conv_epilogue<G, EPI, MREP>(p, acc, bx, by, bz, red);
 #ifdef VF_TILE_STATS
     if constexpr (EPI == EPI_LSTM) {

@@ -434,7 +434,7 @@ struct vf_handle {
         int B = -1, items = 0, counters = 0, phases = 0;
         bool dedup = true, lstm_dma = false;
         int xcd_queues = 0, nq = 1, total_q[kRoles][kQueues] = {{0}};
-        bool role_mode = false, roles2 = false;
+        bool role_mode = false, roles2 = false, fuse_top = false;
         double flops = 0.0;
         size_t lds = 0;
         std::vector<int> types, nitems;
@@ -449,6 +449,7 @@ struct vf_handle {
     int xcd_queues = kQueues;           // ticket queues of the persistent launch (vf_set_xcd_queues): kQueues or 1
     // role mode (vf_set_role_mode, vf_persistent.h): three workgroups per CU, the third one serving the light phases
     bool role_mode = false, role_ok = false, role_active = false;
+    bool fuse_top = false;              // vf_set_fuse_top: top transposed conv + compositing as one item (vf_fused_top.h)
     int *d_status = nullptr;            // sticky failure word of the persistent kernel
     unsigned long long *d_stats = nullptr;  // per-phase wait/run ticks (vf_set_phase_stats)
     bool phase_stats = false;
@@ -1191,6 +1192,12 @@ struct LaunchSink {
         VF_HIP_CHECK(hipGetLastError());
         return VF_OK;
     }
+    int top(const ConvLayer &l, const ConvParams &p, const CompositeParams &cp, int ntiles, int view, int d0, int d1,
+            int dfin, bool /*fuse*/) {      // one launch per layer: never fused
+        int rc = conv(PH_CONVT_RAW, l, p, {d0, d1});
+        if (rc) return rc;
+        return composite(cp, ntiles, view, {dfin});
+    }
     static bool failed(int rc) { return rc != VF_OK; }
 };
 #endif
@@ -1260,6 +1267,31 @@ struct ScheduleSink {
         memset(&P, 0, sizeof(P));
         P.type = PH_COMPOSITE; P.comp = p; P.B = p.B; P.gx = ntiles; P.view = view; P.role = role_mode ? 1 : 0;
         return add(P, ntiles * p.B, p.B, deps);
+    }
+    // top transposed conv + compositing: one fused item per conv tile where the tile geometry allows it (a region
+    // of whole 4 x 16 cost-sum blocks, one image and one channel group per tile, LDS), two phases otherwise
+    static bool fusable(const ConvLayer &l, int ND) {
+        return l.NI == 1 && l.ncg == 1 && l.Cout == 32 && l.nsplit == 1 && l.TH * l.TW <= 128 &&
+               (2 * l.TH) % kSumBlockH == 0 && (2 * l.TW) % kSumBlockW == 0 &&
+               fused_top_lds_floats(l.TH, l.TW, ND) * 4 <= 78 * 1024;
+    }
+    int top(const ConvLayer &l, const ConvParams &p, const CompositeParams &cp, int ntiles, int view, int d0, int d1,
+            int dfin, bool fuse) {
+        if (!fuse || !fusable(l, cp.ND)) {
+            const int u = conv(PH_CONVT_RAW, l, p, {d0, d1});
+            if (u < 0) return u;
+            return composite(cp, ntiles, view, {u, dfin});
+        }
+        PhaseDesc P;
+        memset(&P, 0, sizeof(P));
+        P.type = PH_TOP_FUSED; P.conv = p; P.comp = cp; P.B = p.B; P.view = view;
+        P.NI = 1; P.tiles_per_img = l.tilesY * l.tilesX;
+        P.gx = p.B * P.tiles_per_img; P.gy = 1;
+        P.mrep = 1; P.role = 0;
+        P.aux_base = next_counter + p.B;        // behind the completion counters of this phase
+        max_lds = std::max(max_lds, std::max(l.lds_bytes, fused_top_lds_floats(l.TH, l.TW, cp.ND) * 4));
+        flops += 2.0 * (double)p.B * l.Hout * l.Wout * 9.0 * (l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0)) * l.Cout;
+        return add(P, P.gx, 2 * p.B, {d0, d1, dfin});
     }
     static bool failed(int rc) { return rc < 0; }
     static int skipped() { return kSkipped; }
@@ -1469,18 +1501,20 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         }
 
         if (produce) {      // never an all-shared step
+            // the top transposed conv and the compositing go to the sink together: the persistent schedule may
+            // fuse them into one item per tile (vf_fused_top.h)
             p = params(h->convt3, B, h_normed(6), &enc0_n);
             p.out = v.enc6_o; p.stats = v.st_enc6;
-            VF_EMIT(u_t3, sink.conv(PH_CONVT_RAW, h->convt3, p, {u_l7}))
-            int u_top = u_t3;
+            const ConvLayer *top_l = &h->convt3;
+            int top_d0 = u_l7, top_d1 = -1;
             if (h->savp) {  // extra decoder scale: enc7 = convT(concat[relu(LN9(enc6)), relu(LNa(enc00))]), LNb on use
                 // (an encoder-shared enc00 of a context step is read with batch stride 0)
                 SegArg enc6_n = normed(v.enc6_o, (long long)Hc * Wc * 32, v.st_enc6, h->convt3.stats_nparts,
                                        h->convt3.stats_nparts, false, (long long)Hc * Wc * 32, vd.ln_g[8], vd.ln_b[8], 32, 1);
+                VF_EMIT(u_t3, sink.conv(PH_CONVT_RAW, h->convt3, p, {u_l7}))
                 p = params(h->convt4, B, enc6_n, &enc00_n);
                 p.out = v.enc7_o; p.stats = v.st_enc7;
-                VF_EMIT(u_t4, sink.conv(PH_CONVT_RAW, h->convt4, p, {u_t3, u_enc00}))
-                u_top = u_t4;
+                top_l = &h->convt4; top_d0 = u_t3; top_d1 = u_enc00;
             }
 
             CompositeParams cp; memset(&cp, 0, sizeof(cp));
@@ -1511,7 +1545,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
             cp.out_sums = v.sums + (long long)t_out * h->sums_step_stride;
             if (goal_pix)
                 for (int d = 0; d < ND; ++d) { cp.goal[d][0] = goal_pix[2 * d]; cp.goal[d][1] = goal_pix[2 * d + 1]; }
-            VF_EMIT(u_comp, sink.composite(cp, h->ntiles, view, {u_top, u_fin}))
+            VF_EMIT(u_comp, sink.top(*top_l, p, cp, h->ntiles, view, top_d0, top_d1, u_fin, h->fuse_top && !h->role_active && h->persist_wgs_per_cu <= 2))
             last = u_comp;
         }
     }
@@ -1571,7 +1605,7 @@ static int build_schedule_as(vf_handle *h, int B, bool skip_shared, BuiltSchedul
     for (PhaseDesc &P : out.phases) {
         P.q_gy = 1; P.q_inner = 1;
         if (nq > 1) {
-            if (P.type <= PH_CONVT_RAW) {
+            if (P.type <= PH_CONVT_RAW || P.type == PH_TOP_FUSED) {     // (fused: a sample's tiles MUST share a queue)
                 if (P.gy <= nq && nq % P.gy == 0) P.q_gy = P.gy;
                 if (P.NI == 1 && P.n_items == P.gx * P.gy) P.q_inner = P.tiles_per_img;
                 if (P.n_items % (P.q_gy * P.q_inner)) { P.q_gy = 1; P.q_inner = 1; }
@@ -1642,11 +1676,11 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
             if (!found) return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + " depends on a later phase");
             if (P.dep[d].expect <= 0) return fail(VF_ERR_INVALID, "non-positive expected count");
         }
-        const int ncnt = P.whole ? 1 : P.B;
+        const int ncnt = P.whole ? 1 : (P.type == PH_TOP_FUSED ? 2 * P.B : P.B);
         if (P.cnt_base < 0 || P.cnt_base + ncnt > bs.counters) return fail(VF_ERR_INVALID, "counter out of range");
         // every pointer a tile dereferences must lie inside an allocation of this handle
         bool ok = true;
-        if (P.type <= PH_FC_PARTIAL) {
+        if (P.type <= PH_FC_PARTIAL || P.type == PH_TOP_FUSED) {
             const ConvParams &c = P.conv;
             for (int s = 0; s < c.nseg; ++s) {
                 const long long span = (long long)(P.B - 1) * c.seg[s].bstride + (long long)c.Hin * c.Win * c.seg[s].C;
@@ -1655,10 +1689,14 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
             }
             ok = ok && in_allocs(h, c.Wp, 16) && in_allocs(h, c.bias, 4) && in_allocs(h, c.out, 4);
             ok = ok && in_allocs(h, c.cstate, 4) && in_allocs(h, c.cstate_in, 4) && in_allocs(h, c.stats, 8);
-        } else if (P.type == PH_COMPOSITE) {
+        }
+        if (P.type == PH_TOP_FUSED && (P.aux_base != P.cnt_base + P.B || P.aux_base + P.B > bs.counters))
+            return fail(VF_ERR_INVALID, "fused phase: bad auxiliary counters");
+        if (P.type <= PH_FC_PARTIAL) {
+        } else if (P.type == PH_COMPOSITE || P.type == PH_TOP_FUSED) {
             const CompositeParams &c = P.comp;
             const size_t hw = (size_t)c.H * c.W;
-            ok = ok && in_allocs(h, c.enc6, (size_t)P.B * hw * 32 * 4);
+            if (P.type == PH_COMPOSITE) ok = ok && in_allocs(h, c.enc6, (size_t)P.B * hw * 32 * 4);
             ok = ok && in_allocs(h, c.prev_frame, ((size_t)(P.B - 1) * c.prev_frame_bstride + hw * 3) * 4);
             ok = ok && in_allocs(h, c.prev_distrib, ((size_t)(P.B - 1) * c.prev_distrib_bstride + hw * c.ND) * 4);
             ok = ok && in_allocs(h, c.out_frame, ((size_t)(P.B - 1) * c.out_frame_bstride + hw * 3) * 4);
@@ -1724,6 +1762,11 @@ extern "C" int vf_set_role_mode(vf_handle *h, int32_t enable) {     // (the devi
     h->role_mode = enable != 0;
     return VF_OK;
 }
+extern "C" int vf_set_fuse_top(vf_handle *h, int32_t enable) {
+    if (!h) return fail(VF_ERR_INVALID, "null handle");
+    h->fuse_top = enable != 0;
+    return VF_OK;
+}
 #else   // ------------------------------------------------------------------ device execution
 
 // the zero initial LSTM state is one shared image per layer
@@ -1784,7 +1827,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     const bool skip_shared = shared_cache_hit(h, cfg);
     vf_handle::SchedCache &sc_host = h->sched[skip_shared ? 1 : 0];
     if (sc_host.B != B || sc_host.dedup != h->dedup || sc_host.lstm_dma != h->lstm_dma ||
-        sc_host.xcd_queues != h->xcd_queues || sc_host.role_mode != h->role_mode) {
+        sc_host.xcd_queues != h->xcd_queues || sc_host.role_mode != h->role_mode || sc_host.fuse_top != h->fuse_top) {
         BuiltSchedule bs;
         if ((rc = build_schedule(h, B, skip_shared, bs))) return rc;
         // Upload without synchronising the caller's stream: the copy is stream-ordered behind the
@@ -1794,6 +1837,15 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         const int slot = h->stage_next;
         h->stage_next = (slot + 1) % kSchedRing;
         if (h->stage_used[slot]) VF_HIP_CHECK(hipEventSynchronize(h->stage_done[slot]));
+        for (size_t i = 0; i < bs.phases.size(); ++i) {     // device addresses the fused items need
+            PhaseDesc &P = bs.phases[i];
+            if (P.type != PH_TOP_FUSED) continue;
+            P.conv.fuse_comp = &sc_host.d_phases[i].comp;
+            P.conv.fuse_ready = h->d_sync + kSyncHead + P.aux_base;
+            P.conv.fuse_status = h->d_status;
+            P.conv.fuse_view = P.view;
+            P.conv.fuse_nd = h->ND;
+        }
         memcpy(h->stage[slot], bs.phases.data(), bs.phases.size() * sizeof(PhaseDesc));
         VF_HIP_CHECK(hipMemcpyAsync(sc_host.d_phases, h->stage[slot], bs.phases.size() * sizeof(PhaseDesc),
                                     hipMemcpyHostToDevice, st));
@@ -1801,6 +1853,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         h->stage_used[slot] = true;
         sc_host.B = B; sc_host.dedup = h->dedup; sc_host.lstm_dma = h->lstm_dma;
         sc_host.xcd_queues = h->xcd_queues; sc_host.role_mode = h->role_mode; sc_host.roles2 = bs.roles2;
+        sc_host.fuse_top = h->fuse_top;
         sc_host.items = bs.items; sc_host.counters = bs.counters;
         sc_host.nq = bs.nq;
         for (int r = 0; r < kRoles; ++r)
@@ -1948,6 +2001,12 @@ int vf_set_persistent(vf_handle *h, int32_t enable) {
 int vf_set_role_mode(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->role_mode = enable != 0;
+    return VF_OK;
+}
+
+int vf_set_fuse_top(vf_handle *h, int32_t enable) {
+    if (!h) return fail(VF_ERR_INVALID, "null handle");
+    h->fuse_top = enable != 0;
     return VF_OK;
 }
 

@@ -1,0 +1,211 @@
+// vf_fused_top.h - the top transposed convolution of the decoder fused with the compositing of the next frame.
+//
+// Unfused, the top decoder tensor (64x64x32 floats per sample-step; 128x128x32 in arch 1) is written by the
+// transposed conv and read back by the compositing tiles: 1 - 4 MB per sample-step of HBM traffic and two items
+// with their fixed costs.  Fused, one item = one transposed-conv tile (128 input pixels -> 512 output pixels):
+//   1. the K loop of conv_tile<4, EPI_CONVT_FUSED> leaves the tile in the accumulators;
+//   2. bias, the tile's exact LayerNorm partial (integers), published with a release + a per-sample counter;
+//   3. the haloed previous frame / distributions of the tile's output region and the sample's CDNA kernels go to LDS;
+//   4. the item WAITS until the sample's other tiles have published their partials (they are adjacent tickets of the
+//      same queue, drawn within microseconds of each other): LayerNorm needs the statistics of the whole image;
+//   5. the outputs go through LDS ([256 px][36]: lane = channel on the way in, thread = pixel on the way out), four
+//      cost-sum blocks (4 rows x 16 columns, one per wave) at a time, and composite_pixel() - the very code of the
+//      stand-alone compositing tile - finishes every pixel.
+// Deadlock: a waiting item only waits for tiles of its own sample; a queue hands tickets out in order, so all
+// but the last group of every queue is completely drawn and finishes; at most kQueues x (tiles - 1) workgroups can
+// therefore be waiting for undrawn mates, far fewer than are resident.  The wait is bounded like every other one.
+// Bit-identity with the unfused path: same K loop, same bias add, same statistics, same composite_pixel on the same
+// floats, cost sums per block in the same lane order (the per-layer launches stay unfused and are compared in tests).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vf_conv_mfma.h"
+#include "vf_small_kernels.h"
+
+namespace vf {
+
+constexpr unsigned kFusedSpinLimit = 1u << 24;
+constexpr int kFusedCtlGoal = 8;        // == kCtlGoal of vf_persistent.h (checked there)
+
+// LDS floats the fused epilogue needs for a tile of TH x TW input pixels (host + device)
+__host__ __device__ inline size_t fused_top_lds_floats(int TH, int TW, int ND) {
+    const size_t halo = (size_t)(2 * TH + 4) * (2 * TW + 4);
+    return (size_t)256 * kCompEncPad + halo * (3 + ND) + (size_t)kTaps * 10 + 16 + 64;
+}
+
+template <int ND, bool FIRST, class PT, class CT>
+__device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 (&acc)[1][4], const int bx,
+                                               long long *red, float *smem, const int *goal) {
+    constexpr int K = 10;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    const int tiles_per_img = p.tilesY * p.tilesX;
+    const int b = bx / tiles_per_img, tile_id = bx - b * tiles_per_img;
+    const int ty0 = (tile_id / p.tilesX) * p.TH, tx0 = (tile_id % p.tilesX) * p.TW;    // input coordinates
+    const TileDiv div_tw(p.TW);
+
+    // ---- 2. bias + exact statistics of this tile (as conv_epilogue<4, EPI_CONVT_RAW_STATS>)
+    float bias_g[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias_g[g] = p.bias[g * 32 + n];
+    long long ssum = 0, ssq = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int yy = div_tw.div(row), xx = row - yy * p.TW;
+        const bool ok = row < p.TH * p.TW && ty0 + yy < p.Hout && tx0 + xx < p.Wout;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float v = acc[0][g][r] + bias_g[g];
+            acc[0][g][r] = v;
+            if (ok) { ssum += stat_q(v); ssq += stat_q2(v); }
+        }
+    }
+    const long long wsum = wave_sum(ssum), wsq = wave_sum(ssq);
+    __syncthreads();                        // the operand tile is dead; `red` lies behind it
+    if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
+    __syncthreads();
+    if (tid == 0) {
+        long long su = 0, sq = 0;
+        for (int w = 0; w < 4; ++w) { su += red[2 * w]; sq += red[2 * w + 1]; }
+        long long *dst = p.stats + ((long long)b * p.stats_nparts + tile_id) * 2;
+        dst[0] = su; dst[1] = sq;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(p.fuse_ready + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                        // red is dead from here on: the LDS below may cover it
+
+    // ---- LDS layout of the compositing part
+    const int RH = 2 * p.TH, RW = 2 * p.TW;             // output region of this tile
+    const int HW_ = RW + 4, HH_ = RH + 4;               // its halo tile
+    const int oy0 = 2 * ty0, ox0 = 2 * tx0;
+    float *s_enc = smem;                                 // [256][kCompEncPad]
+    float *s_frame = s_enc + 256 * kCompEncPad;          // [HH_ * HW_][3]
+    float *s_dist = s_frame + HH_ * HW_ * 3;             // [HH_ * HW_][ND]
+    float *s_kern = s_dist + HH_ * HW_ * ND;             // [kTaps * K]
+    float *s_ln = s_kern + kTaps * K;                    // [2]
+    float *s_dscale = s_ln + 2;                          // [ND]
+    int *s_flag = reinterpret_cast<int *>(s_dscale + ND + 1);
+    const int nblocks = sum_blocks(c.H, c.W);
+
+    // ---- 3. scale of the previous distributions, CDNA kernels, halo
+    for (int d = (wave + 3) & 3; d < ND; d += 4) {
+        float sc = 1.0f;
+        if (c.prev_sums) {
+            double su = 0.0;
+            const double *pp = c.prev_sums + ((long long)b * ND + d) * nblocks * 2;
+            for (int k = lane; k < nblocks; k += 64) su += pp[2 * k];
+            su = wave_sum(su);
+            sc = (float)(1.0 / su);
+        }
+        if (lane == 0) s_dscale[d] = sc;
+    }
+    for (int i = tid; i < kTaps * K; i += 256) s_kern[i] = c.kern[(long long)b * kTaps * K + i];
+    __syncthreads();
+    {
+        const float *pf = c.prev_frame + (long long)b * c.prev_frame_bstride;
+        const float *pd = c.prev_distrib + (long long)b * c.prev_distrib_bstride;
+        const TileDiv div_hw(HW_);
+        for (int i = tid; i < HH_ * HW_; i += 256) {
+            const int ly = div_hw.div(i), lx = i - ly * HW_;
+            const int y = oy0 + ly - 2, x = ox0 + lx - 2;
+            const bool in = y >= 0 && y < c.H && x >= 0 && x < c.W;
+            const long long o = (long long)y * c.W + x;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) s_frame[i * 3 + ch] = in ? pf[o * 3 + ch] : 0.f;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) s_dist[i * ND + d] = in ? pd[o * ND + d] * s_dscale[d] : 0.f;
+        }
+    }
+
+    // ---- 4. wait for the sample's other tiles, then the LayerNorm of the whole image
+    if (wave == 0) {
+        unsigned spins = 0;
+        int ok = 1;
+        if (lane == 0) {
+            while (__hip_atomic_load(p.fuse_ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tiles_per_img) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > kFusedSpinLimit ||
+                    __hip_atomic_load(p.fuse_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            *s_flag = ok;
+        }
+        __builtin_amdgcn_wave_barrier();
+        ok = __shfl(ok, 0, 64);
+        if (ok) {
+            long long su = 0, sq = 0;
+            const long long *pp = p.stats + (long long)b * p.stats_nparts * 2;
+            for (int k = lane; k < tiles_per_img; k += 64) {
+                su += __hip_atomic_load(pp + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sq += __hip_atomic_load(pp + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            su = wave_sum(su); sq = wave_sum(sq);
+            if (lane == 0) ln_from_totals(su, sq, c.ln_inv_n, s_ln[0], s_ln[1]);
+        }
+    }
+    __syncthreads();
+    if (*s_flag == 0) {                      // a mate never arrived: raise the launch's failure word and give up
+        if (tid == 0) atomicExch(const_cast<int *>(p.fuse_status), 1);
+        return;
+    }
+    const float mean = s_ln[0], rstd = s_ln[1];
+
+    // ---- 5. four blocks (4 rows x 16 columns, one per wave) at a time through LDS
+    const int nbx = RW / kSumBlockW, nby = RH / kSumBlockH, nblk = nbx * nby;
+    for (int pass = 0; pass * 4 < nblk; ++pass) {
+        if (pass) __syncthreads();           // the previous pass has read s_enc
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int yy = div_tw.div(row), xx = row - yy * p.TW;
+            if (row >= p.TH * p.TW) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int oy = 2 * yy + (g >> 1), ox = 2 * xx + (g & 1);
+                const int blk = (oy >> 2) * nbx + (ox >> 4);
+                if ((blk >> 2) == pass)
+                    s_enc[((blk & 3) * 64 + (oy & 3) * 16 + (ox & 15)) * kCompEncPad + n] = acc[0][g][r];
+            }
+        }
+        __syncthreads();
+        const int blk = pass * 4 + wave;
+        const int byl = blk / nbx, bxl = blk - byl * nbx;
+        const int hy = byl * kSumBlockH + (lane >> 4), hx = bxl * kSumBlockW + (lane & 15);   // inside the region
+        const int y = oy0 + hy, x = ox0 + hx;
+        const bool valid = blk < nblk && y < c.H && x < c.W;
+        double cost[2 * ND];
+#pragma unroll
+        for (int i = 0; i < 2 * ND; ++i) cost[i] = 0.0;
+        if (valid)
+            composite_pixel<ND, K, FIRST>(c, b, y, x, &s_enc[tid * kCompEncPad], mean, rstd, s_frame, s_dist, s_kern, HW_,
+                                          hy, hx, goal, cost);
+#pragma unroll
+        for (int i = 0; i < 2 * ND; ++i) cost[i] = wave_sum(cost[i]);
+        const int y_blk = oy0 + byl * kSumBlockH, x_blk = ox0 + bxl * kSumBlockW;
+        if (lane == 0 && blk < nblk && y_blk < c.H && x_blk < c.W) {
+            const int gblk = (y_blk / kSumBlockH) * sum_blocks_x(c.W) + x_blk / kSumBlockW;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                double *dst = c.out_sums + (((long long)b * ND + d) * nblocks + gblk) * 2;
+                dst[0] = cost[2 * d]; dst[1] = cost[2 * d + 1];
+            }
+        }
+    }
+}
+
+// epilogue hook of conv_tile<4, fused_epi(ND, FIRST), 1>: the compositing parameters (a device address inside the
+// schedule) are read through the constant address space, the goal pixels from the launch's LDS control block
+template <int ND, bool FIRST, class PT>
+__device__ __forceinline__ void convt_fused_epilogue(const PT &p, f32x16 (&acc)[1][4], int bx, long long *red, float *smem) {
+    typedef const __attribute__((address_space(4))) CompositeParams CT;
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p.fuse_comp);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    CT &c = *(CT *)(((unsigned long long)hi << 32) | lo);
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int *goal = reinterpret_cast<const int *>(smem_all) + kFusedCtlGoal + p.fuse_view * ND * 2;
+    fused_top_body<ND, FIRST>(p, c, acc, bx, red, smem, goal);
+}
+
+}  // namespace vf

@@ -20,12 +20,14 @@
 #include "vf_conv_mfma.h"
 #include "vf_small_kernels.h"
 #include "vf_conv_bf16x6.h"
+#include "vf_fused_top.h"
 
 namespace vf {
 
 enum PhaseType {
     PH_LSTM = 0, PH_CONV_RELU, PH_CONV_RAW, PH_CONVT_RELU, PH_CONVT_RAW, PH_FC_PARTIAL,
-    PH_SA, PH_CDNA_FIN, PH_COMPOSITE
+    PH_SA, PH_CDNA_FIN, PH_COMPOSITE,
+    PH_TOP_FUSED            // top transposed conv + compositing in one item (vf_fused_top.h)
 };
 
 constexpr int kMaxDeps = 3;
@@ -59,6 +61,7 @@ struct PhaseDesc {
     int prec;               // conv-LSTM tile: 0 fp32 (B through LDS), 1 split-bf16, 2 fp32 DMA tile, 3 fp32 with B from L2
     int view;               // camera view this phase belongs to (selects the goal pixels of PH_COMPOSITE)
     int cnt_base;
+    int aux_base;           // PH_TOP_FUSED: first of the per-sample "LayerNorm partial published" counters
     int ndep;
     PhaseDep dep[kMaxDeps];
     ConvParams conv;
@@ -69,6 +72,7 @@ struct PhaseDesc {
 
 constexpr int kCtlWords = 64;               // LDS control block: [0..3] scheduler, [8..8+32) goal pixels
 constexpr int kCtlGoal = 8;
+static_assert(kCtlGoal == kFusedCtlGoal, "vf_fused_top.h reads the goal pixels from the control block");
 
 struct Schedule {
     const PhaseDesc *phases;
@@ -313,6 +317,13 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
                 case PH_CONVT_RAW: conv_tile_call<4, EPI_CONVT_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
                 case PH_FC_PARTIAL:
                     conv_tile_call<1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx);
+                    break;
+                case PH_TOP_FUSED:      // (two workgroups per CU only: a device function shared with the 168-VGPR
+                                        // instance of this kernel is compiled for 168 VGPRs, and this one then spills)
+                    if constexpr (WPS <= 2) {
+                        if (P.comp.first_frame) conv_tile_call<4, fused_epi(ND, true), 1>(&P.conv, bx, 0, 0);
+                        else conv_tile_call<4, fused_epi(ND, false), 1>(&P.conv, bx, 0, 0);
+                    }
                     break;
                 case PH_COMPOSITE:
                     if (P.comp.first_frame) composite_tile_call<ND, true>(&P.comp, local % P.gx, b0, P.view);

@@ -149,6 +149,98 @@ __host__ __device__ constexpr int composite_lds_floats() {
     return ((composite_small_floats<ND, K>() + 3) & ~3) + kCompTile * kCompTile * kCompEncPad;
 }
 
+// One output pixel (y, x) of sample b: LN + relu of its 32 features (a row of the LDS feature tile), the two 1x1
+// heads, softmax, the effective 5x5 flow kernel over the haloed previous frame / distributions in LDS
+// (halo_w = pixels per halo row, (hy, hx) = the pixel's position inside the halo tile, halo 2), outputs and cost terms.
+// Shared by the stand-alone compositing tile and the fused transposed-conv + compositing tile: same expressions,
+// same bits.
+template <int ND, int K, bool FIRST, class PT>
+__device__ __forceinline__ void composite_pixel(const PT &p, const int b, const int y, const int x, const float *feat,
+                                                const float mean, const float rstd, const float *s_frame,
+                                                const float *s_dist, const float *s_kern, const int halo_w,
+                                                const int hy, const int hx, const int *goal, double (&cost)[2 * ND]) {
+    constexpr int NM = K + 1;
+    // ---- LN9 + relu of this pixel's 32 features, then the two 1x1 heads
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(feat);
+    float o_rgb[3], o_m[NM];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o_rgb[j] = p.b_rgb[j];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) o_m[j] = p.b_mask[j];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4 raw = src[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = q * 4 + e;
+            const float f = fmaxf(fmaf((raw[e] - mean) * rstd, p.gamma[c], p.beta[c]), 0.f);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) o_rgb[j] = fmaf(f, p.w_rgb[c * 3 + j], o_rgb[j]);
+#pragma unroll
+            for (int j = 0; j < NM; ++j) o_m[j] = fmaf(f, p.w_mask[c * NM + j], o_m[j]);
+        }
+    }
+    float mx = o_m[0];
+#pragma unroll
+    for (int j = 1; j < NM; ++j) mx = fmaxf(mx, o_m[j]);
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < NM; ++j) { o_m[j] = __expf(o_m[j] - mx); den += o_m[j]; }
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int j = 0; j < NM; ++j) o_m[j] *= inv;
+
+    // ---- per-pixel effective flow kernel: keff[tap] = sum_k mask[k+2] * kern[tap][k]
+    // (arch 1: mask 2 weighs the first context frame, the warps use masks 3.. and kernels 0..K-3)
+    float of[3], od[ND];
+    const int ctr = (hy + 2) * halo_w + (hx + 2);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        of[c] = fmaf(o_m[0], s_frame[ctr * 3 + c], o_m[1] * sigmoidf_(o_rgb[c]));
+#pragma unroll
+    for (int d = 0; d < ND; ++d) od[d] = o_m[0] * s_dist[ctr * ND + d];
+    if constexpr (FIRST) {
+        const long long o1 = (long long)y * p.W + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) of[c] = fmaf(o_m[2], p.first_frame[o1 * 3 + c], of[c]);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) od[d] = fmaf(o_m[2], p.first_distrib[o1 * ND + d], od[d]);
+        // the warp loop below pairs kernel k with o_m[k + 2]: shift the warp masks down by one and
+        // retire the last kernel (its product with 0 leaves the sum unchanged)
+#pragma unroll
+        for (int j = 2; j < K; ++j) o_m[j] = o_m[j + 1];
+        o_m[K] = 0.f;
+    }
+#pragma unroll
+    for (int dy = 0; dy < kDnaKern; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < kDnaKern; ++dx) {
+            const int tap = dy * kDnaKern + dx;
+            float ke = 0.f;
+#pragma unroll
+            for (int k = 0; k < K - 1; ++k) ke = fmaf(o_m[k + 2], s_kern[tap * K + k], ke);
+            const int sp = (hy + dy) * halo_w + (hx + dx);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) of[c] = fmaf(ke, s_frame[sp * 3 + c], of[c]);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) od[d] = fmaf(ke, s_dist[sp * ND + d], od[d]);
+        }
+    }
+    const long long o = (long long)y * p.W + x;
+    float *fo = p.out_frame + (long long)b * p.out_frame_bstride + o * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) fo[c] = of[c];
+    float *dout = p.out_distrib + (long long)b * p.out_distrib_bstride + o * ND;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        dout[d] = od[d];
+        const float ry = (float)(y - goal[2 * d]), rx = (float)(x - goal[2 * d + 1]);
+        const float dist = sqrtf(fmaf(ry, ry, rx * rx));
+        cost[2 * d] = (double)od[d];
+        cost[2 * d + 1] = (double)od[d] * (double)dist;
+    }
+}
+
 // one 16x16 pixel tile of one sample.  FIRST (arch 1, savp_arch.py): the first context frame is one more compositing
 // layer - a template parameter, because a run-time branch around the mask bookkeeping costs the CDNA path 3.5 us per
 // tile (measured).
@@ -235,88 +327,9 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
 #pragma unroll
     for (int i = 0; i < 2 * ND; ++i) cost[i] = 0.0;
 
-    if (valid) {
-        // ---- LN9 + relu of this pixel's 32 features, then the two 1x1 heads
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(&s_enc[tid * kCompEncPad]);
-        float o_rgb[3], o_m[NM];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) o_rgb[j] = p.b_rgb[j];
-#pragma unroll
-        for (int j = 0; j < NM; ++j) o_m[j] = p.b_mask[j];
-        const float mean = s_ln[0], rstd = s_ln[1];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f32x4 raw = src[q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = q * 4 + e;
-                const float f = fmaxf(fmaf((raw[e] - mean) * rstd, p.gamma[c], p.beta[c]), 0.f);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) o_rgb[j] = fmaf(f, p.w_rgb[c * 3 + j], o_rgb[j]);
-#pragma unroll
-                for (int j = 0; j < NM; ++j) o_m[j] = fmaf(f, p.w_mask[c * NM + j], o_m[j]);
-            }
-        }
-        float mx = o_m[0];
-#pragma unroll
-        for (int j = 1; j < NM; ++j) mx = fmaxf(mx, o_m[j]);
-        float den = 0.f;
-#pragma unroll
-        for (int j = 0; j < NM; ++j) { o_m[j] = __expf(o_m[j] - mx); den += o_m[j]; }
-        const float inv = 1.0f / den;
-#pragma unroll
-        for (int j = 0; j < NM; ++j) o_m[j] *= inv;
-
-        // ---- per-pixel effective flow kernel: keff[tap] = sum_k mask[k+2] * kern[tap][k]
-        // (arch 1: mask 2 weighs the first context frame, the warps use masks 3.. and kernels 0..K-3)
-        float of[3], od[ND];
-        const int ctr = (ly + 2) * HS + (lx + 2);
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            of[c] = fmaf(o_m[0], s_frame[ctr * 3 + c], o_m[1] * sigmoidf_(o_rgb[c]));
-#pragma unroll
-        for (int d = 0; d < ND; ++d) od[d] = o_m[0] * s_dist[ctr * ND + d];
-        if constexpr (FIRST) {
-            const long long o1 = (long long)y * p.W + x;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) of[c] = fmaf(o_m[2], p.first_frame[o1 * 3 + c], of[c]);
-#pragma unroll
-            for (int d = 0; d < ND; ++d) od[d] = fmaf(o_m[2], p.first_distrib[o1 * ND + d], od[d]);
-            // the warp loop below pairs kernel k with o_m[k + 2]: shift the warp masks down by one and
-            // retire the last kernel (its product with 0 leaves the sum unchanged)
-#pragma unroll
-            for (int j = 2; j < K; ++j) o_m[j] = o_m[j + 1];
-            o_m[K] = 0.f;
-        }
-#pragma unroll
-        for (int dy = 0; dy < kDnaKern; ++dy) {
-#pragma unroll
-            for (int dx = 0; dx < kDnaKern; ++dx) {
-                const int tap = dy * kDnaKern + dx;
-                float ke = 0.f;
-#pragma unroll
-                for (int k = 0; k < K - 1; ++k) ke = fmaf(o_m[k + 2], s_kern[tap * K + k], ke);
-                const int sp = (ly + dy) * HS + (lx + dx);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) of[c] = fmaf(ke, s_frame[sp * 3 + c], of[c]);
-#pragma unroll
-                for (int d = 0; d < ND; ++d) od[d] = fmaf(ke, s_dist[sp * ND + d], od[d]);
-            }
-        }
-        const long long o = (long long)y * p.W + x;
-        float *fo = p.out_frame + (long long)b * p.out_frame_bstride + o * 3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) fo[c] = of[c];
-        float *dout = p.out_distrib + (long long)b * p.out_distrib_bstride + o * ND;
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            dout[d] = od[d];
-            const float ry = (float)(y - goal[2 * d]), rx = (float)(x - goal[2 * d + 1]);
-            const float dist = sqrtf(fmaf(ry, ry, rx * rx));
-            cost[2 * d] = (double)od[d];
-            cost[2 * d + 1] = (double)od[d] * (double)dist;
-        }
-    }
+    if (valid)
+        composite_pixel<ND, K, FIRST>(p, b, y, x, &s_enc[tid * kCompEncPad], s_ln[0], s_ln[1], s_frame, s_dist, s_kern, HS,
+                                      ly, lx, goal, cost);
     // ---- cost sums of this wave's block (4 rows x 16 columns): lanes in a fixed butterfly, one entry per block
 #pragma unroll
     for (int i = 0; i < 2 * ND; ++i) cost[i] = wave_sum(cost[i]);

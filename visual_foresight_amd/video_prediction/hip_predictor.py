@@ -90,6 +90,7 @@ class HipVPredEvaluation(object):
         self.set_lstm_tile(int(hp.get('lstm_tile', os.environ.get('VF_LSTM_TILE', 0))))
         self.set_xcd_queues(int(hp.get('xcd_queues', os.environ.get('VF_XCD_QUEUES', 1))))
         self.set_role_mode(int(hp.get('role_mode', os.environ.get('VF_ROLE_MODE', 0))))
+        self.set_fuse_top(int(hp.get('fuse_top', os.environ.get('VF_FUSE_TOP', 0))))
         self.weights = None
         self._ctx_key = None
         self._last_M = 0
@@ -129,6 +130,11 @@ class HipVPredEvaluation(object):
         """Three workgroups per CU, the third one serving the light phases (vf_set_role_mode); bit-identical results."""
         _lib.check(self._libh.vf_set_role_mode(self._handle, int(bool(enable))))
         self.role_mode = bool(enable)
+
+    def set_fuse_top(self, enable):
+        """Top transposed conv + compositing as one item per tile (vf_set_fuse_top); bit-identical results."""
+        _lib.check(self._libh.vf_set_fuse_top(self._handle, int(bool(enable))))
+        self.fuse_top = bool(enable)
 
     def role_census(self):
         """-> (role mode active in the last launch, [CUs with k workgroup arrivals for k = 0..7])."""
