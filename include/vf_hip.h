@@ -205,7 +205,7 @@ int vf_set_xcd_queues(vf_handle *h, int32_t enable);
 int vf_set_role_mode(vf_handle *h, int32_t enable);
 int vf_debug_role_census(vf_handle *h, int32_t *active, int32_t *hist8);
 
-/* Fused decoder top of the persistent rollout (no reference counterpart).  The last transposed convolution and the
+/* Fused decoder top of the persistent rollout (default on; no reference counterpart).  The last transposed convolution and the
  * compositing of the next frame become ONE item per tile: the tile stays in registers / LDS, its LayerNorm partial
  * is published, the item waits for the sample's other tiles and composes its pixels itself - the full-resolution
  * decoder tensor is never written to memory (visual_foresight_amd/csrc/vf_fused_top.h).  Same arithmetic on the same

@@ -529,6 +529,7 @@ def test_fused_decoder_top_is_invisible_in_the_results(H, W, nd, M):
     actions = rs.normal(0, 0.1, (M, T, 4))
     goal = rs.randint(0, min(H, W), (1, nd, 2))
     pred, weights = _predictor(H, W, T, nd, bs=M)
+    pred.set_fuse_top(0)            # the two-phase schedule
     base, base_pt = pred.score(ctx, {'actions': actions}, goal)
     ref = pred(ctx, {'actions': actions})
     hp = dict(designated_pixel_count=nd, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,

@@ -449,7 +449,7 @@ struct vf_handle {
     int xcd_queues = kQueues;           // ticket queues of the persistent launch (vf_set_xcd_queues): kQueues or 1
     // role mode (vf_set_role_mode, vf_persistent.h): three workgroups per CU, the third one serving the light phases
     bool role_mode = false, role_ok = false, role_active = false;
-    bool fuse_top = false;              // vf_set_fuse_top: top transposed conv + compositing as one item (vf_fused_top.h)
+    bool fuse_top = true;               // vf_set_fuse_top: top transposed conv + compositing as one item (vf_fused_top.h)
     int *d_status = nullptr;            // sticky failure word of the persistent kernel
     unsigned long long *d_stats = nullptr;  // per-phase wait/run ticks (vf_set_phase_stats)
     bool phase_stats = false;

@@ -136,30 +136,38 @@ __device__ __forceinline__ float *tile_lds() {
     return smem_all + kCtlWords;    // the control block comes first
 }
 
-template <int G, int EPI, int MREP>
+// (WPS: the kernel instance a tile body is compiled for.  Device functions shared by the 2- and the 3-workgroups-
+// per-CU kernels would be compiled once, for the tighter 168-VGPR budget; the unused parameter keeps them apart.)
+// Exception, measured: the 128-row fp32 conv-LSTM tile is FASTER when compiled for 168 VGPRs (C2: 71.69 vs 71.86 ms),
+// so both kernels call the instance tagged 3.
+constexpr int kSharedLstmWps = 3;
+template <int WPS, int G, int EPI, int MREP>
 __device__ __noinline__ void conv_tile_call(const ConvParams *p, int bx, int by, int bz) {
     conv_tile<G, EPI, MREP>(const_params(p), bx, by, bz, tile_lds());
 }
+template <int WPS>
 __device__ __noinline__ void lstm_bd_tile_call(const ConvParams *p, int bx, int by) {
     conv_tile<4, EPI_LSTM, 1, const VF_CONST_AS ConvParams, 4, true>(const_params(p), bx, by, 0, tile_lds());
 }
-template <int RB>
+template <int WPS, int RB>
 __device__ __noinline__ void lstm_split_tile_call(const ConvParams *p, int bx, int by) {
     conv_tile<4, EPI_LSTM, 1, const VF_CONST_AS ConvParams, RB>(const_params(p), bx, by, 0, tile_lds());
 }
+template <int WPS>
 __device__ __noinline__ void lstm_dma_tile_call(const ConvParams *p, int bx, int by) {
     conv_lstm_dma_tile<1>(const_params(p), bx, by, tile_lds());
 }
-template <int MREP>
+template <int WPS, int MREP>
 __device__ __noinline__ void lstm_bf16x6_tile_call(const ConvParams *p, int bx, int by) {
     conv_lstm_bf16x6_tile<MREP>(const_params(p), bx, by, tile_lds());
 }
-template <int ND, bool FIRST>
+template <int WPS, int ND, bool FIRST>
 __device__ __noinline__ void composite_tile_call(const CompositeParams *p, int tile, int b, int view) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
     composite_tile<ND, 10, FIRST>(const_params(p), tile, b, goal, tile_lds());
 }
+template <int WPS>
 __device__ __noinline__ void small_item_call(const PhaseDesc *P, int type, int b0, int b1) {
     float *smem = tile_lds();
     if (type == PH_SA) {
@@ -299,37 +307,37 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
             switch (P.type) {
                 case PH_LSTM:
                     if (P.prec == 1) {
-                        lstm_bf16x6_tile_call<1>(&P.conv, bx, by);      // 128-row tiles only
+                        lstm_bf16x6_tile_call<WPS, 1>(&P.conv, bx, by);      // 128-row tiles only
                     } else if (P.mrep == 0) {
-                        lstm_split_tile_call<2>(&P.conv, bx, by);
+                        lstm_split_tile_call<WPS, 2>(&P.conv, bx, by);
                     } else if (P.mrep < 0) {
-                        lstm_split_tile_call<1>(&P.conv, bx, by);
+                        lstm_split_tile_call<WPS, 1>(&P.conv, bx, by);
                     } else if (P.prec == 3) {
-                        lstm_bd_tile_call(&P.conv, bx, by);
+                        lstm_bd_tile_call<WPS>(&P.conv, bx, by);
                     } else if (P.prec == 2) {
-                        lstm_dma_tile_call(&P.conv, bx, by);
-                    } else if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
-                    else if constexpr (WPS <= 2) conv_tile_call<4, EPI_LSTM, 2>(&P.conv, bx, by, 0);
+                        lstm_dma_tile_call<WPS>(&P.conv, bx, by);
+                    } else if (P.mrep == 1) conv_tile_call<kSharedLstmWps, 4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
+                    else if constexpr (WPS <= 2) conv_tile_call<WPS, 4, EPI_LSTM, 2>(&P.conv, bx, by, 0);
                     break;
-                case PH_CONV_RELU: conv_tile_call<1, EPI_BIAS_RELU, 1>(&P.conv, bx, by, 0); break;
-                case PH_CONV_RAW: conv_tile_call<1, EPI_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
-                case PH_CONVT_RELU: conv_tile_call<4, EPI_CONVT_RELU, 1>(&P.conv, bx, by, 0); break;
-                case PH_CONVT_RAW: conv_tile_call<4, EPI_CONVT_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONV_RELU: conv_tile_call<WPS, 1, EPI_BIAS_RELU, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONV_RAW: conv_tile_call<WPS, 1, EPI_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONVT_RELU: conv_tile_call<WPS, 4, EPI_CONVT_RELU, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONVT_RAW: conv_tile_call<WPS, 4, EPI_CONVT_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
                 case PH_FC_PARTIAL:
-                    conv_tile_call<1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx);
+                    conv_tile_call<WPS, 1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx);
                     break;
                 case PH_TOP_FUSED:      // (two workgroups per CU only: a device function shared with the 168-VGPR
                                         // instance of this kernel is compiled for 168 VGPRs, and this one then spills)
                     if constexpr (WPS <= 2) {
-                        if (P.comp.first_frame) conv_tile_call<4, fused_epi(ND, true), 1>(&P.conv, bx, 0, 0);
-                        else conv_tile_call<4, fused_epi(ND, false), 1>(&P.conv, bx, 0, 0);
+                        if (P.comp.first_frame) conv_tile_call<WPS, 4, fused_epi(ND, true), 1>(&P.conv, bx, 0, 0);
+                        else conv_tile_call<WPS, 4, fused_epi(ND, false), 1>(&P.conv, bx, 0, 0);
                     }
                     break;
                 case PH_COMPOSITE:
-                    if (P.comp.first_frame) composite_tile_call<ND, true>(&P.comp, local % P.gx, b0, P.view);
-                    else composite_tile_call<ND, false>(&P.comp, local % P.gx, b0, P.view);
+                    if (P.comp.first_frame) composite_tile_call<WPS, ND, true>(&P.comp, local % P.gx, b0, P.view);
+                    else composite_tile_call<WPS, ND, false>(&P.comp, local % P.gx, b0, P.view);
                     break;
-                default: small_item_call(&P, P.type, b0, b1); break;
+                default: small_item_call<WPS>(&P, P.type, b0, b1); break;
             }
         }
 

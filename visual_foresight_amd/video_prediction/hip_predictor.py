@@ -90,7 +90,7 @@ class HipVPredEvaluation(object):
         self.set_lstm_tile(int(hp.get('lstm_tile', os.environ.get('VF_LSTM_TILE', 0))))
         self.set_xcd_queues(int(hp.get('xcd_queues', os.environ.get('VF_XCD_QUEUES', 1))))
         self.set_role_mode(int(hp.get('role_mode', os.environ.get('VF_ROLE_MODE', 0))))
-        self.set_fuse_top(int(hp.get('fuse_top', os.environ.get('VF_FUSE_TOP', 0))))
+        self.set_fuse_top(int(hp.get('fuse_top', os.environ.get('VF_FUSE_TOP', 1))))
         self.weights = None
         self._ctx_key = None
         self._last_M = 0
