@@ -142,3 +142,25 @@ def test_savp_two_views_one_launch():
             np.testing.assert_array_equal(scores, first[0])
             np.testing.assert_array_equal(got['predicted_frames'], first[1])
     assert pred.device_status() == 0
+
+
+def test_savp_fused_top_at_128_matches_the_per_layer_launches():
+    """128x128: 32 transposed-conv tiles per sample wait for each other inside the fused decoder top; the
+    persistent launch (fused) and the per-layer launches (never fused) agree bit for bit."""
+    H = W = 128
+    T, M = 2, 5
+    rs = np.random.RandomState(17)
+    ctx = _context(H, W, 2, 6, rs)
+    actions = rs.normal(0, 0.1, (M, T, 6))
+    goal = np.array([[[100, 20], [7, 77]]])
+    pred, _ = _predictor(H, W, T, 2, bs=M)
+    fused, fused_pt = pred.score(ctx, {'actions': actions}, goal)
+    out_fused = pred(ctx, {'actions': actions})
+    pred.set_persistent(0)
+    plain, plain_pt = pred.score(ctx, {'actions': actions}, goal)
+    out_plain = pred(ctx, {'actions': actions})
+    np.testing.assert_array_equal(fused, plain)
+    np.testing.assert_array_equal(fused_pt, plain_pt)
+    np.testing.assert_array_equal(out_fused['predicted_frames'], out_plain['predicted_frames'])
+    np.testing.assert_array_equal(out_fused['predicted_pixel_distributions'], out_plain['predicted_pixel_distributions'])
+    assert pred.device_status() == 0
