@@ -173,6 +173,14 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
     size_t packed_b() const { return (size_t)ncg * G * 32; }
 };
 
+// can the top transposed conv `l` be fused with the compositing (vf_fused_top.h)?  One image and one channel
+// group per tile, an output region of whole 4 x 16 cost-sum blocks, and the LDS of the fused epilogue
+static bool top_fusable(const ConvLayer &l, int ND) {
+    return l.NI == 1 && l.ncg == 1 && l.Cout == 32 && l.nsplit == 1 && l.TH * l.TW <= 128 &&
+           (2 * l.TH) % kSumBlockH == 0 && (2 * l.TW) % kSumBlockW == 0 &&
+           fused_top_lds_floats(l.TH, l.TW, ND) * 4 <= 78 * 1024;
+}
+
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 static size_t conv_lds_bytes(const ConvLayer &l, int KC) {
@@ -828,6 +836,11 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
             if (h->half_ok[k]) h->max_lds = std::max(h->max_lds, h->lstm_half[k].lds_bytes);
             if (h->quarter_ok[k]) h->max_lds = std::max(h->max_lds, h->lstm_quarter[k].lds_bytes);
         }
+    {       // the fused decoder top (vf_fused_top.h) may need more than any stand-alone tile of a small image
+        const ConvLayer &top = h->savp ? h->convt4 : h->convt3;
+        if (top_fusable(top, h->ND))
+            h->max_lds = std::max(h->max_lds, fused_top_lds_floats(top.TH, top.TW, h->ND) * 4);
+    }
     h->max_lds += 16;
     // role mode (three workgroups per CU): exact fp32 only (the split-bf16 tile needs more LDS), every light layer and
     // the weights-from-L2 conv-LSTM tile within a third of the LDS; the occupancy of the 168-VGPR kernel is checked below
@@ -1270,11 +1283,7 @@ struct ScheduleSink {
     }
     // top transposed conv + compositing: one fused item per conv tile where the tile geometry allows it (a region
     // of whole 4 x 16 cost-sum blocks, one image and one channel group per tile, LDS), two phases otherwise
-    static bool fusable(const ConvLayer &l, int ND) {
-        return l.NI == 1 && l.ncg == 1 && l.Cout == 32 && l.nsplit == 1 && l.TH * l.TW <= 128 &&
-               (2 * l.TH) % kSumBlockH == 0 && (2 * l.TW) % kSumBlockW == 0 &&
-               fused_top_lds_floats(l.TH, l.TW, ND) * 4 <= 78 * 1024;
-    }
+    static bool fusable(const ConvLayer &l, int ND) { return top_fusable(l, ND); }
     int top(const ConvLayer &l, const ConvParams &p, const CompositeParams &cp, int ntiles, int view, int d0, int d1,
             int dfin, bool fuse) {
         if (!fuse || !fusable(l, cp.ND)) {
