@@ -2,20 +2,33 @@
 
 Follows ``/root/reference/visual_mpc/policy/cem_controllers/register_gtruth_controller.py``
 ``get_warp_err`` :113-173 and the trade-off normalisation of ``register_gtruth`` :88-91, written
-with explicit loops.  PARITY UNPINNED: the reference file cannot be imported (it needs
-``visual_mpc.registration_network`` and two visualizer modules that are not in the snapshot,
-``:4,5,7``) and the reference has no tests, so no golden vector could be minted; this restatement
-is checked against the product's vectorised version only.  One documented deviation from the
-text of the reference: in point mode (``register_region=False``) the reference leaves
-``region_tradeoff = True`` (``:118``) and therefore never fills the warp errors (``:163-170`` is
-dead), which makes every trade-off NaN; both this oracle and the product use the pixel-L2 error of
-``:165-170`` in point mode, which is evidently what was meant.
+with explicit loops.  PINNED: ``tools/make_golden.py::golden_registration`` imports that file (with
+three more stub modules for the imports of ``:4,5,7``), builds the controller with
+``object.__new__`` and runs the REAL ``get_warp_err`` and ``register_gtruth`` on seeded images and a
+seeded fake warper; ``tests/test_oracle_golden.py`` requires this restatement to reproduce
+``tests/golden/registration.npz`` (tracked pixels bit-exact; warp errors / trade-off to 1e-6,
+because the reference takes ``np.mean`` of the float32 squares IN float32 while the loops here add
+them in float64 - the product's NumPy version, same expression as the reference, is bit-exact).  What stays unpinned is the
+registration NETWORK (absent from the snapshot): ``bilinear_warp_loops`` below is this repo's
+definition of its output convention.
+
+One documented deviation from the text of the reference: in point mode
+(``register_region=False``) the reference leaves ``region_tradeoff = True`` (``:118``), never
+fills the warp errors (``:163-170`` is dead; the fixture records the zeros) and every trade-off
+becomes NaN; ``point_errors='l2'`` (what the product uses) takes the pixel-L2 error of
+``:165-170``, which is evidently what was meant, ``point_errors='reference'`` leaves the zeros.
+In region mode with only ``'start'`` registered the reference raises TypeError (the goal half of
+the branch is unconditional, ``:152-160``); the oracle and the product handle that case.
 """
 import numpy as np
 
 
 def warp_err_loops(icam, pix_t0, goal_pix, start_image, goal_image, start_warp_pts, goal_warp_pts,
-                   warped_start, warped_goal, register_gtruth, register_region):
+                   warped_start, warped_goal, register_gtruth, register_region, pred_height=None,
+                   point_errors='l2'):
+    """``pix_t0`` / ``goal_pix`` [ntask, 2] (row, col) at the resolution of the images handed in (the
+    reference picks its ``*_med`` arrays when that differs from the predictor's, ``:121-128``);
+    ``pred_height``: the predictor's image height, tracked pixels are rescaled to it (``:172``)."""
     H, W = start_image.shape[1:3]
     nreg, ntask = len(register_gtruth), len(pix_t0)
     errs = np.zeros((ntask, nreg))
@@ -42,9 +55,11 @@ def warp_err_loops(icam, pix_t0, goal_pix, start_image, goal_image, start_warp_p
                 desig[p, r] = (np.median(ys), np.median(xs))
             else:
                 d = ref[icam][pix[0], pix[1]] - warped[icam][pix[0], pix[1]]
-                errs[p, r] = np.sqrt(np.sum(d * d))
+                errs[p, r] = np.sqrt(np.sum(d * d)) if point_errors == 'l2' else 0.0
                 desig[p, r] = (pts[icam][pix[0], pix[1], 1], pts[icam][pix[0], pix[1], 0])
             r += 1
+    if pred_height is not None:
+        desig = desig * pred_height / H
     return errs, desig
 
 

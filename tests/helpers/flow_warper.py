@@ -32,3 +32,14 @@ def make_flow_warper(scale=2.0):
         warped, pts = bilinear_warp_loops(current, flow)
         return warped, flow, pts
     return warper
+
+
+def registration_inputs(seed, ncam, H, W, scale=2.5):
+    """Seeded images and the fake warper's outputs, shared by ``tools/make_golden.py`` (which feeds
+    them to the reference's real ``get_warp_err``) and the tests that must reproduce the fixture."""
+    rs = np.random.RandomState(seed)
+    start, goal, cur = (rs.uniform(0, 1, (ncam, H, W, 3)).astype(np.float32) for _ in range(3))
+    warper = make_flow_warper(scale)
+    ws, _, ps = warper(cur, start)
+    wg, _, pg = warper(cur, goal)
+    return start, goal, cur, ws, ps, wg, pg

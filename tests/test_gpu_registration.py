@@ -90,3 +90,52 @@ def test_register_controller_device_path_matches_host_path():
     np.testing.assert_array_equal(dev['actions'], host['actions'])
     assert dev['plan_stat']['tradeoff'].shape == (ncam, 2)
     np.testing.assert_allclose(dev['plan_stat']['tradeoff'].sum(), 1.0, rtol=1e-6)   # one task: weights sum to 1
+
+
+def test_vf_register_reproduces_the_reference_fixture(golden_dir):
+    """``vf_register`` through the C ABI against ``tests/golden/registration.npz`` - outputs of the
+    reference's REAL ``get_warp_err`` (``register_gtruth_controller.py:113-173``) on the same seeded images
+    and flow: tracked pixels bit-exact (window medians / flips of the same float32 warp points), region
+    warp errors to 2e-5 (float32 sums in another order); and the trade-off of ``register_gtruth``
+    (``:88-91``) computed from the device's errors."""
+    import json
+    import os
+    from tests.helpers.flow_warper import registration_inputs, synthetic_flow
+    from visual_foresight_amd.policy.cem_controllers.registration import tradeoff_weights
+    meta = json.load(open(os.path.join(golden_dir, 'registration.json')))
+    arrays = np.load(os.path.join(golden_dir, 'registration.npz'))
+    done = 0
+    for case in meta['cases']:
+        if case.get('pred_height', case['H']) != case['H']:
+            continue                                    # medium-resolution images: host-only feature
+        name, ncam, ntask, H, W = case['name'], case['ncam'], case['ntask'], case['H'], case['W']
+        pred = _predictor(H, W, ncam)
+        region = (5 if H >= 96 else 2) if case['region'] else 0
+        if case.get('full'):
+            rs = np.random.RandomState(case['seed'])
+            start, goal, cur = (rs.uniform(0, 1, (ncam, H, W, 3)).astype(np.float32) for _ in range(3))
+            pix_t0, goal_pix = arrays[name + '/pix_t0'], arrays[name + '/goal_pix']
+        else:
+            start, goal, cur = registration_inputs(case['seed'], ncam, H, W, case['flow_scale'])[:3]
+            pix_t0, goal_pix = np.array(case['pix_t0']), np.array(case['goal_pix'])
+        per_reg = []
+        if 'start' in case['regs']:
+            per_reg.append(pred.register(cur, start, synthetic_flow(cur, start, case['flow_scale']), pix_t0,
+                                         region=region, clip_sub=1))
+        if 'goal' in case['regs']:
+            per_reg.append(pred.register(cur, goal, synthetic_flow(cur, goal, case['flow_scale']), goal_pix,
+                                         region=region, clip_sub=0))
+        desig = np.stack([d for d, _ in per_reg], axis=2)               # [ncam, ntask, nreg, 2]
+        errs = np.stack([e for _, e in per_reg], axis=2)                # [ncam, ntask, nreg]
+        if case.get('full'):
+            np.testing.assert_array_equal(desig.reshape(ncam, -1, 2), arrays[name + '/desig_pix'])
+            np.testing.assert_allclose(errs.reshape(ncam, -1), arrays[name + '/warperrs'], rtol=2e-5)
+            np.testing.assert_allclose(tradeoff_weights(errs).reshape(ncam, -1), arrays[name + '/tradeoff'],
+                                       rtol=4e-5)
+        else:
+            for c in range(ncam):
+                np.testing.assert_array_equal(desig[c], arrays['%s/cam%d/desig' % (name, c)])
+                if case['region']:
+                    np.testing.assert_allclose(errs[c], arrays['%s/cam%d/warperrs' % (name, c)], rtol=2e-5)
+        done += 1
+    assert done == 7

@@ -90,3 +90,61 @@ def test_missing_warper_is_an_error():
                  images=img[:1], state=np.zeros((1, 5)))
         ctrl.act(goal_image=np.zeros((1, 1, 16, 16, 3)), t=1, i_tr=0, desig_pix=[[1, 1]], goal_pix=[[2, 2]],
                  images=img, state=np.zeros((2, 5)))
+
+
+# ------------------------------------------------------------------ pinned to the reference (tests/golden/registration.*)
+def _reg_fixture(golden_dir):
+    import json
+    import os
+    return (json.load(open(os.path.join(golden_dir, 'registration.json'))),
+            np.load(os.path.join(golden_dir, 'registration.npz')))
+
+
+def test_get_warp_err_reproduces_the_reference(golden_dir):
+    """Product ``get_warp_err`` == the reference's real ``get_warp_err`` outputs, bit for bit (same NumPy
+    expressions); point-mode errors are this repo's documented deviation and are not compared."""
+    from tests.helpers.flow_warper import registration_inputs
+    meta, arrays = _reg_fixture(golden_dir)
+    for case in meta['cases']:
+        if case.get('full'):
+            continue
+        name, ncam, H, W = case['name'], case['ncam'], case['H'], case['W']
+        start, goal, cur, ws, ps, wg, pg = registration_inputs(case['seed'], ncam, H, W, case['flow_scale'])
+        pix_t0 = (np.array(case['pix_t0']) * H / case['pred_height']).astype(int)
+        goal_pix = (np.array(case['goal_pix']) * H / case['pred_height']).astype(int)
+        for c in range(ncam):
+            e, d = get_warp_err(c, pix_t0[c], goal_pix[c], start, goal, ps, pg, ws, wg, case['regs'],
+                                case['region'], pred_height=case['pred_height'])
+            np.testing.assert_array_equal(d, arrays['%s/cam%d/desig' % (name, c)])
+            if case['region']:
+                np.testing.assert_array_equal(e, arrays['%s/cam%d/warperrs' % (name, c)])
+            else:
+                assert np.all(arrays['%s/cam%d/warperrs' % (name, c)] == 0) and np.all(e > 0)
+
+
+@pytest.mark.parametrize('name', ['full64', 'full128'])
+def test_controller_register_gtruth_reproduces_the_reference(golden_dir, name):
+    """``RegisterGtruthController.register_gtruth`` (host path) == the reference's ``register_gtruth``
+    (``:54-111``) on the same images and warper: tracked pixels, warp errors and trade-off bit for bit."""
+    from tests.helpers.flow_warper import make_flow_warper
+    meta, arrays = _reg_fixture(golden_dir)
+    case = [c for c in meta['cases'] if c['name'] == name][0]
+    ncam, ntask, H, W = case['ncam'], case['ntask'], case['H'], case['W']
+    rs = np.random.RandomState(case['seed'])
+    start, goal, cur = (rs.uniform(0, 1, (ncam, H, W, 3)).astype(np.float32) for _ in range(3))
+    fake = make_fake_predictor_class(5, H, W, ncam=ncam)
+    fake.n_cam = ncam
+    pol = {'predictor_class': fake, 'verbose': False, 'designated_pixel_count': 2 * ntask,
+           'registration_warper': make_flow_warper(case['flow_scale']), 'register_region': True}
+    ag = {'adim': 4, 'sdim': 5, 'image_height': H, 'image_width': W, 'ncam': ncam}
+    with contextlib.redirect_stdout(io.StringIO()):
+        ctrl = RegisterGtruthController(ag, pol, 0, 1)
+        ctrl.reset()
+    ctrl.desig_pix_t0 = arrays[name + '/pix_t0']
+    ctrl.goal_pix_sel = arrays[name + '/goal_pix']
+    ctrl.goal_image = goal
+    ctrl.plan_stat = {}
+    desig, tradeoff = ctrl.register_gtruth(start, cur)
+    np.testing.assert_array_equal(desig, arrays[name + '/desig_pix'])
+    np.testing.assert_array_equal(tradeoff, arrays[name + '/tradeoff'])
+    np.testing.assert_array_equal(ctrl.plan_stat['warperrs'], arrays[name + '/warperrs'])

@@ -3,7 +3,8 @@
 
 Runs only in the build container: it imports ``/root/reference`` (read-only) with the five
 stub modules SURVEY.md 8(c) lists injected into ``sys.modules`` (funcsigs, tensorflow's
-HParams, cv2, robonet's VPredEvaluation, and the removed ``np.int`` alias), drives the
+HParams, cv2, robonet's VPredEvaluation, and the removed ``np.int`` alias; three more for
+``register_gtruth_controller.py``, see ``install_registration_stubs``), drives the
 reference's own ``get_policy_args`` / ``CEMBaseController`` / ``PixelCostController`` /
 samplers / ``controller_utils`` / ``pred_util`` on seeded synthetic inputs, and stores the
 inputs' seeds plus the observed outputs.  Nothing of the reference travels: the fixtures are
@@ -457,6 +458,114 @@ def golden_traj_layout():
     return arrays, meta
 
 
+# ----------------------------------------------------------------------------- a15 / f2: registration
+def install_registration_stubs():
+    """Three more stubs so that ``register_gtruth_controller.py`` imports: the two visualizer modules
+    (``:4,5``) and ``visual_mpc.registration_network.setup_registration`` (``:7``) are absent from the
+    snapshot.  None of them is touched by ``get_warp_err`` / ``register_gtruth`` apart from the warper
+    object, which the fixture replaces by a seeded fake (``tests/helpers/flow_warper.py``)."""
+    base = 'visual_mpc.policy.cem_controllers.visualizer.'
+    ru = types.ModuleType(base + 'render_utils')
+    ru.resize_image = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError('stub'))
+    mv = types.ModuleType(base + 'make_cem_visuals')
+    mv.CEM_Visual_Preparation_Registration = type('CEM_Visual_Preparation_Registration', (), {})
+    rn = types.ModuleType('visual_mpc.registration_network')
+    sr = types.ModuleType('visual_mpc.registration_network.setup_registration')
+    sr.setup_gdn = lambda conf, gpu_id: None
+    rn.setup_registration = sr
+    sys.modules.update({base + 'render_utils': ru, base + 'make_cem_visuals': mv,
+                        'visual_mpc.registration_network': rn,
+                        'visual_mpc.registration_network.setup_registration': sr})
+
+
+def golden_registration():
+    """Run the reference's REAL ``Register_Gtruth_Controller.get_warp_err`` (:113-173) and
+    ``register_gtruth`` (:54-111) on an instance made with ``object.__new__`` (its ``__init__`` needs
+    a gdnconf.py and the absent network) and a seeded fake warper."""
+    install_registration_stubs()
+    from tests.helpers.flow_warper import registration_inputs
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        from visual_mpc.policy.cem_controllers.register_gtruth_controller import Register_Gtruth_Controller as RGC
+    arrays, meta = {}, {'numpy': np.__version__, 'cases': []}
+
+    def make(ncam, ntask, H, W, regs, region, pred_height, pix_t0, goal_pix):
+        c = object.__new__(RGC)
+        c._hp = HParams(register_gtruth=list(regs), register_region=region)
+        c.ntask, c._n_cam, c._n_desig = ntask, ncam, ntask * len(regs)
+        c.agentparams = {'image_height': H, 'image_width': W}
+        c._img_height = pred_height
+        c.desig_pix_t0 = np.array(pix_t0).reshape(ncam, ntask, 2)
+        c.goal_pix_sel = np.array(goal_pix).reshape(ncam, ntask, 2)
+        # the *_med arrays are what act() derives (:183,190); the reference tiles goal_pix over r first
+        c.desig_pix_t0_med = (c.desig_pix_t0 * H / pred_height).astype(int)
+        c.goal_pix_med = (c.goal_pix_sel * H / pred_height).astype(int)
+        return c
+
+    cases = [  # name, seed, ncam, ntask, H, W, regs, region, pred_height, pix_t0, goal_pix
+        ('region64', 41, 2, 3, 64, 64, ['start', 'goal'], True, 64,
+         [[[0, 0], [63, 63], [1, 62]], [[30, 31], [62, 2], [17, 40]]],
+         [[[63, 63], [0, 0], [62, 1]], [[5, 60], [33, 33], [63, 0]]]),
+        ('region128', 42, 1, 2, 128, 128, ['start', 'goal'], True, 128,
+         [[[3, 125], [70, 64]]], [[[126, 2], [127, 127]]]),
+        ('region48x64', 43, 1, 2, 48, 64, ['start', 'goal'], True, 48,
+         [[[47, 10], [20, 63]]], [[[0, 63], [47, 0]]]),
+        ('point64', 44, 2, 2, 64, 64, ['start', 'goal'], False, 64,
+         [[[0, 0], [63, 63]], [[30, 31], [12, 50]]], [[[63, 0], [9, 9]], [[5, 60], [33, 33]]]),
+        ('point_start_only', 45, 1, 2, 64, 64, ['start'], False, 64,
+         [[[10, 20], [40, 41]]], [[[1, 1], [2, 2]]]),
+        ('region_medium', 46, 1, 2, 96, 96, ['start', 'goal'], True, 48,
+         [[[10, 40], [47, 0]]], [[[24, 24], [0, 47]]]),
+    ]
+    for name, seed, ncam, ntask, H, W, regs, region, ph, pix_t0, goal_pix in cases:
+        start, goal, cur, ws, ps, wg, pg = registration_inputs(seed, ncam, H, W)
+        c = make(ncam, ntask, H, W, regs, region, ph, pix_t0, goal_pix)
+        for icam in range(ncam):
+            with quiet():
+                e, d = c.get_warp_err(icam, start, goal, ps, pg if 'goal' in regs else None, ws,
+                                      wg if 'goal' in regs else None)
+            arrays['%s/cam%d/warperrs' % (name, icam)] = e
+            arrays['%s/cam%d/desig' % (name, icam)] = d
+        meta['cases'].append({'name': name, 'seed': seed, 'ncam': ncam, 'ntask': ntask, 'H': H, 'W': W,
+                              'regs': regs, 'region': region, 'pred_height': ph,
+                              'pix_t0': pix_t0, 'goal_pix': goal_pix, 'flow_scale': 2.5})
+    # region mode with only 'start' registered: the goal half of the region branch is unconditional
+    # (:152-160) and indexes goal_warp_pts = None
+    start, goal, cur, ws, ps, wg, pg = registration_inputs(47, 1, 64, 64)
+    c = make(1, 1, 64, 64, ['start'], True, 64, [[[5, 5]]], [[[6, 6]]])
+    try:
+        with quiet():
+            c.get_warp_err(0, start, goal, ps, None, ws, None)
+        meta['region_start_only'] = 'ok'
+    except TypeError:
+        meta['region_start_only'] = 'TypeError'
+
+    # the whole register_gtruth (:54-111) with the fake warper behind goal_image_warper
+    from tests.helpers.flow_warper import make_flow_warper
+    for name, seed, ncam, ntask, H, W, region in [('full64', 51, 2, 2, 64, 64, True),
+                                                   ('full128', 52, 1, 1, 128, 128, True)]:
+        rs = np.random.RandomState(seed)
+        start, goal, cur = (rs.uniform(0, 1, (ncam, H, W, 3)).astype(np.float32) for _ in range(3))
+        pix_t0 = rs.randint(0, [H, W], (ncam, ntask, 2))
+        goal_pix = rs.randint(0, [H, W], (ncam, ntask, 2))
+        c = make(ncam, ntask, H, W, ['start', 'goal'], region, H, pix_t0, goal_pix)
+        warper = make_flow_warper(2.5)
+        c.goal_image_warper = lambda a, b: warper(a[0], b[0])       # the reference adds a batch axis (:64-66)
+        c.goal_image, c.start_image = goal, start
+        c._net_context, c.plan_stat, c.vd = 2, {}, types.SimpleNamespace()
+        last_frames = np.stack([np.zeros_like(cur), cur], 0)[None]   # [1, n_context, ncam, H, W, 3]
+        with quiet():
+            _, _, tradeoff = c.register_gtruth(start, last_frames)
+        arrays[name + '/pix_t0'], arrays[name + '/goal_pix'] = pix_t0, goal_pix
+        arrays[name + '/desig_pix'] = c.desig_pix
+        arrays[name + '/tradeoff'] = tradeoff
+        arrays[name + '/warperrs'] = c.plan_stat['warperrs']
+        meta['cases'].append({'name': name, 'seed': seed, 'ncam': ncam, 'ntask': ntask, 'H': H, 'W': W,
+                              'regs': ['start', 'goal'], 'region': region, 'full': True, 'flow_scale': 2.5})
+    return arrays, meta
+
+
 def main():
     install_stubs()
     from visual_mpc.policy.cem_controllers import PixelCostController, CEMBaseController
@@ -476,6 +585,7 @@ def main():
     dump('act', *golden_act(ref))
     dump('pred_util', *golden_pred_util(ref))
     dump('traj_layout', *golden_traj_layout())
+    dump('registration', *golden_registration())
     print('wrote fixtures to', OUT, 'with numpy', np.__version__)
     for fn in sorted(os.listdir(OUT)):
         print('  %-20s %8d B' % (fn, os.path.getsize(os.path.join(OUT, fn))))

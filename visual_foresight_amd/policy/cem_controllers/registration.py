@@ -7,7 +7,7 @@ frame (the first frame of the episode and/or the goal image), re-localise every 
 in the current frame and derive per-(camera, registration) trade-off weights from the warp error.
 
 The registration *network* (``visual_mpc.registration_network``, ``:7,32``) is not part of the
-reference snapshot (the file cannot even be imported), so the warper is a plug-in:
+reference snapshot, so the warper is a plug-in:
 
     warper(current [ncam,H,W,3] float32, reference [ncam,H,W,3] float32)
         -> warped [ncam,H,W,3], flow (ignored), warp_pts [ncam,H,W,2]
@@ -33,14 +33,17 @@ def region_bounds(center, width, limit_rows, limit_cols, inclusive_limit):
 
 def get_warp_err(icam, pix_t0, goal_pix, start_image, goal_image, start_warp_pts, goal_warp_pts,
                  warped_image_start, warped_image_goal, register_gtruth=('start', 'goal'),
-                 register_region=False):
+                 register_region=False, pred_height=None):
     """Tracked pixel and warp error of every task for one camera.
 
     pix_t0, goal_pix: [ntask, 2] (row, col) of the designated pixel in the first frame / of the
     goal pixel in the goal image.  Returns ``warperrs [ntask, nreg]`` and ``desig [ntask, nreg, 2]``
     (row, col) in the current frame.  ``register_region`` takes the median flow and the mean
     squared photometric error over a window (half-width 2 below 96 rows, else 5, ``:139-141``);
-    otherwise the flow and the L2 photometric error at the single pixel (``:129-135,163-170``).
+    otherwise the flow and the L2 photometric error at the single pixel (``:129-135,163-170`` - dead code
+    in the reference, whose point mode leaves the errors zero; see ``oracle/registration.py``).
+    ``pred_height``: the predictor's image height when it differs from the images' (``:172``).
+    Pinned to the reference's own outputs by ``tests/golden/registration.npz``.
     """
     H, W = start_image.shape[1:3]
     nreg = len(register_gtruth)
@@ -65,6 +68,8 @@ def get_warp_err(icam, pix_t0, goal_pix, start_image, goal_image, start_warp_pts
             else:
                 warperrs[p, r] = np.linalg.norm(ref_img[icam][pr, pc] - warped[icam][pr, pc])
                 desig[p, r] = np.flip(warp_pts[icam][pr, pc], 0)
+    if pred_height is not None:
+        desig = desig * pred_height / H
     return warperrs, desig
 
 
