@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 4
+#define VF_ABI_VERSION 5
 
 typedef enum vf_status {
     VF_OK = 0,
@@ -128,7 +128,8 @@ int vf_set_context(vf_handle *h, const uint8_t *d_frames, const float *d_states,
  * [ncam][ndesig][2] (row, col).  d_scores_per_task may be NULL.  Predictions stay resident in
  * the handle until the next vf_rollout (see vf_export).  If a tile of the launch gave up
  * waiting for its producers (see vf_device_status) every score of this and of later rollouts
- * is NaN until the status has been read. */
+ * is NaN until the status has been read, and the predictions vf_export would copy out are
+ * undefined (the launch was abandoned): check the scores or vf_device_status first. */
 int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *goal_pix,
                float finalweight, const float *task_weights, double *d_scores,
                double *d_scores_per_task, void *stream);
@@ -171,20 +172,15 @@ int vf_register(vf_handle *h, const float *d_current, const float *d_reference, 
 int vf_allgather_scores(vf_handle *h, void *nccl_comm, const double *d_local, int32_t n_local,
                         double *d_all, void *stream);
 
-/* Sub-batch concurrency (no reference counterpart).  Samples never interact before their
- * scores are compared, so vf_rollout may cut the batch into n contiguous sub-batches that
- * advance on internal streams forked from / joined back to the caller's stream; idle CUs in
- * the tail of one sub-batch's launch are filled by the other's.  Results are bit-identical
- * for every n.  Default 1. */
-int vf_set_substreams(vf_handle *h, int32_t n);
-
 /* Persistent rollout (no reference counterpart).  When enabled vf_rollout runs ALL steps, layers
  * and samples as one persistent launch whose workgroups draw tiles from a ticket queue and
  * honour per-sample dependencies, so the tail of one layer overlaps the head of the next
  * (visual_foresight_amd/csrc/vf_persistent.h).  Results are bit-identical to the per-layer
  * launches.  A tile that waits too long for its producers (a bounded spin, ~seconds) raises a
  * STICKY device status word: from then on every score is NaN.  vf_device_status synchronises
- * the device, returns the word (0 = healthy) and re-arms it. */
+ * the device, returns the word (0 = healthy) and, if it was raised, re-arms it and drops the
+ * cached context-only part of the network (the abandoned launch may have left it half-written),
+ * so a retry recomputes it. */
 int vf_set_persistent(vf_handle *h, int32_t enable);
 int vf_device_status(vf_handle *h, int32_t *status);
 
@@ -195,29 +191,12 @@ int vf_device_status(vf_handle *h, int32_t *status);
  * are bit-identical with one queue (enable = 0), which is the plain phase order. */
 int vf_set_xcd_queues(vf_handle *h, int32_t enable);
 
-/* Role mode of the persistent rollout (no reference counterpart).  Three resident workgroups per CU instead
- * of two: the first two to arrive on a CU serve the conv-LSTM items, the third one the light phases (encoder /
- * decoder convolutions, CDNA FC, compositing), which then run under the matrix work instead of taking turns in
- * the same slots.  Needs exact fp32, tiles within a third of the LDS (the 128-row conv-LSTM tile then reads its
- * weights straight from L2) and a launch large enough to fill the chip; otherwise the plain schedule is used.
- * Placement only: results are bit-identical.  vf_debug_role_census reports whether the last launch ran in role
- * mode and the histogram of workgroups per CU it saw (hist8[k] = CUs with k arrivals). */
-int vf_set_role_mode(vf_handle *h, int32_t enable);
-int vf_debug_role_census(vf_handle *h, int32_t *active, int32_t *hist8);
-
 /* Fused decoder top of the persistent rollout (default on; no reference counterpart).  The last transposed convolution and the
  * compositing of the next frame become ONE item per tile: the tile stays in registers / LDS, its LayerNorm partial
  * is published, the item waits for the sample's other tiles and composes its pixels itself - the full-resolution
  * decoder tensor is never written to memory (visual_foresight_amd/csrc/vf_fused_top.h).  Same arithmetic on the same
  * values: results are bit-identical to the two-phase schedule and to the per-layer launches. */
 int vf_set_fuse_top(vf_handle *h, int32_t enable);
-
-/* conv-LSTM tile selection (no reference counterpart): 0 (default) = single input buffer, weights
- * staged through LDS, one barrier per tap; 2 = double-buffered LDS-DMA input staging
- * (global_load_lds_dwordx4) with the weight operand read straight from L2 and one barrier per
- * 32-channel chunk.  Same arithmetic in the same order: results are bit-identical; measured equally
- * fast, so the switch exists for A/B measurements. */
-int vf_set_lstm_tile(vf_handle *h, int32_t variant);
 
 /* Context de-duplication (default on).  While a step's inputs are context, part of the network
  * sees identical inputs for every sample (step < n_context-1: everything; step < n_context: the

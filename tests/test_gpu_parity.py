@@ -212,8 +212,8 @@ def test_errors_are_loud():
 
 
 def test_launch_strategies_are_bit_identical():
-    """Context de-duplication, sub-batch streams, the persistent single-launch rollout and the two conv-LSTM
-    tile generations only reorganise the same per-sample arithmetic: same bits out."""
+    """Context de-duplication, the persistent single-launch rollout, the XCD queues and the fused decoder top only
+    reorganise the same per-sample arithmetic: same bits out."""
     H = W = 32
     T, M = 3, 37
     pred, _ = _predictor(H, W, T, 2, bs=M)
@@ -222,12 +222,12 @@ def test_launch_strategies_are_bit_identical():
     actions = rs.normal(0, 0.1, (M, T, 4))
     goal = np.array([[[3, 20], [30, 1]]])
     outs = []
-    for dedup, nsub, persistent, tile in ((1, 1, 0, 2), (0, 1, 0, 0), (1, 2, 0, 2), (0, 3, 0, 2), (1, 1, 1, 2),
-                                          (0, 1, 1, 2), (1, 1, 1, 0), (1, 1, 0, 0)):
+    for dedup, persistent, xcd, fuse in ((1, 0, 1, 1), (0, 0, 1, 1), (1, 1, 1, 1), (0, 1, 1, 1), (1, 1, 0, 1),
+                                         (1, 1, 1, 0), (0, 1, 0, 0)):
         pred.set_dedup(dedup)
-        pred.set_substreams(nsub)
         pred.set_persistent(persistent)
-        pred.set_lstm_tile(tile)        # 2: LDS-DMA double-buffered conv-LSTM tile, 0: first-generation tile
+        pred.set_xcd_queues(xcd)
+        pred.set_fuse_top(fuse)
         s, pt = pred.score(ctx, {'actions': actions}, goal)
         assert pred.device_status() == 0
         got = pred(ctx, {'actions': actions})
@@ -265,9 +265,8 @@ def test_two_view_predictor_matches_per_view_oracle():
     want_d = np.concatenate(want_d, axis=2)
     want, want_pt = pixel_cost.eval_pixel_cost(want_d, goal, 10.)
     first = None
-    for persistent, nsub in ((1, 1), (0, 1), (0, 2)):
+    for persistent in (1, 0):
         pred.set_persistent(persistent)
-        pred.set_substreams(nsub)
         scores, per_task = pred.score(ctx, {'actions': actions}, goal)
         got = pred(ctx, {'actions': actions})
         assert got['predicted_frames'].shape == (M, T, ncam, H, W, 3)
@@ -474,38 +473,6 @@ def test_legacy_boundary_get_context_rollout_predictions():
     with pytest.raises(ValueError):
         pred.predictor_func()(input_images=frames_ctx, input_state=states_ctx, input_actions=bad[:bs],
                               input_one_hot_images=one_hot)
-
-
-def test_role_mode_is_invisible_in_the_results():
-    """Three workgroups per CU with a dedicated light-phase workgroup (vf_set_role_mode): the same bits as the plain
-    schedule, and the launch really ran that way (every CU saw three workgroups arrive)."""
-    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
-    H = W = 64
-    T, M = 4, 96
-    rs = np.random.RandomState(21)
-    ctx = _context(H, W, 2, rs)
-    actions = rs.normal(0, 0.1, (M, T, 4))
-    goal = np.array([[[12, 40], [50, 9]]])
-    pred, weights = _predictor(H, W, T, 2, bs=M)
-    base, base_pt = pred.score(ctx, {'actions': actions}, goal)
-    assert pred.role_census()[0] is False
-    hp = dict(designated_pixel_count=2, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,
-              sequence_length=T + 2, role_mode=1)
-    other = HipVPredEvaluation('', hp).restore(weights)
-    got, got_pt = other.score(ctx, {'actions': actions}, goal)
-    active, hist = other.role_census()
-    assert active, 'the launch did not qualify for the role mode'
-    assert hist[3] >= 200 and sum(hist[4:]) == 0, hist          # three arrivals on (nearly) every CU, never more
-    np.testing.assert_array_equal(got, base)
-    np.testing.assert_array_equal(got_pt, base_pt)
-    out, ref = other(ctx, {'actions': actions}), pred(ctx, {'actions': actions})
-    np.testing.assert_array_equal(out['predicted_frames'], ref['predicted_frames'])
-    np.testing.assert_array_equal(out['predicted_pixel_distributions'], ref['predicted_pixel_distributions'])
-    assert other.device_status() == 0
-    # a launch too small to fill the chip falls back to the plain schedule
-    got_small, _ = other.score(ctx, {'actions': actions[:1]}, goal)
-    np.testing.assert_array_equal(got_small, base[:1])
-    assert other.role_census()[0] is False
 
 
 def test_float16_conf_key_selects_the_reduced_precision_mode():

@@ -75,7 +75,7 @@ def test_savp_launch_strategies_and_chunking_are_bit_identical():
     pred, weights = _predictor(H, W, T, 1, bs=M)
     base, _ = pred.score(ctx, {'actions': actions}, goal)
     base_out = pred(ctx, {'actions': actions})
-    for kw in (dict(persistent=0), dict(xcd_queues=0), dict(dedup=0), dict(run_batch_size=9), dict(role_mode=1), dict(fuse_top=0)):
+    for kw in (dict(persistent=0), dict(xcd_queues=0), dict(dedup=0), dict(run_batch_size=9), dict(fuse_top=0)):
         hp = dict(kw)
         bs = hp.pop('run_batch_size', M)
         other, _ = _predictor(H, W, T, 1, bs=bs, **hp)

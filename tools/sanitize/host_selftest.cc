@@ -16,7 +16,6 @@
 
 #include "../../include/vf_hip.h"
 
-extern "C" int vf_set_role_mode(vf_handle *h, int32_t enable);
 extern "C" int vf_set_fuse_top(vf_handle *h, int32_t enable);
 extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared, int64_t *out_items,
                                     uint64_t *out_upload_checksum);
@@ -38,9 +37,8 @@ static int run_case(int H, int W, int adim, int sdim, int nd, int nctx, int T, i
     }
     if (vf_load_weights(h, blob.data(), blob.size() - 1) == 0) { std::fprintf(stderr, "short blob accepted\n"); return 1; }
     uint64_t sum = 0;
-    for (int role = 0; role < 2; ++role) {
-      vf_set_role_mode(h, role);       // role mode: used where the launch qualifies, the plain schedule elsewhere
-      vf_set_fuse_top(h, !role);       // fused decoder top with the plain schedule
+    for (int fuse = 1; fuse >= 0; --fuse) {
+      vf_set_fuse_top(h, fuse);        // fused decoder top, then the two-phase top
       for (int i = 0; i < n_batches; ++i)
         for (int skip = 0; skip < 2; ++skip) {
             int64_t items = 0;
@@ -49,7 +47,7 @@ static int run_case(int H, int W, int adim, int sdim, int nd, int nctx, int T, i
                 return 1;
             }
             std::printf("  %dx%d adim %d nd %d ncam %d prec %d  B=%-4d %s%s: %lld items\n", H, W, adim, nd, ncam,
-                        precision, batches[i], skip ? "cached-context" : "full", role ? " (role mode asked)" : "",
+                        precision, batches[i], skip ? "cached-context" : "full", fuse ? "" : " (unfused top)",
                         (long long)items);
         }
     }

@@ -22,9 +22,9 @@ SOURCES = [os.path.join(_HERE, 'csrc', f) for f in
 EXPORTS = ('vf_abi_version', 'vf_last_error', 'vf_weight_count', 'vf_create', 'vf_destroy',
            'vf_load_weights', 'vf_set_context', 'vf_rollout', 'vf_export', 'vf_register',
            'vf_allgather_scores', 'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile',
-           'vf_set_substreams', 'vf_set_dedup', 'vf_set_persistent', 'vf_set_xcd_queues', 'vf_set_role_mode', 'vf_set_fuse_top', 'vf_debug_role_census', 'vf_set_lstm_tile', 'vf_device_status',
+           'vf_set_dedup', 'vf_set_persistent', 'vf_set_xcd_queues', 'vf_set_fuse_top', 'vf_device_status',
            'vf_set_phase_stats', 'vf_debug_phase_stats', 'vf_debug_poison_status')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class VfError(RuntimeError):
@@ -104,23 +104,16 @@ def load_library():
     lib.vf_set_profiling.argtypes = [P, ctypes.c_int32]
     lib.vf_get_profile.argtypes = [P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                    ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-    lib.vf_set_substreams.argtypes = [P, ctypes.c_int32]
     lib.vf_set_dedup.argtypes = [P, ctypes.c_int32]
     lib.vf_set_dedup.restype = ctypes.c_int
     lib.vf_set_persistent.argtypes = [P, ctypes.c_int32]
-    lib.vf_set_lstm_tile.argtypes = [P, ctypes.c_int32]
     lib.vf_set_xcd_queues.argtypes = [P, ctypes.c_int32]
-    lib.vf_set_role_mode.argtypes = [P, ctypes.c_int32]
     lib.vf_set_fuse_top.argtypes = [P, ctypes.c_int32]
     lib.vf_set_fuse_top.restype = ctypes.c_int
-    lib.vf_set_role_mode.restype = ctypes.c_int
-    lib.vf_debug_role_census.argtypes = [P, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
-    lib.vf_debug_role_census.restype = ctypes.c_int
     lib.vf_set_xcd_queues.restype = ctypes.c_int
-    lib.vf_set_lstm_tile.restype = ctypes.c_int
     lib.vf_device_status.argtypes = [P, ctypes.POINTER(ctypes.c_int32)]
     lib.vf_set_persistent.restype = lib.vf_device_status.restype = ctypes.c_int
-    lib.vf_set_profiling.restype = lib.vf_get_profile.restype = lib.vf_set_substreams.restype = ctypes.c_int
+    lib.vf_set_profiling.restype = lib.vf_get_profile.restype = ctypes.c_int
     for name in ('vf_create', 'vf_destroy', 'vf_load_weights', 'vf_set_context', 'vf_rollout',
                  'vf_export', 'vf_register', 'vf_allgather_scores', 'vf_set_phase_stats',
                  'vf_debug_phase_stats', 'vf_debug_poison_status'):

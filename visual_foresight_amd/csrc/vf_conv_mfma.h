@@ -34,12 +34,6 @@
 #define VF_LAUNCH_BOUNDS(...) __launch_bounds__(__VA_ARGS__)
 #endif
 
-// VF_LSTM_B_DIRECT=1 (experiment): conv-LSTM tiles read the weight operand straight from L1/L2 instead of
-// staging it through LDS - frees 32 KiB of LDS per workgroup (3 resident workgroups per CU)
-#ifndef VF_LSTM_B_DIRECT
-#define VF_LSTM_B_DIRECT 0
-#endif
-
 namespace vf {
 
 #ifdef VF_TILE_STATS
@@ -113,8 +107,7 @@ struct ConvParams {
     int stats_nparts;
     int chunks_per_split;   // K split (blockIdx.z)
     int n_valid;            // EPI_PARTIAL: valid output columns
-    const float *zeros;     // >= 16 bytes of zeros (LDS-DMA source of out-of-image / out-of-batch positions)
-    int tile_variant;       // EPI_LSTM: 0 = conv_tile (B through LDS), 1 = split-bf16, 2 = conv_lstm_dma_tile
+    int tile_variant;       // EPI_LSTM: 0 = conv_tile (fp32), 1 = split-bf16 (vf_conv_bf16x6.h)
     // EPI_CONVT_FUSED only (vf_fused_top.h): the compositing parameters of the same step (device address inside the
     // schedule), the per-sample "LayerNorm partials published" counters, the launch's failure word, view, pixels
     const void *fuse_comp;
@@ -404,18 +397,15 @@ __device__ __forceinline__ void lstm_split_epilogue(const PT &p, f32x16 (&acc)[1
 // RB < 4 (conv-LSTM, B through LDS only): the workgroup covers RB row blocks of 32 - 64 or 32 rows instead of
 // 128 - and wave w takes row block w % RB and RB of the four gates, for batches so small that the per-sample
 // dependency chain, not the throughput, bounds a rollout; same chunking and K order, i.e. the same bits.
-// BD (conv-LSTM, 128 rows): read the weight operand straight from L1/L2 instead of staging it through LDS - the
-// same K order, hence the same bits, measured equally fast, and 32 KiB less LDS per workgroup: the tile of the
-// three-workgroups-per-CU role mode of the persistent launch (vf_persistent.h).
 // epilogue of EPI_CONVT_FUSED, defined in vf_fused_top.h (it needs the compositing code)
 template <int ND, bool FIRST, class PT>
 __device__ __forceinline__ void convt_fused_epilogue(const PT &p, f32x16 (&acc)[1][4], int bx, long long *red, float *smem);
 
-template <int G, int EPI, int MREP, class PT, int RB = 4, bool BD = false>
+template <int G, int EPI, int MREP, class PT, int RB = 4>
 __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int by, const int bz,
                                           float *smem) {
     constexpr bool SPLIT = RB < 4;
-    static_assert(!SPLIT || (G == 4 && EPI == EPI_LSTM && MREP == 1 && !VF_LSTM_B_DIRECT && (RB == 1 || RB == 2)),
+    static_assert(!SPLIT || (G == 4 && EPI == EPI_LSTM && MREP == 1 && (RB == 1 || RB == 2)),
                   "the row-split tiles are conv-LSTM tiles");
     constexpr int WROWS = MREP * 32;    // GEMM rows per wave
     constexpr int GA = SPLIT ? RB : G;  // gates (accumulator tiles) per wave
@@ -423,8 +413,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     // lose more to its per-tap barrier than they gain, so they read B straight from L1/L2
     // (the 256-row conv-LSTM tile reads B directly as well: its input tile needs the LDS, and it must keep the
     // 32-channel chunks of the 128-row tile so that both plans accumulate every output in the same K order)
-    constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1 && !VF_LSTM_B_DIRECT && !BD;
-    static_assert(!BD || (EPI == EPI_LSTM && MREP == 1 && !SPLIT), "BD is a variant of the 128-row conv-LSTM tile");
+    constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     const int wrow0 = SPLIT ? (wave % RB) * 32 : wave * WROWS;     // first GEMM row of this wave
@@ -707,254 +696,6 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #endif
 }
 
-// ------------------------------------------------------------------------------------------
-// conv-LSTM tile, second generation ("DMA tile"): same GEMM decomposition and the same
-// chunk -> tap -> k8 -> j accumulation order as conv_tile<4, EPI_LSTM> (bit-identical results), but
-//   * the weight operand is read straight from L1/L2 (one 16-B load per lane per gate, software
-//     pipelined one step ahead) - measured as fast as staging it through LDS, and it frees 32 KiB;
-//   * the input tile is DOUBLE-buffered in LDS: while the matrix pipe works through chunk c, the
-//     tile of chunk c+1 lands in the other buffer via LDS-DMA (global_load_lds_dwordx4: no VGPRs,
-//     no VALU, one instruction per KiB), one instruction per tap;
-//   * one workgroup barrier per CHUNK (25 taps) instead of one per tap.
-// Only chunks whose producer needs LayerNorm (+relu) applied on the way in - the first chunk(s)
-// of a layer - take the synchronous VALU staging path.
-// LDS layout of one buffer: [pixel][32 floats] without padding; the 16-B slot s of pixel p holds
-// channel quad s ^ ((p >> 1) & 7), so 16 consecutive pixels at a fixed quad hit 16 distinct slots of
-// the 64 banks (ds_read_b128 serves 16 lanes per cycle) and a DMA instruction (64 lanes x 16 B,
-// contiguous KiB) fills 8 whole pixels.  Positions outside the image / batch are DMA'd from a
-// 16-byte zero page, so no lane is ever masked.  Requires KC == 32, stride 1, <= 288 halo pixels.
-template <int MREP, class PT>
-__device__ __forceinline__ void conv_lstm_dma_tile(const PT &p, const int bx, const int by, float *smem) {
-    constexpr int G = 4, KC = 32, K8 = 4, Q4 = 8;
-    constexpr int WROWS = MREP * 32;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 31, kh = lane >> 5;
-    const int LH = p.TH - 1 + p.KH, LW = p.TW - 1 + p.KW;
-    const int tile_px = LH * LW;
-    const int total_px = p.NI * tile_px;
-    const int n_dma = (total_px + 7) >> 3;                  // DMA instructions per chunk (8 pixels each)
-    const int buf_floats = n_dma * 8 * KC;                  // whole KiB blocks
-    float *lnTab = smem + 2 * buf_floats;                   // [2][NI][2]: mean, rstd
-    long long *red = reinterpret_cast<long long *>(lnTab + 4 * p.NI + (p.NI & 1) * 2);
-    const int cg = by;
-    const int tiles_per_img = p.tilesY * p.tilesX;
-
-    int bimg0, ty0, tx0;
-    if (p.NI == 1) {
-        bimg0 = bx / tiles_per_img;
-        const int tile_id = bx % tiles_per_img;
-        ty0 = (tile_id / p.tilesX) * p.TH;
-        tx0 = (tile_id % p.tilesX) * p.TW;
-    } else {
-        bimg0 = bx * p.NI;
-        ty0 = 0; tx0 = 0;
-    }
-
-    // ---- LayerNorm statistics of the producing layers (this workgroup's samples only)
-    ln_table(p, bimg0, lnTab);
-
-    // ---- this lane's A rows: halo-tile pixel index of GEMM row wave*WROWS + m*32 + n at tap (0, 0)
-    const int px_per_img = p.TH * p.TW;
-    int apix[MREP];
-#pragma unroll
-    for (int m = 0; m < MREP; ++m) {
-        const int row = wave * WROWS + m * 32 + n;
-        const int img = row / p.RPI, rem = row % p.RPI;
-        const bool ok = img < p.NI && rem < px_per_img;
-        const int y = rem / p.TW, x = rem % p.TW;
-        apix[m] = ok ? img * tile_px + y * LW + x : 0;
-    }
-
-    f32x16 acc[MREP][G];
-#pragma unroll
-    for (int m = 0; m < MREP; ++m)
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][g][r] = 0.f;
-
-    const int ntaps = p.KH * p.KW;
-    const int Ntot = p.ncg * G * 32;
-    const int total_chunks = p.seg[0].nchunk + (p.nseg > 1 ? p.seg[1].nchunk : 0);
-    const float *wlane = p.Wp + ((long long)kh * Ntot + (cg * G) * 32 + n) * 4;
-    const long long wstep = (long long)2 * Ntot * 4;        // floats per (chunk, tap, k8) block
-
-    // geometry of halo pixel `pix` (index into the staged tile): sample, in-bounds flag, pixel offset
-    auto locate = [&](const int pix, int &b, long long &gpix) -> bool {
-        const int img = pix / tile_px, r = pix - img * tile_px;
-        const int ly = r / LW, lx = r - ly * LW;
-        const int iy = ty0 - p.pad + ly, ix = tx0 - p.pad + lx;
-        b = bimg0 + img;
-        gpix = (long long)iy * p.Win + ix;
-        return pix < total_px && b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-    };
-    auto seg_of = [&](const int ci, int &c0) -> int {
-        const int s = (ci < p.seg[0].nchunk) ? 0 : 1;
-        c0 = (s == 0 ? ci : ci - p.seg[0].nchunk) * KC;
-        return s;
-    };
-    // may chunk ci be brought in by DMA?  (plain copy: no LayerNorm, no relu, whole 16-B quads)
-    auto dma_ok = [&](const int ci) -> bool {
-        int c0;
-        const auto &sg = p.seg[seg_of(ci, c0)];
-        return !sg.ln_part && !sg.relu && (sg.C & 3) == 0 && c0 + KC <= sg.C;
-    };
-
-    // ---- synchronous staging (VALU path: LayerNorm / relu / ragged channel counts)
-    auto stage_sync = [&](const int ci, float *buf) {
-        int c0;
-        const int s = seg_of(ci, c0);
-        const auto &sg = p.seg[s];
-        const bool vec_ok = (sg.C & 3) == 0;
-        for (int it = tid; it < n_dma * 64; it += kConvThreads) {
-            const int pix = it >> 3, slot = it & 7;
-            const int q = slot ^ ((pix >> 1) & 7);
-            const int c = c0 + 4 * q;
-            int b; long long gpix;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (locate(pix, b, gpix) && c < sg.C) {
-                const float *src = sg.ptr + (long long)b * sg.bstride + gpix * sg.C + c;
-                const int nvalid = min(4, sg.C - c);
-                if (vec_ok) {
-                    v = *reinterpret_cast<const f32x4 *>(src);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (j < nvalid) ? src[j] : 0.f;
-                }
-                if (sg.ln_part) {
-                    const int img = pix / tile_px;
-                    const float mean = lnTab[2 * (s * p.NI + img)];
-                    const float rstd = lnTab[2 * (s * p.NI + img) + 1];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int cc = (c + j) % sg.gamma_mod;
-                        v[j] = fmaf((v[j] - mean) * rstd, sg.gamma[cc], sg.beta[cc]);
-                    }
-                }
-                if (sg.relu) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (j < nvalid) ? v[j] : 0.f;
-            }
-            *reinterpret_cast<f32x4 *>(&buf[pix * KC + 4 * slot]) = v;
-        }
-    };
-
-    // ---- LDS-DMA descriptors of this wave's blocks (blocks wave, wave + 4, ...; 8 pixels = 1 KiB each): the
-    // halo geometry does not change from chunk to chunk, so the per-lane source pixel is computed once per item
-    constexpr int kMaxBlk = 9;              // 36 blocks = 288 halo pixels per workgroup at most
-    int srcpix[kMaxBlk];                    // (sample slot << 24) | pixel offset in the image, or -1: zero page
-    const int my_slot = lane & 7;
-#pragma unroll
-    for (int j = 0; j < kMaxBlk; ++j) {
-        const int pix = (wave + 4 * j) * 8 + (lane >> 3);
-        int b; long long gpix;
-        const bool ok = (wave + 4 * j) < n_dma && locate(pix, b, gpix);
-        srcpix[j] = ok ? (((b - bimg0) << 24) | (int)gpix) : -1;
-    }
-    auto dma_chunk = [&](const int ci, float *buf) {
-        int c0;
-        const auto &sg = p.seg[seg_of(ci, c0)];
-        const float *base = sg.ptr + (long long)bimg0 * sg.bstride + c0;
-#pragma unroll
-        for (int j = 0; j < kMaxBlk; ++j) {
-            const int blk = wave + 4 * j;
-            if (blk < n_dma) {              // wave-uniform
-                const int pix = blk * 8 + (lane >> 3);
-                const int q = my_slot ^ ((pix >> 1) & 7);
-                const float *src = srcpix[j] < 0 ? p.zeros
-                    : base + (long long)(srcpix[j] >> 24) * sg.bstride + (long long)(srcpix[j] & 0xffffff) * sg.C + 4 * q;
-                // Issued as inline asm on purpose: for the builtin the compiler assumes that every later LDS
-                // read may alias the DMA's destination and drains vmcnt to 0 in front of each ds_read, which
-                // also drains the in-flight weight loads.  The other buffer is what the K loop reads; the
-                // landing is awaited explicitly (vmcnt(0) + barrier) at the end of the chunk.
-                const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
-                    (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)(buf + blk * (8 * KC)));
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                             :: "s"(lds_addr), "v"(src) : "memory");
-            }
-        }
-    };
-
-    __syncthreads();                        // lnTab visible
-    stage_sync(0, smem);
-    __syncthreads();
-
-    const f32x4 *smem4 = reinterpret_cast<const f32x4 *>(smem);
-    for (int ci = 0; ci < total_chunks; ++ci) {
-        const int cur = ci & 1;
-        const f32x4 *a4 = smem4 + cur * (buf_floats >> 2);
-        float *nxt = smem + (cur ^ 1) * buf_floats;
-        const bool have_next = ci + 1 < total_chunks;
-        const bool next_dma = have_next && dma_ok(ci + 1);
-        const float *wchunk = wlane + (long long)ci * ntaps * K8 * wstep;
-
-        f32x4 aP[MREP], aQ[MREP], bP[G], bQ[G];
-#define VF_MFMA(A_, B_)                                                                         \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
-            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                     \
-                _Pragma("unroll") for (int m = 0; m < MREP; ++m)                                \
-                    acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m][j], B_[g][j], acc[m][g], 0, 0, 0); \
-            }                                                                                   \
-        }
-        // operands of (tap, k8): A = quad 2*k8 + kh of the lane's pixel at that tap, B = 4 gate blocks
-#define VF_FETCH_D(A_, B_, TAPOFF_, K8_, WIDX_)                                                 \
-        {                                                                                       \
-            _Pragma("unroll") for (int m = 0; m < MREP; ++m) {                                  \
-                const int pl_ = apix[m] + (TAPOFF_);                                            \
-                A_[m] = a4[pl_ * Q4 + (((K8_) * 2 + kh) ^ ((pl_ >> 1) & 7))];                   \
-            }                                                                                   \
-            const float *wp_ = wchunk + (long long)(WIDX_) * wstep;                             \
-            _Pragma("unroll") for (int g = 0; g < G; ++g)                                       \
-                B_[g] = *reinterpret_cast<const f32x4 *>(wp_ + g * 128);                        \
-        }
-        VF_FETCH_D(aP, bP, 0, 0, 0)
-        // the whole next chunk is requested now, behind the first operand fetch: VMEM returns in order, so
-        // its landing delays one later fetch once per chunk instead of one per block
-        if (next_dma) dma_chunk(ci + 1, nxt);
-        int tapoff = 0, kx = 0;
-        for (int tap = 0; tap < ntaps; ++tap) {
-            // tap offset of the NEXT tap (row-major over the 5x5 window)
-            int tapoff_n = tapoff + 1, kx_n = kx + 1;
-            if (kx_n == p.KW) { kx_n = 0; tapoff_n = tapoff + 1 + LW - p.KW; }
-            const int w0 = tap * K8;
-            // sched_barrier: the machine scheduler otherwise sinks each operand fetch next to its first use,
-            // which exposes the full L2 latency of the weight loads on every 16-MFMA step
-            VF_FETCH_D(aQ, bQ, tapoff, 1, w0 + 1)
-            __builtin_amdgcn_sched_barrier(0);
-            VF_MFMA(aP, bP)
-            __builtin_amdgcn_sched_barrier(0);
-            VF_FETCH_D(aP, bP, tapoff, 2, w0 + 2)
-            __builtin_amdgcn_sched_barrier(0);
-            VF_MFMA(aQ, bQ)
-            __builtin_amdgcn_sched_barrier(0);
-            VF_FETCH_D(aQ, bQ, tapoff, 3, w0 + 3)
-            __builtin_amdgcn_sched_barrier(0);
-            VF_MFMA(aP, bP)
-            __builtin_amdgcn_sched_barrier(0);
-            if (tap + 1 < ntaps) VF_FETCH_D(aP, bP, tapoff_n, 0, w0 + 4)
-            __builtin_amdgcn_sched_barrier(0);
-            VF_MFMA(aQ, bQ)
-            __builtin_amdgcn_sched_barrier(0);
-            tapoff = tapoff_n; kx = kx_n;
-        }
-#undef VF_FETCH_D
-#undef VF_MFMA
-        if (have_next) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA blocks have landed
-            __syncthreads();                                    // everybody's have, and chunk ci is consumed
-            if (!next_dma) {
-                stage_sync(ci + 1, nxt);
-                __syncthreads();
-            }
-        }
-    }
-    conv_epilogue<G, EPI_LSTM, MREP>(p, acc, bx, by, 0, red);
-}
-
 template <int G, int EPI, int MREP>
 VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_mfma_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -965,18 +706,6 @@ template <int RB>
 VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_lstm_split_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     conv_tile<4, EPI_LSTM, 1, ConvParams, RB>(p, blockIdx.x, blockIdx.y, 0, smem);
-}
-
-template <int MREP>
-VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_lstm_dma_kernel(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    conv_lstm_dma_tile<MREP>(p, blockIdx.x, blockIdx.y, smem);
-}
-
-// LDS bytes of the DMA tile for a layer geometry
-__host__ __device__ inline size_t lstm_dma_lds_bytes(int NI, int LH, int LW) {
-    const size_t blocks = ((size_t)NI * LH * LW + 7) / 8;
-    return (2 * blocks * 8 * 32 + 4 * (size_t)NI + 2) * 4 + 64;
 }
 
 }  // namespace vf

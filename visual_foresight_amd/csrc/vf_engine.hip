@@ -57,15 +57,9 @@ static int fail(int code, const std::string &msg) {
 static const int kLstmSizes[7] = {32, 32, 64, 64, 128, 64, 32};
 static const int kEnc00Ch = 16;             // channels of the extra encoder scale of arch 1 (savp_arch.py)
 static const int kNumLn = 11;               // ln1..ln9, lna, lnb
-static const int kMaxSubBatches = 8;
 static const int kSchedRing = 4;            // pinned staging buffers for schedule uploads
-// ints in front of the completion counters: the ticket heads and the per-CU arrival counters of the role mode
-static const int kSyncHead = kRoles * kQueues * kTicketStride + kCuSlots;
-// Role mode: three resident workgroups per CU must share its 160 KiB of LDS (512-byte granules): what one
-// workgroup's tile workspace may use next to the control block
-// (48 KiB per workgroup: with the full third - 53 KiB - the occupancy query still answers 3, but the third
-// workgroup of most CUs is not placed until another one exits)
-static const size_t kRoleLdsLimit = 48 * 1024 - kCtlWords * sizeof(int) - 16;
+// ints in front of the completion counters: the ticket heads
+static const int kSyncHead = kQueues * kTicketStride;
 
 // ------------------------------------------------------------------ canonical tensor table
 struct TensorDesc {
@@ -156,8 +150,6 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
     int mrep;                       // MFMA row blocks per wave: the workgroup covers 128 * mrep rows;
                                     // 0 / -1 = the 64- / 32-row conv-LSTM tiles (waves split rows x gates)
     int prec = 0;                   // 1: split-bf16 tile (conv-LSTM only)
-    size_t lds_dma = 0;             // conv-LSTM, fp32: LDS bytes of the DMA tile (0: tile not applicable)
-    size_t lds_bd = 0;              // conv-LSTM, fp32, 128 rows: LDS bytes with the weights read from L2 (0: n/a)
     int NI, TH, TW, RPI, tilesY, tilesX;
     int ni_cap = 0;                 // > 0: at most this many whole images per workgroup (plans for narrow phases)
     int ncg, Cout;
@@ -187,7 +179,7 @@ static size_t conv_lds_bytes(const ConvLayer &l, int KC) {
     const int LH = (l.TH - 1) * l.stride + l.KH, LW = (l.TW - 1) * l.stride + l.KW;
     // A tile + LayerNorm table + reduction scratch (+ for 4-gate layers the double-buffered
     // per-tap B blocks: 2 x KC/8 x [4 gates][64 lanes] float4)
-    const size_t b_lds = (l.mode == PACK_LSTM && l.mrep <= 1 && !VF_LSTM_B_DIRECT) ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
+    const size_t b_lds = (l.mode == PACK_LSTM && l.mrep <= 1) ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
     return ((size_t)l.NI * LH * LW * (KC + 4) + 4 * (size_t)l.NI) * 4 + 64 + b_lds;
 }
 
@@ -228,14 +220,6 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
         l.lds_bytes = bf16x6_lds_bytes(l.NI, LH, LW);
     }
     l.stats_nparts = (l.NI == 1 ? l.tilesY * l.tilesX : 1) * l.ncg;
-    // second-generation conv-LSTM tile (vf_conv_mfma.h, conv_lstm_dma_tile): same packing, needs 32-channel chunks
-    l.lds_dma = 0;
-    l.lds_bd = (l.mode == PACK_LSTM && l.prec == 0 && l.mrep == 1) ? l.lds_bytes - (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
-    if (l.mode == PACK_LSTM && l.prec == 0 && KC == 32 && l.mrep == 1 && l.stride == 1) {   // (128-row plan only)
-        const int LH = l.TH - 1 + l.KH, LW = l.TW - 1 + l.KW;
-        const size_t need = lstm_dma_lds_bytes(l.NI, LH, LW);
-        if (need <= 79 * 1024 && l.NI * LH * LW <= 288) l.lds_dma = need;
-    }
 }
 
 // canonical [KH][KW][Cin][Ctot] -> packed [chunk][tap][k8][khalf][Ntot][4]
@@ -346,9 +330,8 @@ static std::vector<float> pack_bias(const ConvLayer &l, const float *b) {
 
 using namespace vf;
 
-// Views of the engine's working buffers: one per (camera view, sub-batch) - offset to its first
-// sample - and one "shared" set of batch-1 buffers per (view, sub-batch) for tensors that are
-// identical for every sample (see emit_rollout).
+// Views of the engine's working buffers: one per camera view and one "shared" set of batch-1
+// buffers per view for tensors that are identical for every sample (see emit_rollout).
 struct BatchView {
     float *enc0_o, *enc1_o, *enc2_o, *enc3_o, *enc4_o, *enc5_o, *enc6_o;
     float *enc00_o, *enc7_o;            // arch 1: extra encoder / decoder scale
@@ -429,7 +412,7 @@ struct vf_handle {
 
     std::vector<AllocRec> allocs;
 
-    // batch-1 buffers for tensors shared by all samples (context de-duplication): [view][sub-batch]
+    // batch-1 buffers for tensors shared by all samples (context de-duplication): [view]
     bool dedup = true;
     std::vector<BatchView> shared_views;
 
@@ -440,9 +423,9 @@ struct vf_handle {
     struct SchedCache {                 // device copy of one schedule + the key it was built for
         PhaseDesc *d_phases = nullptr;
         int B = -1, items = 0, counters = 0, phases = 0;
-        bool dedup = true, lstm_dma = false;
-        int xcd_queues = 0, nq = 1, total_q[kRoles][kQueues] = {{0}};
-        bool role_mode = false, roles2 = false, fuse_top = false;
+        bool dedup = true;
+        int xcd_queues = 0, nq = 1, total_q[kQueues] = {0};
+        bool fuse_top = false;
         double flops = 0.0;
         size_t lds = 0;
         std::vector<int> types, nitems;
@@ -455,26 +438,16 @@ struct vf_handle {
     int stage_next = 0;
     int *d_sync = nullptr;              // [kQueues ticket heads, one cache line each | counters...]
     int xcd_queues = kQueues;           // ticket queues of the persistent launch (vf_set_xcd_queues): kQueues or 1
-    // role mode (vf_set_role_mode, vf_persistent.h): three workgroups per CU, the third one serving the light phases
-    bool role_mode = false, role_ok = false, role_active = false;
     bool fuse_top = true;               // vf_set_fuse_top: top transposed conv + compositing as one item (vf_fused_top.h)
     int *d_status = nullptr;            // sticky failure word of the persistent kernel
     unsigned long long *d_stats = nullptr;  // per-phase wait/run ticks (vf_set_phase_stats)
     bool phase_stats = false;
     int persist_wgs_per_cu = 2;
     size_t max_lds = 0;                 // largest dynamic LDS any tile of this engine needs
-    float *d_zeros = nullptr;           // 256 bytes of zeros (LDS-DMA source for padding positions)
-    bool lstm_dma = false;              // conv-LSTM layers use the DMA tile where it applies (vf_set_lstm_tile)
 
     // cross-rollout cache of the shared (batch-1, context-only) units
     bool cache_shared = true, shared_valid = false;
     int shared_cfg = -1;
-
-    // sub-batch streams (forked from / joined to the caller's stream inside vf_rollout)
-    int n_sub = 1;
-    std::vector<hipStream_t> sub_streams;
-    std::vector<hipEvent_t> ev_join;
-    hipEvent_t ev_fork = nullptr;
 
     // optional per-launch timing of the dominant kernel (HIP events on the launch stream)
     bool profiling = false;
@@ -589,18 +562,13 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_CONVT_RAW_STATS, 1>, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_PARTIAL, 2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_bf16x6_kernel<1>, n))) return rc;
-    if ((rc = allow_lds(&conv_lstm_dma_kernel<1>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_split_kernel<2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_split_kernel<1>, n))) return rc;
     const size_t np = n + kCtlWords * sizeof(int);
-    if ((rc = allow_lds(&rollout_persistent_kernel<1, 2>, np))) return rc;
-    if ((rc = allow_lds(&rollout_persistent_kernel<2, 2>, np))) return rc;
-    if ((rc = allow_lds(&rollout_persistent_kernel<3, 2>, np))) return rc;
-    if ((rc = allow_lds(&rollout_persistent_kernel<4, 2>, np))) return rc;
-    if ((rc = allow_lds(&rollout_persistent_kernel<1, 3>, np))) return rc;
-    if ((rc = allow_lds(&rollout_persistent_kernel<2, 3>, np))) return rc;
-    if ((rc = allow_lds(&rollout_persistent_kernel<3, 3>, np))) return rc;
-    if ((rc = allow_lds(&rollout_persistent_kernel<4, 3>, np))) return rc;
+    if ((rc = allow_lds(&rollout_persistent_kernel<1>, np))) return rc;
+    if ((rc = allow_lds(&rollout_persistent_kernel<2>, np))) return rc;
+    if ((rc = allow_lds(&rollout_persistent_kernel<3>, np))) return rc;
+    if ((rc = allow_lds(&rollout_persistent_kernel<4>, np))) return rc;
     return VF_OK;
 }
 
@@ -623,13 +591,6 @@ static int launch_lstm_split(const ConvLayer &l, const ConvParams &p, hipStream_
     return VF_OK;
 }
 
-static int launch_lstm_dma(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
-    const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
-    hipLaunchKernelGGL((conv_lstm_dma_kernel<1>), dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_dma, st, p);
-    VF_HIP_CHECK(hipGetLastError());
-    return VF_OK;
-}
-
 template <int MREP>
 static int launch_lstm_bf16x6(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
@@ -645,7 +606,6 @@ static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st
     if constexpr (EPI == EPI_LSTM) {
         if (l.prec == 1) return launch_lstm_bf16x6<1>(l, p, st);        // 128-row tiles only
         if (l.mrep <= 0) return launch_lstm_split(l, p, st);
-        if (p.tile_variant == 2) return launch_lstm_dma(l, p, st);
         return l.mrep == 1 ? launch_conv_m<G, EPI, 1>(l, p, st) : launch_conv_m<G, EPI, 2>(l, p, st);
     } else if constexpr (EPI == EPI_PARTIAL) {
         return launch_conv_m<G, EPI, 2>(l, p, st);
@@ -661,8 +621,7 @@ struct SegArg {
     const float *gamma, *beta; int gamma_mod; int relu;
 };
 
-static ConvParams make_params(const ConvLayer &l, const LayerW &w, int B, const SegArg &s0, const SegArg *s1,
-                              const float *zeros = nullptr, bool lstm_dma = false, bool b_direct = false) {
+static ConvParams make_params(const ConvLayer &l, const LayerW &w, int B, const SegArg &s0, const SegArg *s1) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
     const SegArg *sa[2] = {&s0, s1};
@@ -683,8 +642,7 @@ static ConvParams make_params(const ConvLayer &l, const LayerW &w, int B, const 
     p.ncg = l.ncg; p.Cout = l.Cout; p.Wp = w.w; p.Wp16 = w.w16; p.bias = w.b;
     p.chunks_per_split = l.chunks_per_split; p.n_valid = l.n_valid;
     p.stats_nparts = l.stats_nparts;    // row stride of p.stats; the conv-LSTM plans overwrite it with st_rows[k]
-    p.zeros = zeros;
-    p.tile_variant = l.prec == 1 ? 1 : (b_direct && l.lds_bd ? 3 : (lstm_dma && l.lds_dma ? 2 : 0));
+    p.tile_variant = l.prec == 1 ? 1 : 0;
     return p;
 }
 
@@ -816,17 +774,17 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         if (h->big_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_big[k].stats_nparts);
         init_layer(h->lstm_half[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[0],
                    sm.segC[1], sm.Cout, true, false, 0, 0);
-        h->half_ok[k] = h->lstm_half[k].KC == sm.KC && sm.KC == 32 && !VF_LSTM_B_DIRECT;
+        h->half_ok[k] = h->lstm_half[k].KC == sm.KC && sm.KC == 32;
         if (h->half_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_half[k].stats_nparts);
         init_layer(h->lstm_quarter[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2,
                    sm.segC[0], sm.segC[1], sm.Cout, true, false, -1, 0);
-        h->quarter_ok[k] = h->lstm_quarter[k].KC == sm.KC && sm.KC == 32 && !VF_LSTM_B_DIRECT;
+        h->quarter_ok[k] = h->lstm_quarter[k].KC == sm.KC && sm.KC == 32;
         if (h->quarter_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_quarter[k].stats_nparts);
     }
     h->max_lds = (size_t)composite_lds_floats<kMaxDesig, 10>() * 4;
     for (size_t i = 0; i < h->layers.size(); ++i) {
         h->layers[i]->id = (int)i;
-        h->max_lds = std::max(h->max_lds, std::max(h->layers[i]->lds_bytes, h->layers[i]->lds_dma));
+        h->max_lds = std::max(h->max_lds, h->layers[i]->lds_bytes);
     }
     h->enc2_one.id = h->enc2.id; h->enc3_one.id = h->enc3.id; h->convt1_one.id = h->convt1.id;   // shared packed weights
     for (int k = 0; k < 7; ++k)
@@ -842,13 +800,6 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
             h->max_lds = std::max(h->max_lds, fused_top_lds_floats(top.TH, top.TW, h->ND) * 4);
     }
     h->max_lds += 16;
-    // role mode (three workgroups per CU): exact fp32 only (the split-bf16 tile needs more LDS), every light layer and
-    // the weights-from-L2 conv-LSTM tile within a third of the LDS; the occupancy of the 168-VGPR kernel is checked below
-    h->role_ok = cfg->precision == 0;
-    for (const ConvLayer *l : h->layers) {
-        if (l->mode == PACK_LSTM) h->role_ok = h->role_ok && l->lds_bd > 0 && l->lds_bd <= kRoleLdsLimit;
-        else h->role_ok = h->role_ok && l->lds_bytes <= kRoleLdsLimit;
-    }
 
 #define VF_ALLOC(ptr, n)                           \
     do {                                           \
@@ -925,9 +876,8 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     VF_ALLOC(h->sched[1].d_phases, h->sched_capacity);
     VF_ALLOC(h->d_sync, kSyncHead + h->counter_capacity);
     VF_ALLOC(h->d_status, 1);
-    VF_ALLOC(h->d_zeros, 64);
     VF_ALLOC(h->d_stats, h->sched_capacity * 2);
-    for (int i = 0; i < NV * kMaxSubBatches; ++i) {
+    for (int i = 0; i < NV; ++i) {
         BatchView sv;
         memset(&sv, 0, sizeof(sv));
         VF_ALLOC(sv.enc0_o, (size_t)H2 * W2 * 32);
@@ -953,8 +903,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     }
 #undef VF_ALLOC
 #ifndef VF_HOST_SELFTEST
-    if (hipMemset(h->d_sync, 0, kSyncHead * sizeof(int)) != hipSuccess || hipMemset(h->d_status, 0, sizeof(int)) != hipSuccess ||
-        hipMemset(h->d_zeros, 0, 64 * sizeof(float)) != hipSuccess) {
+    if (hipMemset(h->d_sync, 0, kSyncHead * sizeof(int)) != hipSuccess || hipMemset(h->d_status, 0, sizeof(int)) != hipSuccess) {
         vf_destroy(h);
         return fail(VF_ERR_HIP, "hipMemset of the scheduler words failed");
     }
@@ -973,18 +922,6 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
             h->n_cu = prop.multiProcessorCount;
     }
     if ((rc = configure_kernels(h))) { vf_destroy(h); return rc; }
-    if (h->role_ok) {       // do three workgroups of the 168-VGPR kernel really fit one CU?
-        int nb = 0;
-        const size_t lds3 = kRoleLdsLimit + 16 + kCtlWords * sizeof(int);
-        hipError_t e;
-        switch (h->ND) {
-            case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_persistent_kernel<1, 3>, kConvThreads, lds3); break;
-            case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_persistent_kernel<2, 3>, kConvThreads, lds3); break;
-            case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_persistent_kernel<3, 3>, kConvThreads, lds3); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rollout_persistent_kernel<4, 3>, kConvThreads, lds3); break;
-        }
-        h->role_ok = e == hipSuccess && nb >= 3;
-    }
 #endif
     *out = h;
     return VF_OK;
@@ -1003,9 +940,6 @@ int vf_destroy(vf_handle *h) {
         if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
     }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : h->ev_join) (void)hipEventDestroy(e);
-    for (hipStream_t s : h->sub_streams) (void)hipStreamDestroy(s);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->rccl_lib) dlclose(h->rccl_lib);
 #endif
     delete h;
@@ -1216,7 +1150,6 @@ struct LaunchSink {
 #endif
 
 struct ScheduleSink {
-    bool role_mode = false;     // light phases get role 1 (vf_persistent.h)
     std::vector<PhaseDesc> phases;
     int next_ticket = 0, next_counter = 0;      // tickets are re-assigned when the views are merged
     double flops = 0.0;         // algorithmic FLOPs of all MFMA (conv / FC) phases
@@ -1255,8 +1188,7 @@ struct ScheduleSink {
         P.whole = type == PH_FC_PARTIAL;
         P.mrep = l.mrep;
         P.prec = p.tile_variant;
-        max_lds = std::max(max_lds, p.tile_variant == 2 ? l.lds_dma : (p.tile_variant == 3 ? l.lds_bd : l.lds_bytes));
-        P.role = (role_mode && type != PH_LSTM) ? 1 : 0;
+        max_lds = std::max(max_lds, l.lds_bytes);
         const double rows = (double)p.B * l.Hout * l.Wout;
         const double taps = l.mode == PACK_CONVT ? 9.0 / 4.0 * 4.0 : (double)l.KH * l.KW;   // real taps
         flops += 2.0 * rows * taps * (l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0)) *
@@ -1266,19 +1198,19 @@ struct ScheduleSink {
     int sa(const SaParams &p, std::initializer_list<int> deps) {
         PhaseDesc P;
         memset(&P, 0, sizeof(P));
-        P.type = PH_SA; P.sa = p; P.B = p.B; P.role = role_mode ? 1 : 0;
+        P.type = PH_SA; P.sa = p; P.B = p.B;
         return add(P, (p.B + kSaPerItem - 1) / kSaPerItem, p.B, deps);
     }
     int fin(const FinParams &p, std::initializer_list<int> deps) {
         PhaseDesc P;
         memset(&P, 0, sizeof(P));
-        P.type = PH_CDNA_FIN; P.fin = p; P.B = p.B; P.role = role_mode ? 1 : 0;
+        P.type = PH_CDNA_FIN; P.fin = p; P.B = p.B;
         return add(P, p.B, p.B, deps);
     }
     int composite(const CompositeParams &p, int ntiles, int view, std::initializer_list<int> deps) {
         PhaseDesc P;
         memset(&P, 0, sizeof(P));
-        P.type = PH_COMPOSITE; P.comp = p; P.B = p.B; P.gx = ntiles; P.view = view; P.role = role_mode ? 1 : 0;
+        P.type = PH_COMPOSITE; P.comp = p; P.B = p.B; P.gx = ntiles; P.view = view;
         return add(P, ntiles * p.B, p.B, deps);
     }
     // top transposed conv + compositing: one fused item per conv tile where the tile geometry allows it (a region
@@ -1296,7 +1228,7 @@ struct ScheduleSink {
         P.type = PH_TOP_FUSED; P.conv = p; P.comp = cp; P.B = p.B; P.view = view;
         P.NI = 1; P.tiles_per_img = l.tilesY * l.tilesX;
         P.gx = p.B * P.tiles_per_img; P.gy = 1;
-        P.mrep = 1; P.role = 0;
+        P.mrep = 1;
         P.aux_base = next_counter + p.B;        // behind the completion counters of this phase
         max_lds = std::max(max_lds, std::max(l.lds_bytes, fused_top_lds_floats(l.TH, l.TW, cp.ND) * 4));
         flops += 2.0 * (double)p.B * l.Hout * l.Wout * 9.0 * (l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0)) * l.Cout;
@@ -1329,7 +1261,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
     const int *L = kLstmSizes;
     const int lh[7] = {H2, H2, H4, H4, H8, H4, H2}, lw[7] = {W2, W2, W4, W4, W8, W4, W2};
     auto params = [&](const ConvLayer &l, int Bp, const SegArg &s0, const SegArg *s1) {
-        return make_params(l, vd.lw[l.id], Bp, s0, s1, h->d_zeros, h->lstm_dma, h->role_active);
+        return make_params(l, vd.lw[l.id], Bp, s0, s1);
     };
 
     // tile plan of conv-LSTM k for a phase of Bp samples: the 256-row plan once the phase has many more items than
@@ -1346,10 +1278,6 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         int want = beff >= 500.0 || (beff >= 150.0 && k < 2) ? 2
                    : (n128 <= h->n_cu ? 4 : (n128 <= 2 * h->n_cu ? 3 : 1));
         if (h->mrep_override[k]) want = h->mrep_override[k];
-        if (h->role_active) {       // three workgroups per CU: only tiles that fit a third of the LDS and 168 VGPRs
-            if (want >= 3 && h->half_ok[k] && h->lstm_half[k].lds_bytes <= kRoleLdsLimit) return h->lstm_half[k];
-            return h->lstm[k];
-        }
         if (want == 2 && h->big_ok[k]) return h->lstm_big[k];
         if (want == 4 && h->quarter_ok[k]) return h->lstm_quarter[k];
         if (want >= 3 && h->half_ok[k]) return h->lstm_half[k];
@@ -1554,7 +1482,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
             cp.out_sums = v.sums + (long long)t_out * h->sums_step_stride;
             if (goal_pix)
                 for (int d = 0; d < ND; ++d) { cp.goal[d][0] = goal_pix[2 * d]; cp.goal[d][1] = goal_pix[2 * d + 1]; }
-            VF_EMIT(u_comp, sink.top(*top_l, p, cp, h->ntiles, view, top_d0, top_d1, u_fin, h->fuse_top && !h->role_active && h->persist_wgs_per_cu <= 2))
+            VF_EMIT(u_comp, sink.top(*top_l, p, cp, h->ntiles, view, top_d0, top_d1, u_fin, h->fuse_top))
             last = u_comp;
         }
     }
@@ -1567,27 +1495,22 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
 struct BuiltSchedule {
     std::vector<PhaseDesc> phases;
     int items = 0, counters = 0;
-    int nq = 1, total_q[kRoles][kQueues] = {{0}};
-    bool roles2 = false;
+    int nq = 1, total_q[kQueues] = {0};
     double flops = 0.0;
     size_t lds = 0;
 };
 
 // One phase list per view (own weights, own buffers, own counters), merged phase by phase so that
 // the views advance together and a phase's items of both views are neighbours in ticket order.
-static int build_schedule_as(vf_handle *h, int B, bool skip_shared, BuiltSchedule &out, bool roles2) {
+static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &out) {
     std::vector<ScheduleSink> sinks(h->ncam);
     int counters = 0, rc;
     out.flops = 0.0;
-    out.roles2 = roles2;
     size_t max_lds = 0;
     for (int v = 0; v < h->ncam; ++v) {
         sinks[v].next_counter = counters;
-        sinks[v].role_mode = roles2;
-        h->role_active = roles2;        // tile plans and variants of the emission below
-        rc = emit_rollout(h, v, make_view(h, v, h->actions_buf, 0), h->shared_views[(size_t)v * kMaxSubBatches],
-                          B, nullptr, sinks[v], skip_shared);
-        h->role_active = false;
+        rc = emit_rollout(h, v, make_view(h, v, h->actions_buf, 0), h->shared_views[(size_t)v], B, nullptr, sinks[v],
+                          skip_shared);
         if (rc < 0) return rc;
         counters = sinks[v].next_counter;
         out.flops += sinks[v].flops;
@@ -1609,8 +1532,7 @@ static int build_schedule_as(vf_handle *h, int B, bool skip_shared, BuiltSchedul
     while (n_xcd < kQueues && n_xcd * 2 * 32 <= h->n_cu) n_xcd *= 2;
     const int nq = (h->xcd_queues > 1 && ticket >= 4 * h->n_cu) ? n_xcd : 1;
     out.nq = nq;
-    for (int r = 0; r < kRoles; ++r)
-        for (int q = 0; q < kQueues; ++q) out.total_q[r][q] = 0;
+    for (int q = 0; q < kQueues; ++q) out.total_q[q] = 0;
     for (PhaseDesc &P : out.phases) {
         P.q_gy = 1; P.q_inner = 1;
         if (nq > 1) {
@@ -1623,15 +1545,12 @@ static int build_schedule_as(vf_handle *h, int B, bool skip_shared, BuiltSchedul
             }
         }
         const int units = P.n_items / (P.q_gy * P.q_inner), per = nq / P.q_gy;
-        // the phase lives in the queues of its role; in the other role's queues it is an empty range at their
-        // running total, so a workgroup scanning those queues walks straight past it
-        for (int r = 0; r < kRoles; ++r)
-            for (int q = 0; q < kQueues; ++q) {
-                const int qb = q / P.q_gy;
-                P.first_q[r][q] = out.total_q[r][q < nq ? q : 0];
-                P.n_q[r][q] = (r == P.role && q < nq && qb < units) ? ((units - qb + per - 1) / per) * P.q_inner : 0;
-                if (q < nq) out.total_q[r][q] += P.n_q[r][q];
-            }
+        for (int q = 0; q < kQueues; ++q) {
+            const int qb = q / P.q_gy;
+            P.first_q[q] = out.total_q[q < nq ? q : 0];
+            P.n_q[q] = (q < nq && qb < units) ? ((units - qb + per - 1) / per) * P.q_inner : 0;
+            if (q < nq) out.total_q[q] += P.n_q[q];
+        }
     }
     out.counters = counters;
     const size_t comp_lds[kMaxDesig] = {(size_t)composite_lds_floats<1, 10>() * 4, (size_t)composite_lds_floats<2, 10>() * 4,
@@ -1640,17 +1559,6 @@ static int build_schedule_as(vf_handle *h, int B, bool skip_shared, BuiltSchedul
     if (out.phases.size() > h->sched_capacity || (size_t)counters > h->counter_capacity)
         return fail(VF_ERR_INVALID, "persistent schedule exceeds its preallocated capacity");
     return VF_OK;
-}
-
-// Role mode is used when it is asked for (vf_set_role_mode), the engine can run three workgroups per CU (exact
-// fp32, occupancy checked at vf_create) and this launch's tiles fit a third of the LDS; otherwise the plain schedule.
-static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &out) {
-    if (h->role_mode && h->role_ok) {
-        int rc = build_schedule_as(h, B, skip_shared, out, true);
-        if (rc) return rc;
-        if (out.lds <= kRoleLdsLimit + 16 && out.items >= 6 * h->n_cu && out.nq > 1) return VF_OK;
-    }
-    return build_schedule_as(h, B, skip_shared, out, false);
 }
 
 #ifdef VF_HOST_SELFTEST
@@ -1723,55 +1631,40 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
         if (!ok) return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + " points outside the handle's buffers");
     }
     if (ticket != bs.items) return fail(VF_ERR_INVALID, "item count mismatch");
-    // the queue dealing must be a bijection: walking every queue position of a phase's role with the device's
-    // formula (rollout_persistent_kernel) visits each item of each phase exactly once, queues in phase order; in the
-    // other role's queues the phase is an empty range at their running total
+    // the queue dealing must be a bijection: walking every queue position of a phase with the device's formula
+    // (rollout_persistent_kernel) visits each item of each phase exactly once, queues in phase order
     {
-        int head[kRoles][kQueues] = {{0}}, total = 0;
+        int head[kQueues] = {0}, total = 0;
         std::vector<char> seen;
         for (size_t i = 0; i < bs.phases.size(); ++i) {
             const PhaseDesc &P = bs.phases[i];
             if (P.q_gy < 1 || P.q_inner < 1 || bs.nq % P.q_gy) return fail(VF_ERR_INVALID, "bad dealing rule");
-            if (P.role < 0 || P.role >= kRoles || (!bs.roles2 && P.role)) return fail(VF_ERR_INVALID, "bad role");
-            if (bs.roles2 && (P.role == 0) != (P.type == PH_LSTM)) return fail(VF_ERR_INVALID, "role does not match the phase type");
             seen.assign((size_t)P.n_items, 0);
-            for (int r = 0; r < kRoles; ++r)
-                for (int q = 0; q < bs.nq; ++q) {
-                    if (P.first_q[r][q] != head[r][q]) return fail(VF_ERR_INVALID, "queue ranges are not contiguous");
-                    if (r != P.role && P.n_q[r][q]) return fail(VF_ERR_INVALID, "items in a queue of the other role");
-                    for (int lq = 0; lq < P.n_q[r][q]; ++lq) {
-                        const int per = bs.nq / P.q_gy, qb = q / P.q_gy, cg = q - qb * P.q_gy;
-                        const int grp = lq / P.q_inner, inner = lq - grp * P.q_inner;
-                        const int local = ((grp * per + qb) * P.q_inner + inner) * P.q_gy + cg;
-                        if (local < 0 || local >= P.n_items || seen[(size_t)local])
-                            return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": dealing is not a bijection");
-                        seen[(size_t)local] = 1;
-                    }
-                    head[r][q] += P.n_q[r][q];
-                    total += P.n_q[r][q];
+            for (int q = 0; q < bs.nq; ++q) {
+                if (P.first_q[q] != head[q]) return fail(VF_ERR_INVALID, "queue ranges are not contiguous");
+                for (int lq = 0; lq < P.n_q[q]; ++lq) {
+                    const int per = bs.nq / P.q_gy, qb = q / P.q_gy, cg = q - qb * P.q_gy;
+                    const int grp = lq / P.q_inner, inner = lq - grp * P.q_inner;
+                    const int local = ((grp * per + qb) * P.q_inner + inner) * P.q_gy + cg;
+                    if (local < 0 || local >= P.n_items || seen[(size_t)local])
+                        return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": dealing is not a bijection");
+                    seen[(size_t)local] = 1;
                 }
-            for (int r = 0; r < kRoles; ++r)
-                for (int q = bs.nq; q < kQueues; ++q)
-                    if (P.n_q[r][q]) return fail(VF_ERR_INVALID, "items in an unused queue");
-            if (bs.roles2 && P.type == PH_LSTM && P.prec != 3 && P.mrep != 0)
-                return fail(VF_ERR_INVALID, "role mode with a conv-LSTM tile that needs more than a third of the LDS");
+                head[q] += P.n_q[q];
+                total += P.n_q[q];
+            }
+            for (int q = bs.nq; q < kQueues; ++q)
+                if (P.n_q[q]) return fail(VF_ERR_INVALID, "items in an unused queue");
         }
-        for (int r = 0; r < kRoles; ++r)
-            for (int q = 0; q < bs.nq; ++q)
-                if (head[r][q] != bs.total_q[r][q]) return fail(VF_ERR_INVALID, "queue totals mismatch");
+        for (int q = 0; q < bs.nq; ++q)
+            if (head[q] != bs.total_q[q]) return fail(VF_ERR_INVALID, "queue totals mismatch");
         if (total != bs.items) return fail(VF_ERR_INVALID, "dealt item count mismatch");
-        if (bs.roles2 && bs.lds > kRoleLdsLimit + 16) return fail(VF_ERR_INVALID, "role mode beyond its LDS budget");
     }
     if (out_items) *out_items = bs.items;
     if (out_upload_checksum) *out_upload_checksum = h->upload_checksum;
     return VF_OK;
 }
-extern "C" int vf_set_role_mode(vf_handle *h, int32_t enable) {     // (the device build defines it further down)
-    if (!h) return fail(VF_ERR_INVALID, "null handle");
-    h->role_mode = enable != 0;
-    return VF_OK;
-}
-extern "C" int vf_set_fuse_top(vf_handle *h, int32_t enable) {
+extern "C" int vf_set_fuse_top(vf_handle *h, int32_t enable) {      // (the device build defines it further down)
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->fuse_top = enable != 0;
     return VF_OK;
@@ -1807,21 +1700,11 @@ static bool shared_cache_hit(vf_handle *h, int cfg) {
     return h->dedup && h->cache_shared && h->shared_valid && h->shared_cfg == cfg;
 }
 
-template <int ND, int WPS>
-static int launch_persistent_w(const Schedule &sc, int grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((rollout_persistent_kernel<ND, WPS>), dim3(grid), dim3(kConvThreads), lds, st, sc.phases,
-                       sc);
+template <int ND>
+static int launch_persistent_t(const Schedule &sc, int grid, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((rollout_persistent_kernel<ND>), dim3(grid), dim3(kConvThreads), lds, st, sc.phases, sc);
     VF_HIP_CHECK(hipGetLastError());
     return VF_OK;
-}
-
-template <int ND>
-static int launch_persistent_t(vf_handle *h, const Schedule &sc, int grid, size_t lds, hipStream_t st) {
-    // 3 resident workgroups per CU need the 168-VGPR build, which has no 256-row LSTM tile
-    bool any_mrep2 = false;
-    any_mrep2 = h->have_big;
-    if (h->persist_wgs_per_cu >= 3 && !any_mrep2) return launch_persistent_w<ND, 3>(sc, grid, lds, st);
-    return launch_persistent_w<ND, 2>(sc, grid, lds, st);
 }
 
 // the whole rollout (every view) as one persistent launch (vf_persistent.h)
@@ -1835,8 +1718,8 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     const int cfg = 1000;
     const bool skip_shared = shared_cache_hit(h, cfg);
     vf_handle::SchedCache &sc_host = h->sched[skip_shared ? 1 : 0];
-    if (sc_host.B != B || sc_host.dedup != h->dedup || sc_host.lstm_dma != h->lstm_dma ||
-        sc_host.xcd_queues != h->xcd_queues || sc_host.role_mode != h->role_mode || sc_host.fuse_top != h->fuse_top) {
+    if (sc_host.B != B || sc_host.dedup != h->dedup || sc_host.xcd_queues != h->xcd_queues ||
+        sc_host.fuse_top != h->fuse_top) {
         BuiltSchedule bs;
         if ((rc = build_schedule(h, B, skip_shared, bs))) return rc;
         // Upload without synchronising the caller's stream: the copy is stream-ordered behind the
@@ -1860,13 +1743,12 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
                                     hipMemcpyHostToDevice, st));
         VF_HIP_CHECK(hipEventRecord(h->stage_done[slot], st));
         h->stage_used[slot] = true;
-        sc_host.B = B; sc_host.dedup = h->dedup; sc_host.lstm_dma = h->lstm_dma;
-        sc_host.xcd_queues = h->xcd_queues; sc_host.role_mode = h->role_mode; sc_host.roles2 = bs.roles2;
+        sc_host.B = B; sc_host.dedup = h->dedup;
+        sc_host.xcd_queues = h->xcd_queues;
         sc_host.fuse_top = h->fuse_top;
         sc_host.items = bs.items; sc_host.counters = bs.counters;
         sc_host.nq = bs.nq;
-        for (int r = 0; r < kRoles; ++r)
-            for (int q = 0; q < kQueues; ++q) sc_host.total_q[r][q] = bs.total_q[r][q];
+        for (int q = 0; q < kQueues; ++q) sc_host.total_q[q] = bs.total_q[q];
         sc_host.phases = (int)bs.phases.size();
         sc_host.types.clear(); sc_host.nitems.clear();
         for (const PhaseDesc &P : bs.phases) { sc_host.types.push_back(P.type); sc_host.nitems.push_back(P.n_items); }
@@ -1876,17 +1758,14 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     h->last_sched = skip_shared ? 1 : 0;
     if (!skip_shared)
         for (int v = 0; v < h->ncam; ++v)
-            if ((rc = zero_shared_state(h, h->shared_views[(size_t)v * kMaxSubBatches], st))) return rc;
+            if ((rc = zero_shared_state(h, h->shared_views[(size_t)v], st))) return rc;
     VF_HIP_CHECK(hipMemsetAsync(h->d_sync, 0, (kSyncHead + (size_t)sc_host.counters) * sizeof(int), st));
     Schedule sc;
     memset(&sc, 0, sizeof(sc));
     sc.phases = sc_host.d_phases; sc.n_phases = sc_host.phases; sc.total_items = sc_host.items;
     sc.ticket = h->d_sync; sc.counters = h->d_sync + kSyncHead; sc.status = h->d_status;
     sc.nq = sc_host.nq;
-    sc.roles = sc_host.roles2 ? kRoles : 1;
-    sc.cu_arrivals = h->d_sync + kRoles * kQueues * kTicketStride;
-    for (int r = 0; r < kRoles; ++r)
-        for (int q = 0; q < kQueues; ++q) sc.total_q[r][q] = sc_host.total_q[r][q];
+    for (int q = 0; q < kQueues; ++q) sc.total_q[q] = sc_host.total_q[q];
     sc.stats = nullptr;
     sc.nd = h->ND;
     for (int i = 0; i < h->ncam * h->ND * 2; ++i) sc.goal[i] = goal_pix[i];
@@ -1898,7 +1777,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     // resident workgroups per CU: bounded by the LDS a workgroup needs (160 KiB per CU)
     const size_t lds = sc_host.lds + kCtlWords * sizeof(int);
     const int by_lds = (int)std::max<size_t>(1, (160 * 1024) / lds);
-    const int wgs_per_cu = sc_host.roles2 ? 3 : std::min(h->persist_wgs_per_cu, by_lds);
+    const int wgs_per_cu = std::min(h->persist_wgs_per_cu, by_lds);
     const int grid = std::min(sc_host.items, h->n_cu * wgs_per_cu);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) {
@@ -1910,20 +1789,11 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         e0 = h->ev_pool[h->ev_used]; e1 = h->ev_pool[h->ev_used + 1];
         VF_HIP_CHECK(hipEventRecord(e0, st));
     }
-    if (sc_host.roles2) {
-        switch (h->ND) {
-            case 1: rc = launch_persistent_w<1, 3>(sc, grid, lds, st); break;
-            case 2: rc = launch_persistent_w<2, 3>(sc, grid, lds, st); break;
-            case 3: rc = launch_persistent_w<3, 3>(sc, grid, lds, st); break;
-            default: rc = launch_persistent_w<4, 3>(sc, grid, lds, st); break;
-        }
-    } else {
-        switch (h->ND) {
-            case 1: rc = launch_persistent_t<1>(h, sc, grid, lds, st); break;
-            case 2: rc = launch_persistent_t<2>(h, sc, grid, lds, st); break;
-            case 3: rc = launch_persistent_t<3>(h, sc, grid, lds, st); break;
-            default: rc = launch_persistent_t<4>(h, sc, grid, lds, st); break;
-        }
+    switch (h->ND) {
+        case 1: rc = launch_persistent_t<1>(sc, grid, lds, st); break;
+        case 2: rc = launch_persistent_t<2>(sc, grid, lds, st); break;
+        case 3: rc = launch_persistent_t<3>(sc, grid, lds, st); break;
+        default: rc = launch_persistent_t<4>(sc, grid, lds, st); break;
     }
     if (rc) return rc;
     if (h->profiling) {
@@ -1952,36 +1822,14 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
 
-    // Samples never interact before the scores are compared, so the per-layer path may cut the
-    // batch into sub-batches that advance on forked streams: while one sub-batch drains the tail of
-    // a layer, the other's workgroups fill the idle CUs.  Results are bit-identical for any split.
-    const int nsub = std::max(1, std::min({h->n_sub, B / 16, (int)h->sub_streams.size() + 1}));
     if (h->persistent) {
         if ((rc = run_persistent(h, d_actions, B, goal_pix, st))) return rc;
-    } else if (nsub == 1) {
+    } else {
         const bool skip = shared_cache_hit(h, 1);
         for (int v = 0; v < h->ncam; ++v)
-            if ((rc = run_steps(h, v, make_view(h, v, d_actions, 0), h->shared_views[(size_t)v * kMaxSubBatches], B,
-                                goal_pix, st, skip)))
+            if ((rc = run_steps(h, v, make_view(h, v, d_actions, 0), h->shared_views[(size_t)v], B, goal_pix, st, skip)))
                 return rc;
         h->shared_valid = h->dedup; h->shared_cfg = 1;
-    } else {
-        const bool skip = shared_cache_hit(h, 100 + nsub);
-        VF_HIP_CHECK(hipEventRecord(h->ev_fork, st));
-        for (int i = 0; i < nsub; ++i) {
-            const int b0 = (int)((long long)B * i / nsub), b1 = (int)((long long)B * (i + 1) / nsub);
-            hipStream_t ss = i == 0 ? st : h->sub_streams[i - 1];
-            if (i > 0) VF_HIP_CHECK(hipStreamWaitEvent(ss, h->ev_fork, 0));
-            for (int v = 0; v < h->ncam; ++v)
-                if ((rc = run_steps(h, v, make_view(h, v, d_actions, b0),
-                                    h->shared_views[(size_t)v * kMaxSubBatches + i], b1 - b0, goal_pix, ss, skip)))
-                    return rc;
-            if (i > 0) {
-                VF_HIP_CHECK(hipEventRecord(h->ev_join[i - 1], ss));
-                VF_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join[i - 1], 0));
-            }
-        }
-        h->shared_valid = h->dedup; h->shared_cfg = 100 + nsub;
     }
     TaskWeights tw;
     memset(&tw, 0, sizeof(tw));
@@ -2002,35 +1850,14 @@ int vf_set_persistent(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->persistent = enable != 0;
 #ifdef VF_DEBUG_KNOBS
-    if (const char *e = getenv("VF_PERSIST_WGS_PER_CU")) h->persist_wgs_per_cu = std::max(1, std::min(4, atoi(e)));
+    if (const char *e = getenv("VF_PERSIST_WGS_PER_CU")) h->persist_wgs_per_cu = std::max(1, std::min(2, atoi(e)));
 #endif
-    return VF_OK;
-}
-
-int vf_set_role_mode(vf_handle *h, int32_t enable) {
-    if (!h) return fail(VF_ERR_INVALID, "null handle");
-    h->role_mode = enable != 0;
     return VF_OK;
 }
 
 int vf_set_fuse_top(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->fuse_top = enable != 0;
-    return VF_OK;
-}
-
-int vf_debug_role_census(vf_handle *h, int32_t *active, int32_t *hist8) {
-    if (!h || !active || !hist8) return fail(VF_ERR_INVALID, "null argument");
-#ifndef VF_HOST_SELFTEST
-    VF_HIP_CHECK(hipSetDevice(h->cfg.device));
-    VF_HIP_CHECK(hipDeviceSynchronize());
-    std::vector<int> arr(kCuSlots);
-    VF_HIP_CHECK(hipMemcpy(arr.data(), h->d_sync + kRoles * kQueues * kTicketStride, kCuSlots * sizeof(int),
-                           hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; ++i) hist8[i] = 0;
-    for (int v : arr) ++hist8[std::min(std::max(v, 0), 7)];
-#endif
-    *active = h->sched[h->last_sched].roles2 ? 1 : 0;
     return VF_OK;
 }
 
@@ -2045,7 +1872,10 @@ int vf_device_status(vf_handle *h, int32_t *status) {
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
     VF_HIP_CHECK(hipDeviceSynchronize());
     VF_HIP_CHECK(hipMemcpy(status, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
-    if (*status != 0) VF_HIP_CHECK(hipMemset(h->d_status, 0, sizeof(int)));    // observed: re-arm
+    if (*status != 0) {     // observed: re-arm; the abandoned launch may have left the context-only buffers half-written
+        VF_HIP_CHECK(hipMemset(h->d_status, 0, sizeof(int)));
+        h->shared_valid = false;
+    }
     return VF_OK;
 }
 
@@ -2090,32 +1920,10 @@ int vf_debug_tile_clocks(uint64_t *out /*[16][8]*/, int32_t reset) {
 }
 #endif
 
-int vf_set_lstm_tile(vf_handle *h, int32_t variant) {
-    if (!h || (variant != 0 && variant != 2)) return fail(VF_ERR_INVALID, "tile variant must be 0 (LDS-B tile) or 2 (DMA tile)");
-    h->lstm_dma = variant == 2;
-    return VF_OK;
-}
-
 int vf_set_dedup(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->dedup = enable != 0;
     h->shared_valid = false;
-    return VF_OK;
-}
-
-int vf_set_substreams(vf_handle *h, int32_t n) {
-    if (!h || n < 1 || n > kMaxSubBatches) return fail(VF_ERR_INVALID, "sub-stream count must be 1..8");
-    VF_HIP_CHECK(hipSetDevice(h->cfg.device));
-    while ((int)h->sub_streams.size() < n - 1) {
-        hipStream_t s;
-        hipEvent_t e;
-        VF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        VF_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->sub_streams.push_back(s);
-        h->ev_join.push_back(e);
-    }
-    if (!h->ev_fork) VF_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    h->n_sub = n;
     return VF_OK;
 }
 

@@ -145,8 +145,12 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
         }
     }
     __syncthreads();
-    if (*s_flag == 0) {                      // a mate never arrived: raise the launch's failure word and give up
-        if (tid == 0) atomicExch(const_cast<int *>(p.fuse_status), 1);
+    if (*s_flag == 0) {                      // a mate never arrived: raise the launch's failure word and give up;
+        if (tid == 0) {                      // word 1 of the control block tells the scheduler loop not to publish
+            extern __shared__ __attribute__((aligned(16))) float smem_all[];
+            atomicExch(const_cast<int *>(p.fuse_status), 1);
+            reinterpret_cast<int *>(smem_all)[1] = 0;
+        }
         return;
     }
     const float mean = s_ln[0], rstd = s_ln[1];

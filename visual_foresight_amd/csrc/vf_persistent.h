@@ -33,8 +33,6 @@ enum PhaseType {
 constexpr int kMaxDeps = 3;
 constexpr int kQueues = 8;                  // one ticket queue per XCD
 constexpr int kTicketStride = 32;           // ints between ticket heads (128 B)
-constexpr int kRoles = 2;                   // workgroup roles of the role mode: 0 conv-LSTM items, 1 everything else
-constexpr int kCuSlots = kQueues * 256;     // per-CU arrival counters of the role mode, indexed by (XCC_ID, HW_ID[15:8])
 constexpr int kSaPerItem = 4;               // samples per PH_SA item (one per wave)
 constexpr unsigned kSpinLimit = 1u << 26;   // polls before a waiting item gives up (~ seconds)
 
@@ -47,9 +45,7 @@ struct PhaseDep {
 struct PhaseDesc {
     int type;
     int first_ticket, n_items;          // position in the global phase order (bookkeeping, statistics)
-    int role;                           // which workgroups serve this phase (0 unless the launch runs in role mode)
-    int first_q[kRoles][kQueues], n_q[kRoles][kQueues];    // ticket range of this phase in each XCD's queue of its
-                                        // role; in the other role's queues it is empty and sits at their running total
+    int first_q[kQueues], n_q[kQueues]; // ticket range of this phase in each XCD's queue
     int q_gy, q_inner;                  // dealing rule: item = (unit * q_inner + inner) * q_gy + cg  ->  queue
                                         // (unit % (nq / q_gy)) * q_gy + cg, so a channel group's weight slice and a
                                         // sample's tiles stay inside one XCD's L2
@@ -58,7 +54,7 @@ struct PhaseDesc {
     int NI, tiles_per_img;  // conv phases: how an item maps to samples
     int whole;              // 1: completion is counted once per item on counter 0
     int mrep;               // MFMA row blocks per wave of this conv phase (1 or 2; 0 / -1: the 64- / 32-row conv-LSTM tiles)
-    int prec;               // conv-LSTM tile: 0 fp32 (B through LDS), 1 split-bf16, 2 fp32 DMA tile, 3 fp32 with B from L2
+    int prec;               // conv-LSTM tile: 0 exact fp32, 1 split-bf16
     int view;               // camera view this phase belongs to (selects the goal pixels of PH_COMPOSITE)
     int cnt_base;
     int aux_base;           // PH_TOP_FUSED: first of the per-sample "LayerNorm partial published" counters
@@ -78,12 +74,9 @@ struct Schedule {
     const PhaseDesc *phases;
     int n_phases;
     int total_items;
-    int *ticket;            // [kRoles][kQueues][kTicketStride] ticket heads, one per role and XCD (own cache lines)
-    int total_q[kRoles][kQueues];   // items per queue
+    int *ticket;            // [kQueues][kTicketStride] ticket heads, one per XCD (own cache lines)
+    int total_q[kQueues];   // items per queue
     int nq;                 // XCD queues in use: kQueues, or 1 (plain phase order)
-    int roles;              // 1: every workgroup serves every phase; 2: role mode (three workgroups per CU: the first
-                            //    two to arrive on a CU take conv-LSTM items, the third everything else)
-    int *cu_arrivals;       // [kCuSlots] role mode: workgroups that have started on each CU (zeroed per launch)
     int *counters;          // completion counters
     int *status;            // [1] sticky: set non-zero when an item gave up waiting; cleared by the host
                             //     only after it has been read (vf_device_status)
@@ -136,38 +129,24 @@ __device__ __forceinline__ float *tile_lds() {
     return smem_all + kCtlWords;    // the control block comes first
 }
 
-// (WPS: the kernel instance a tile body is compiled for.  Device functions shared by the 2- and the 3-workgroups-
-// per-CU kernels would be compiled once, for the tighter 168-VGPR budget; the unused parameter keeps them apart.)
-// Exception, measured: the 128-row fp32 conv-LSTM tile is FASTER when compiled for 168 VGPRs (C2: 71.69 vs 71.86 ms),
-// so both kernels call the instance tagged 3.
-constexpr int kSharedLstmWps = 3;
-template <int WPS, int G, int EPI, int MREP>
+template <int G, int EPI, int MREP>
 __device__ __noinline__ void conv_tile_call(const ConvParams *p, int bx, int by, int bz) {
     conv_tile<G, EPI, MREP>(const_params(p), bx, by, bz, tile_lds());
 }
-template <int WPS>
-__device__ __noinline__ void lstm_bd_tile_call(const ConvParams *p, int bx, int by) {
-    conv_tile<4, EPI_LSTM, 1, const VF_CONST_AS ConvParams, 4, true>(const_params(p), bx, by, 0, tile_lds());
-}
-template <int WPS, int RB>
+template <int RB>
 __device__ __noinline__ void lstm_split_tile_call(const ConvParams *p, int bx, int by) {
     conv_tile<4, EPI_LSTM, 1, const VF_CONST_AS ConvParams, RB>(const_params(p), bx, by, 0, tile_lds());
 }
-template <int WPS>
-__device__ __noinline__ void lstm_dma_tile_call(const ConvParams *p, int bx, int by) {
-    conv_lstm_dma_tile<1>(const_params(p), bx, by, tile_lds());
-}
-template <int WPS, int MREP>
+template <int MREP>
 __device__ __noinline__ void lstm_bf16x6_tile_call(const ConvParams *p, int bx, int by) {
     conv_lstm_bf16x6_tile<MREP>(const_params(p), bx, by, tile_lds());
 }
-template <int WPS, int ND, bool FIRST>
+template <int ND, bool FIRST>
 __device__ __noinline__ void composite_tile_call(const CompositeParams *p, int tile, int b, int view) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
     composite_tile<ND, 10, FIRST>(const_params(p), tile, b, goal, tile_lds());
 }
-template <int WPS>
 __device__ __noinline__ void small_item_call(const PhaseDesc *P, int type, int b0, int b1) {
     float *smem = tile_lds();
     if (type == PH_SA) {
@@ -178,10 +157,9 @@ __device__ __noinline__ void small_item_call(const PhaseDesc *P, int type, int b
     }
 }
 
-// WPS = waves per SIMD the kernel is compiled for (= resident workgroups per CU).  WPS 3 leaves
-// 168 VGPRs per lane, which fits every tile body except the 256-row conv-LSTM tile (MREP 2).
-template <int ND, int WPS>
-VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
+// Two resident workgroups per CU (one wave of each per SIMD): 256 VGPRs per lane for every tile body.
+template <int ND>
+VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
     const PhaseDesc *__restrict__ phases, const Schedule sched) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     // all LDS in one dynamic array: the control block first, the tile workspace after it
@@ -203,56 +181,33 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
     const int nq = sched.nq;
     const int q_own = (int)(xcc & (unsigned)(nq - 1));
 
-    // Role mode (three resident workgroups per CU): the light phases - encoder / decoder convs, FC, compositing:
-    // 4 % of the FLOPs but 13 % of the slot time, all staging and latency - get their own workgroup on every CU, which
-    // runs them under the matrix work of the two conv-LSTM workgroups instead of taking a turn in their slots.  The
-    // role follows the order of arrival on the CU (the first workgroup of a CU is its light one) and only decides
-    // which queues a workgroup prefers: once they are empty it serves the other role's, so any placement is correct.
-    int role_own = 0;
-    if (sched.roles > 1) {
-        if (tid == 0) {
-            unsigned hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            const int slot = (int)((xcc & (kQueues - 1)) * 256u + ((hwid >> 8) & 255u));
-            // the FIRST workgroup of a CU is its light one: every CU that runs anything has one, so a launch whose
-            // third workgroups are placed late (or never) still makes progress
-            s_ctl[3] = (atomicAdd(sched.cu_arrivals + slot, 1) % 3 == 0) ? 1 : 0;
-        }
-        __syncthreads();
-        role_own = s_ctl[3];
-    }
-
     for (;;) {
         [[maybe_unused]] const unsigned long long ts_top = VF_TS_NOW();
         __syncthreads();                    // previous item fully retired (LDS reusable)
         if (tid == 0) {
-            int t = -1, qq = q_own, rr = role_own;
-            for (int ro = 0; ro < sched.roles && t < 0; ++ro) {
-                rr = role_own ^ ro;
-                qq = q_own;
-                for (int tries = 0; tries < nq; ++tries) {
-                    const int cand = atomicAdd(sched.ticket + (rr * kQueues + qq) * kTicketStride, 1);
-                    if (cand < sched.total_q[rr][qq]) { t = cand; break; }
-                    qq = (qq + 1) & (nq - 1);
-                }
+            int t = -1, qq = q_own;
+            for (int tries = 0; tries < nq; ++tries) {
+                const int cand = atomicAdd(sched.ticket + qq * kTicketStride, 1);
+                if (cand < sched.total_q[qq]) { t = cand; break; }
+                qq = (qq + 1) & (nq - 1);
             }
             s_ctl[0] = t;
-            s_ctl[2] = rr * kQueues + qq;
+            s_ctl[2] = qq;
         }
         __syncthreads();
         const int t = s_ctl[0];
         if (t < 0) break;
-        const int rq = s_ctl[2], rr = rq / kQueues, qq = rq - rr * kQueues;
-        const bool own = rq == role_own * kQueues + q_own;
+        const int qq = s_ctl[2];
+        const bool own = qq == q_own;
         if (!own) ph = 0;                   // stolen ticket (tail of the launch): look its phase up from the start
-        while (t >= phases[ph].first_q[rr][qq] + phases[ph].n_q[rr][qq]) ++ph;
+        while (t >= phases[ph].first_q[qq] + phases[ph].n_q[qq]) ++ph;
         const int ph_run = ph;
         const PhaseDesc &P = phases[ph_run];
         if (!own) ph = 0;                   // the cursor is only monotone within one queue
         // queue position -> item of the phase
         int local;
         {
-            const int lq = t - P.first_q[rr][qq];
+            const int lq = t - P.first_q[qq];
             const int per = nq / P.q_gy, qb = qq / P.q_gy, cg = qq - qb * P.q_gy;
             const int grp = lq / P.q_inner, inner = lq - grp * P.q_inner;
             local = ((grp * per + qb) * P.q_inner + inner) * P.q_gy + cg;
@@ -306,38 +261,28 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
             const int by = local % P.gy, bx = local / P.gy;
             switch (P.type) {
                 case PH_LSTM:
-                    if (P.prec == 1) {
-                        lstm_bf16x6_tile_call<WPS, 1>(&P.conv, bx, by);      // 128-row tiles only
-                    } else if (P.mrep == 0) {
-                        lstm_split_tile_call<WPS, 2>(&P.conv, bx, by);
-                    } else if (P.mrep < 0) {
-                        lstm_split_tile_call<WPS, 1>(&P.conv, bx, by);
-                    } else if (P.prec == 3) {
-                        lstm_bd_tile_call<WPS>(&P.conv, bx, by);
-                    } else if (P.prec == 2) {
-                        lstm_dma_tile_call<WPS>(&P.conv, bx, by);
-                    } else if (P.mrep == 1) conv_tile_call<kSharedLstmWps, 4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
-                    else if constexpr (WPS <= 2) conv_tile_call<WPS, 4, EPI_LSTM, 2>(&P.conv, bx, by, 0);
+                    if (P.prec == 1) lstm_bf16x6_tile_call<1>(&P.conv, bx, by);         // 128-row tiles only
+                    else if (P.mrep == 0) lstm_split_tile_call<2>(&P.conv, bx, by);
+                    else if (P.mrep < 0) lstm_split_tile_call<1>(&P.conv, bx, by);
+                    else if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
+                    else conv_tile_call<4, EPI_LSTM, 2>(&P.conv, bx, by, 0);
                     break;
-                case PH_CONV_RELU: conv_tile_call<WPS, 1, EPI_BIAS_RELU, 1>(&P.conv, bx, by, 0); break;
-                case PH_CONV_RAW: conv_tile_call<WPS, 1, EPI_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
-                case PH_CONVT_RELU: conv_tile_call<WPS, 4, EPI_CONVT_RELU, 1>(&P.conv, bx, by, 0); break;
-                case PH_CONVT_RAW: conv_tile_call<WPS, 4, EPI_CONVT_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONV_RELU: conv_tile_call<1, EPI_BIAS_RELU, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONV_RAW: conv_tile_call<1, EPI_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONVT_RELU: conv_tile_call<4, EPI_CONVT_RELU, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONVT_RAW: conv_tile_call<4, EPI_CONVT_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
                 case PH_FC_PARTIAL:
-                    conv_tile_call<WPS, 1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx);
+                    conv_tile_call<1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx);
                     break;
-                case PH_TOP_FUSED:      // (two workgroups per CU only: a device function shared with the 168-VGPR
-                                        // instance of this kernel is compiled for 168 VGPRs, and this one then spills)
-                    if constexpr (WPS <= 2) {
-                        if (P.comp.first_frame) conv_tile_call<WPS, 4, fused_epi(ND, true), 1>(&P.conv, bx, 0, 0);
-                        else conv_tile_call<WPS, 4, fused_epi(ND, false), 1>(&P.conv, bx, 0, 0);
-                    }
+                case PH_TOP_FUSED:
+                    if (P.comp.first_frame) conv_tile_call<4, fused_epi(ND, true), 1>(&P.conv, bx, 0, 0);
+                    else conv_tile_call<4, fused_epi(ND, false), 1>(&P.conv, bx, 0, 0);
                     break;
                 case PH_COMPOSITE:
-                    if (P.comp.first_frame) composite_tile_call<WPS, ND, true>(&P.comp, local % P.gx, b0, P.view);
-                    else composite_tile_call<WPS, ND, false>(&P.comp, local % P.gx, b0, P.view);
+                    if (P.comp.first_frame) composite_tile_call<ND, true>(&P.comp, local % P.gx, b0, P.view);
+                    else composite_tile_call<ND, false>(&P.comp, local % P.gx, b0, P.view);
                     break;
-                default: small_item_call<WPS>(&P, P.type, b0, b1); break;
+                default: small_item_call(&P, P.type, b0, b1); break;
             }
         }
 
@@ -345,6 +290,8 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, WPS) void rollout_persistent_kernel(
         [[maybe_unused]] const unsigned long long ts_pub = VF_TS_NOW();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (s_ctl[1] == 0) break;           // the item itself gave up (fused top: a mate never arrived): its outputs
+                                            // were never written, so nothing is published and the rollout is abandoned
         if (sched.stats && tid == 0) {
             const unsigned long long t_end = wall_clock64();
             atomicAdd(sched.stats + 2 * ph_run, t_run - t_start);

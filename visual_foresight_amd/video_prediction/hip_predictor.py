@@ -84,12 +84,9 @@ class HipVPredEvaluation(object):
                                     self.device_index, self.precision, self.n_cam, self.n_draws, c.arch_id)
         self._handle = ctypes.c_void_p()
         _lib.check(self._libh.vf_create(ctypes.byref(self._c_cfg), ctypes.byref(self._handle)))
-        self.set_substreams(int(hp.get('substreams', os.environ.get('VF_SUBSTREAMS', 1))))
         self.set_dedup(int(hp.get('dedup', os.environ.get('VF_DEDUP', 1))))
         self.set_persistent(int(hp.get('persistent', os.environ.get('VF_PERSISTENT', 1))))
-        self.set_lstm_tile(int(hp.get('lstm_tile', os.environ.get('VF_LSTM_TILE', 0))))
         self.set_xcd_queues(int(hp.get('xcd_queues', os.environ.get('VF_XCD_QUEUES', 1))))
-        self.set_role_mode(int(hp.get('role_mode', os.environ.get('VF_ROLE_MODE', 0))))
         self.set_fuse_top(int(hp.get('fuse_top', os.environ.get('VF_FUSE_TOP', 1))))
         self.weights = None
         self._ctx_key = None
@@ -126,27 +123,10 @@ class HipVPredEvaluation(object):
         _lib.check(self._libh.vf_set_xcd_queues(self._handle, int(bool(enable))))
         self.xcd_queues = bool(enable)
 
-    def set_role_mode(self, enable):
-        """Three workgroups per CU, the third one serving the light phases (vf_set_role_mode); bit-identical results."""
-        _lib.check(self._libh.vf_set_role_mode(self._handle, int(bool(enable))))
-        self.role_mode = bool(enable)
-
     def set_fuse_top(self, enable):
         """Top transposed conv + compositing as one item per tile (vf_set_fuse_top); bit-identical results."""
         _lib.check(self._libh.vf_set_fuse_top(self._handle, int(bool(enable))))
         self.fuse_top = bool(enable)
-
-    def role_census(self):
-        """-> (role mode active in the last launch, [CUs with k workgroup arrivals for k = 0..7])."""
-        active, hist = ctypes.c_int32(), (ctypes.c_int32 * 8)()
-        _lib.check(self._libh.vf_debug_role_census(self._handle, ctypes.byref(active), hist))
-        return bool(active.value), list(hist)
-
-    def set_lstm_tile(self, variant):
-        """conv-LSTM tile: 0 = weights through LDS, barrier per tap (default); 2 = LDS-DMA double-buffered input
-        staging, weights from L2; same bits, same speed (A/B switch)."""
-        _lib.check(self._libh.vf_set_lstm_tile(self._handle, int(variant)))
-        self.lstm_tile = int(variant)
 
     def device_status(self):
         """Synchronise, return the sticky failure word of the persistent kernel (0 = healthy), re-arm it."""
@@ -158,17 +138,13 @@ class HipVPredEvaluation(object):
         """A rollout whose tiles gave up waiting poisons its scores with NaN (vf_hip.h): never hand
         them to the elite selection."""
         if np.isnan(scores_np).any():
+            self._ctx_key = None    # the engine drops its context-only cache with the status: upload the context again
             raise _lib.VfError('the persistent rollout kernel reported a failure (device status %d): a tile gave '
                                'up waiting for its producers; scores are invalid' % self.device_status())
 
     def set_dedup(self, enable):
         """Switch context de-duplication (bit-identical results either way; for A/B timing)."""
         _lib.check(self._libh.vf_set_dedup(self._handle, int(bool(enable))))
-
-    def set_substreams(self, n):
-        """Cut each rollout into n concurrent sub-batches (bit-identical results for any n)."""
-        _lib.check(self._libh.vf_set_substreams(self._handle, int(n)))
-        self.substreams = int(n)
 
     # ------------------------------------------------------------------ weights
     def restore(self, weights=None):
