@@ -97,9 +97,36 @@ def spawn_ranks(args):
         renv = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=renv,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    return wait_ranks(procs)
+
+
+def wait_ranks(procs, grace=10.0, poll=0.2):
+    """Watchdog of the self-launched ranks: when any child exits non-zero the others are terminated (they would
+    otherwise sit in a collective that can never complete until the driver's timeout) and the launcher returns
+    that exit code.  Children are fresh processes; this parent never touches a GPU and never re-execs."""
+    alive, rc = list(procs), 0
+    while alive:
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = abs(r) or 1
+                print('bench: a rank exited with code %d; stopping the other %d' % (r, len(alive)), file=sys.stderr)
+                for q in alive:
+                    q.terminate()
+                deadline = time.monotonic() + grace
+                for q in alive:
+                    try:
+                        q.wait(timeout=max(0.0, deadline - time.monotonic()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                        q.wait()
+                alive = []
+                break
+        if alive:
+            time.sleep(poll)
     return rc
 
 
@@ -185,7 +212,8 @@ def library_hash():
 
 def identity_warper(current, reference):
     """Plug-in for the registration controller in the c3 workload: zero flow (the registration network is
-    not part of the reference snapshot; the device side - warp, window medians, warp error - still runs)."""
+    not part of the reference snapshot; the device side - warp, window medians, warp error - still runs, at its
+    best case: an identity flow samples every pixel at an integer position).  The c3 line says so."""
     ncam, H, W = current.shape[:3]
     return None, np.zeros((ncam, H, W, 2), np.float32), None
 
@@ -386,6 +414,17 @@ class Bench(object):
             roof['traffic_source'] = 'profiles/r02_hbm_traffic.json (rocprofv3 PMC passes of this library, offline)'
             roof['traffic_vs_algorithmic'] = prof.get('ratio_to_algorithmic')
 
+    def metric_label(self):
+        """BASELINE.json's metric string for the configuration it is quoted on (c2 at its own size); any other
+        workload or --samples override names what it actually counts, so a c3/c5 or shard line cannot be read as
+        the headline (frames of every view and latent draw are counted)."""
+        if self.args.workload == 'c2' and not self.args.samples and self.args.scaling == 'strong':
+            return 'predicted frames/sec (whole node), 200-sample x 13-step x 64x64 CEM'
+        extra = ''.join([' x %d views' % self.ncam if self.ncam > 1 else '',
+                         ' x %d latent draws' % self.draws if self.draws else ''])
+        return 'predicted frames/sec (whole node), workload %s: %d-sample x %d-step x %dx%d%s CEM' % (
+            self.args.workload, self.M, self.T, self.H, self.W, extra)
+
     def run(self):
         a = self.args
         T, iters = self.T, self.iters
@@ -394,7 +433,7 @@ class Bench(object):
         frames_total = self.M * max(self.draws, 1) * T * self.ncam * iters * a.steps
         shared_gpus = self.world > 1 and self.backend != 'nccl'
         result = {
-            'metric': 'predicted frames/sec (whole node), 200-sample x 13-step x 64x64 CEM',
+            'metric': self.metric_label(),
             'value': frames_total / m['elapsed'], 'unit': 'frames/s', 'n_gpus': self.world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': 1e3 * m['elapsed'] / a.steps,
             'ms_per_step_median_p10_p90': m['call_ms'],
@@ -410,6 +449,8 @@ class Bench(object):
                        'designated_pixels_per_view': self.ndesig, 'precision': primary,
                        'latent_draws_per_action': self.draws,
                        'network': getattr(m['pred'], 'arch', 'cdna'),
+                       **({'registration_flow': 'identity (zero) flow plug-in: vf_register runs at its best case'}
+                          if a.workload == 'c3' else {}),
                        'sharding': 'samples over %d rank(s), one all-gather of score rows per CEM iteration%s' %
                                    (self.world, ' (gloo dry run: ranks share a GPU, not a scaling measurement)'
                                     if shared_gpus else ' over RCCL' if self.world > 1 else '')},

@@ -172,6 +172,19 @@ int vf_register(vf_handle *h, const float *d_current, const float *d_reference, 
 int vf_allgather_scores(vf_handle *h, void *nccl_comm, const double *d_local, int32_t n_local,
                         double *d_all, void *stream);
 
+/* One host thread driving several GPUs (the reference's in-process towers: `ngpu` GPUs behind one
+ * policy object, visual_mpc/video_prediction/setup_predictor.py:70,117-123).  vf_comm_init_all
+ * creates one RCCL communicator per listed device (ncclCommInitAll; devices distinct) with the same
+ * library instance vf_allgather_scores uses; vf_allgather_scores_group issues the all-gather of
+ * every local rank - handle hs[i] on device hs[i]'s, communicator comms[i], stream streams[i]
+ * (streams NULL = default streams) - inside one ncclGroupStart / ncclGroupEnd, which is how a single
+ * thread must drive several ranks.  vf_comm_destroy releases one communicator. */
+int vf_comm_init_all(int32_t n, const int32_t *devices, void **comms);
+int vf_comm_destroy(void *comm);
+int vf_allgather_scores_group(int32_t n, vf_handle *const *hs, void *const *comms,
+                              const double *const *d_local, int32_t n_local, double *const *d_all,
+                              void *const *streams);
+
 /* Persistent rollout (no reference counterpart).  When enabled vf_rollout runs ALL steps, layers
  * and samples as one persistent launch whose workgroups draw tiles from a ticket queue and
  * honour per-sample dependencies, so the tail of one layer overlaps the head of the next

@@ -49,3 +49,30 @@ def test_roundtrip_through_npz_and_model_dir(tmp_path):
     bad['generator/model/convt1/weights'] = bad['generator/model/convt1/weights'][:, :, :-1]
     with pytest.raises(ValueError, match='convt1/w'):
         ci.import_named_arrays(bad, cfg)
+
+
+def test_missing_bias_of_a_normalised_conv_becomes_zeros_and_savp_is_refused():
+    """TF-slim creates no bias for a conv built with normalizer_fn=layer_norm (scale1_conv1, convt3): a real
+    checkpoint dump lacks those two arrays.  Any other missing variable is still an error."""
+    import pytest
+    from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights
+    from visual_foresight_amd.video_prediction.checkpoint_import import export_named_arrays, import_named_arrays
+    from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
+    cfg = CdnaConfig(height=32, width=32)
+    w = CdnaWeights.random(cfg, seed=2, bias_scale=0.05)
+    arrays = export_named_arrays(w)
+    dump = {k: v for k, v in arrays.items() if k not in ('model/scale1_conv1/biases', 'model/convt3/biases')}
+    assert len(dump) == len(arrays) - 2
+    said = []
+    back = import_named_arrays(dump, cfg, log=said.append)
+    assert len(said) == 2
+    for name, arr in w.tensors.items():
+        if name in ('enc0/b', 'convt3/b'):
+            assert not back.tensors[name].any()
+        else:
+            np.testing.assert_array_equal(back.tensors[name], arr)
+    del dump['model/conv2/biases']
+    with pytest.raises(ValueError, match='conv2/biases'):
+        import_named_arrays(dump, cfg, log=said.append)
+    with pytest.raises(ValueError, match='cdna'):
+        import_named_arrays(arrays, SavpConfig(height=64, width=64))

@@ -155,3 +155,119 @@ def test_two_ranks_of_the_real_predictor_match_one(tmp_path, num_samples, stocha
                 else:
                     np.testing.assert_array_equal(a[k], b[k])
     assert single['log'][-1]['chosen'] is not None
+
+
+def test_n_gpus_in_process_lanes_match_one_engine():
+    """``n_gpus=2`` inside ONE process (the reference's in-graph towers, setup_predictor.py:70,117-123): two
+    engines ("lanes") roll contiguous shards - on this one-GPU box both on the same device, gathered through the
+    host - and scores, per-task scores, exported predictions and the propagation fetch equal the single engine bit
+    for bit, ragged shards and chunked lanes included.  Without the oversubscription switch a host with fewer GPUs
+    than ``n_gpus`` is refused instead of silently planning on one GPU."""
+    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+    H = W = 32
+    T, M = 3, 23
+    hp = dict(designated_pixel_count=2, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,
+              sequence_length=T + 2)
+    cfg = CdnaConfig(height=H, width=W, ndesig=2, sequence_length=T + 2)
+    weights = CdnaWeights.random(cfg, seed=12, bias_scale=0.05, ln_jitter=0.1)
+    one = HipVPredEvaluation('', hp).restore(weights)
+    rs = np.random.RandomState(8)
+    ctx = {'context_frames': rs.randint(0, 256, (2, 1, H, W, 3)).astype(np.uint8),
+           'context_actions': rs.normal(0, 0.05, (1, 4)), 'context_states': rs.normal(0, 0.1, (2, 5)),
+           'context_pixel_distributions': pixel_cost.one_hot_distrib([[[9, 9], [20, 3]]], 2, 1, H, W, 2)}
+    actions = rs.normal(0, 0.1, (M, T, 4))
+    goal = np.array([[[3, 20], [30, 1]]])
+    want, want_pt = one.score(ctx, {'actions': actions}, goal)
+    want_out = one(ctx, {'actions': actions})
+    if torch.cuda.device_count() < 2:
+        with pytest.raises(ValueError):
+            HipVPredEvaluation('', hp, n_gpus=2)
+    with pytest.raises(ValueError):
+        HipVPredEvaluation('', hp, n_gpus=0)
+    for n, bs in ((2, M), (3, 5)):
+        lanes = HipVPredEvaluation('', dict(hp, oversubscribe_gpus=1, run_batch_size=bs), n_gpus=n, first_gpu=0)
+        lanes.restore(weights)
+        assert len(lanes._lanes) == n
+        if torch.cuda.device_count() < n:
+            assert lanes._use_rccl is False                 # lanes share a device: the gather goes through the host
+        got, got_pt = lanes.score(ctx, {'actions': actions}, goal)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(got_pt, want_pt)
+        sizes = [l._last_lo for l in lanes._lanes]
+        assert sizes == sorted(sizes) and sizes[0] <= sizes[-1]
+        if bs == M:         # every lane's whole shard is resident: any sample can be fetched
+            for idx in (0, M // 2, M - 1):
+                np.testing.assert_array_equal(lanes.fetch_pixel_distributions(idx),
+                                              want_out['predicted_pixel_distributions'][idx])
+        out = lanes(ctx, {'actions': actions})
+        for k in want_out:
+            np.testing.assert_array_equal(out[k], want_out[k])
+        assert lanes.device_status() == 0
+
+
+def test_grouped_allgather_entry_points():
+    """``vf_comm_init_all`` + ``vf_allgather_scores_group`` + ``vf_comm_destroy`` on the GPUs this box has (one:
+    the grouped collective degenerates to a copy but runs ncclCommInitAll / ncclGroupStart / ncclGroupEnd through
+    the library's own RCCL binding); a device listed twice is refused in-band."""
+    pred, ctx, actions = _small()
+    lib, P = pred._libh, ctypes.c_void_p
+    n = max(1, min(torch.cuda.device_count(), 2))
+    devs = (ctypes.c_int32 * n)(*range(n))
+    comms = (P * n)()
+    rc = lib.vf_comm_init_all(n, devs, comms)
+    if rc != 0:
+        pytest.skip('no usable RCCL: %s' % lib.vf_last_error().decode())
+    dup = (ctypes.c_int32 * 2)(0, 0)
+    two = (P * 2)()
+    assert lib.vf_comm_init_all(2, dup, two) == -1 and b'twice' in lib.vf_last_error()
+    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+    hp = dict(designated_pixel_count=1, run_batch_size=4, adim=4, sdim=5, image_height=32, image_width=32,
+              sequence_length=5)
+    engines = [pred] + [HipVPredEvaluation('', hp, first_gpu=i) for i in range(1, n)]
+    local, full = [], []
+    for i, e in enumerate(engines):
+        with torch.cuda.device(e.device):
+            local.append(torch.arange(6, dtype=torch.float64, device=e.device) + 10.0 * i + 1e-12)
+            full.append(torch.zeros(6 * n, dtype=torch.float64, device=e.device))
+    arr = lambda items: (P * n)(*items)
+    _lib.check(lib.vf_allgather_scores_group(n, arr([e._handle for e in engines]), arr([P(c) for c in comms]),
+                                             arr([P(t.data_ptr()) for t in local]), 6,
+                                             arr([P(t.data_ptr()) for t in full]), arr([e._stream() for e in engines])))
+    want = np.concatenate([t.cpu().numpy() for t in local])
+    for e, t in zip(engines, full):
+        torch.cuda.synchronize(e.device)
+        np.testing.assert_array_equal(t.cpu().numpy(), want)
+    assert lib.vf_allgather_scores_group(n, None, None, None, 6, None, None) == -1
+    for c in comms:
+        assert lib.vf_comm_destroy(P(c)) == 0
+
+
+def test_failed_first_rollout_of_a_context_does_not_poison_the_shared_cache():
+    """A launch that is abandoned while it computes the context-only (batch-1) part of the network leaves those
+    shared buffers half-written.  Reading the status must drop that cache on both sides of the boundary, so the
+    retry with the SAME context recomputes it and equals a fresh engine - not finite scores from stale state."""
+    pred, ctx, actions = _small()
+    rs = np.random.RandomState(77)
+    new_ctx = dict(ctx, context_frames=rs.randint(0, 256, (2, 1, 32, 32, 3)).astype(np.uint8),
+                   context_states=rs.normal(0, 0.1, (2, 5)))
+    pred.score(ctx, {'actions': actions}, [[[3, 20]]])              # fills the cache for the OLD context
+    _lib.check(pred._libh.vf_debug_poison_status(pred._handle))
+    with pytest.raises(_lib.VfError, match='device status 1'):      # first rollout of the NEW context is abandoned
+        pred.score(new_ctx, {'actions': actions}, [[[3, 20]]])
+    assert pred.device_status() == 0                                 # (read and re-armed by the failed call)
+    retry, _ = pred.score(new_ctx, {'actions': actions}, [[[3, 20]]])
+    fresh, _, _ = _small()
+    want, _ = fresh.score(new_ctx, {'actions': actions}, [[[3, 20]]])
+    np.testing.assert_array_equal(retry, want)
+    # the raw C path: poison, roll (NaN), read the status, roll again without a new vf_set_context
+    _lib.check(pred._libh.vf_set_context(pred._handle, *[t.data_ptr() for t in pred._ctx], pred._stream()))
+    _lib.check(pred._libh.vf_debug_poison_status(pred._handle))
+    with torch.cuda.device(pred.device):
+        a = torch.from_numpy(actions.astype(np.float32)).to(pred.device)
+        sc = torch.zeros(len(actions), dtype=torch.float64, device=pred.device)
+        pt = torch.zeros((len(actions), 1), dtype=torch.float64, device=pred.device)
+        pred._rollout_chunk(a, [[[3, 20]]], 10., sc, pt)
+        assert torch.isnan(sc).all()
+        assert pred.device_status() == 1
+        pred._rollout_chunk(a, [[[3, 20]]], 10., sc, pt)
+        np.testing.assert_array_equal(sc.cpu().numpy(), want)

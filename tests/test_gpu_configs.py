@@ -235,9 +235,10 @@ def test_config4_shard_elites_match_oracle():
 
 
 # ---------------------------------------------------------------------------------------- config 5
-def test_config5_shard_latent_draws_128():
-    """One rank's share of configs[4] in one piece: 25 actions x 5 latent draws x horizon 15 x 128x128 on the
-    SAVP-class generator (savp_arch.py); the mean over draws is taken on the device."""
+def test_config5_fifth_of_a_shard_latent_draws_128():
+    """A fifth of one rank's share of configs[4] (the full share - 125 actions x 5 draws - is the next test):
+    25 actions x 5 latent draws x horizon 15 x 128x128 on the SAVP-class generator (savp_arch.py); the mean over
+    draws is taken on the device."""
     from oracle.savp_predictor import OracleSavp
     from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
     from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
@@ -279,3 +280,94 @@ def test_config5_shard_latent_draws_128():
     pred2 = StochasticHipPredictor('', dict(hp, run_batch_size=10)).restore(weights)
     np.testing.assert_array_equal(pred2.score(ctx, {'actions': actions}, goal)[0], scores)
     assert pred.device_status() == 0
+
+
+def test_config5_full_rank_share_625_sequences_elites_match_oracle():
+    """One rank's REAL share of configs[4]: 125 actions x 5 latent draws = 625 sequences x horizon 15 x 128x128 in
+    one launch (the batch size at which every conv-LSTM takes the 256-row tile plan), through
+    ``StochasticHipPredictor``.  Chunked into 25-action launches (128- and 64-row plans): the same bits.  The first
+    25 actions are a CEM sub-problem whose every sequence also goes through the CPU oracle: mean-over-draws scores
+    to 1e-5 and the identical K = 10 elite set, with a margin assert at the K / K+1 boundary.
+    Shapes: BASELINE.json configs[4]; latent repeats: reference samplers/gaussian_sampler.py:140-141."""
+    from oracle.savp_predictor import OracleSavp
+    from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
+    from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    H = W = 128
+    T, M, nl, zd, sub = 15, 125, 5, 8, 25
+    hp = dict(designated_pixel_count=1, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,
+              sequence_length=T + 2, n_latent=nl, zdim=zd, latent_seed=9)
+    pred = StochasticHipPredictor('', hp)
+    cfg = SavpConfig(height=H, width=W, adim=4 + zd, sdim=5, sequence_length=T + 2)
+    weights = CdnaWeights.random(cfg, seed=6, bias_scale=0.05, ln_jitter=0.1)
+    pred.restore(weights)
+    rs = np.random.RandomState(13)
+    ctx = {'context_frames': rs.randint(0, 256, (2, 1, H, W, 3)).astype(np.uint8),
+           'context_actions': rs.normal(0, 0.05, (1, 4)), 'context_states': rs.normal(0, 0.1, (2, 5)),
+           'context_pixel_distributions': pixel_cost.one_hot_distrib([[[64, 64]]], 2, 1, H, W, 1)}
+    actions = rs.normal(0, 0.1, (M, T, 4))
+    actions[100:] = actions[30:55]                         # duplicates outside the oracle's sub-problem
+    goal = np.array([[[32, 96]]])
+    z = pred.draw_latents(T)
+    scores, per_task = pred.score(ctx, {'actions': actions}, goal)
+    assert scores.shape == (M,) and np.isfinite(scores).all()
+    np.testing.assert_array_equal(scores[100:], scores[30:55])
+    np.testing.assert_array_equal(per_task[:, 0], scores)
+    best = pred.fetch_pixel_distributions(int(np.argmin(scores)))
+    np.testing.assert_allclose(best.sum(axis=(2, 3)), 1.0, atol=5e-6)
+    assert (best >= 0).all()
+    assert pred.device_status() == 0
+    # chunked: five launches of 25 actions = 125 sequences (another tile plan), same latent draws -> same bits
+    chunked = StochasticHipPredictor('', dict(hp, run_batch_size=sub)).restore(weights)
+    np.testing.assert_array_equal(chunked.score(ctx, {'actions': actions}, goal)[0], scores)
+    # the oracle on ALL sequences of the 25-action sub-problem
+    ctx_o = dict(ctx, context_actions=np.concatenate([ctx['context_actions'], np.zeros((1, zd))], axis=1))
+    aug = np.concatenate([np.repeat(actions[:sub], nl, axis=0), np.tile(z, (sub, 1, 1))], axis=2)
+    ora = OracleSavp(weights, torch.float32)
+    want_seq = []
+    for c0 in range(0, sub * nl, 25):
+        _, d, _ = ora.rollout(ctx_o['context_frames'], ctx_o['context_actions'], ctx_o['context_pixel_distributions'],
+                              ctx_o['context_states'], aug[c0:c0 + 25])
+        want_seq.append(pixel_cost.eval_pixel_cost(d, goal, 10.)[0])
+    want = np.concatenate(want_seq).reshape(sub, nl).mean(axis=1)
+    got = scores[:sub]
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+    gap = np.diff(np.sort(want))[9]
+    assert gap > 4 * np.abs(got - want).max(), 'fixture seeds give an ambiguous elite boundary'
+    np.testing.assert_array_equal(np.sort(np.argsort(got)[:10]), np.sort(np.argsort(want)[:10]))
+
+
+def test_config4_all_1000_samples_iteration0_elites_match_oracle():
+    """configs[3] at its full size: CEM iteration 0 of the planning call - all 1000 candidates the sampler draws,
+    horizon 15 - through the HIP predictor (five 200-sample launches) and through the CPU oracle: scores to 1e-5,
+    identical elite set of K = 10 with a margin assert (experiments/robonet/pixel_cost/hparams.py:31-42 pattern:
+    nactions = T, repeat 1, rejection_sampling False)."""
+    from visual_foresight_amd.policy.cem_controllers import PixelCostController
+    from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    M, T = 1000, 15
+    ag = {'adim': 4, 'sdim': 5, 'image_height': 64, 'image_width': 64}
+    pol = {'nactions': T, 'repeat': 1, 'rejection_sampling': False, 'verbose': False, 'num_samples': M,
+           'iterations': 1, 'predictor_class': HipVPredEvaluation}
+    frames = np.random.RandomState(1).randint(0, 256, (2, 1, 64, 64, 3)).astype(np.uint8)
+    states = np.random.RandomState(2).normal(0, .1, (2, 5))
+    with contextlib.redirect_stdout(io.StringIO()):
+        ctrl = PixelCostController(dict(ag), pol, 0, 1)
+        ctrl.reset()
+        rec = _Recorder(ctrl.predictor)
+        np.random.seed(0)
+        ctrl.act(t=0, i_tr=0, desig_pix=[[32, 32]], goal_pix=[[16, 48]], images=frames[:1], state=states[:1])
+        ctrl.act(t=1, i_tr=0, desig_pix=[[32, 32]], goal_pix=[[16, 48]], images=frames, state=states)
+    call = rec.calls[0]
+    assert call['actions'].shape == (M, T, 4) and ctrl.predictor.run_batch_size == 200
+    weights = ctrl.predictor.weights
+    want = []
+    for c0 in range(0, M, 125):
+        _, d, _ = _oracle_rollout(weights, call['context'], call['actions'][c0:c0 + 125])
+        want.append(pixel_cost.eval_pixel_cost(d, np.array([[[16, 48]]]), 10.)[0])
+    want = np.concatenate(want)
+    got = call['scores']
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+    gap = np.diff(np.sort(want))[9]
+    assert gap > 4 * np.abs(got - want).max(), 'fixture seeds give an ambiguous elite boundary'
+    np.testing.assert_array_equal(np.sort(ctrl._best_indices), np.sort(np.argsort(want)[:10]))

@@ -164,3 +164,27 @@ def test_savp_fused_top_at_128_matches_the_per_layer_launches():
     np.testing.assert_array_equal(out_fused['predicted_frames'], out_plain['predicted_frames'])
     np.testing.assert_array_equal(out_fused['predicted_pixel_distributions'], out_plain['predicted_pixel_distributions'])
     assert pred.device_status() == 0
+
+
+def test_savp_tile_plans_are_invisible_in_the_results():
+    """Arch 1 at 128x128 (64x64 conv-LSTM core): the same 160 sequences rolled as one batch (256-row tiles on the two
+    widest conv-LSTMs), in chunks of 70 (128-row tiles) and in chunks of 30 (64- / 32-row tiles) give identical bits
+    for scores and materialised predictions - the arch-1 counterpart of
+    test_gpu_parity.py::test_tile_plans_are_invisible_in_the_results (the all-256-row plan is covered at 625
+    sequences by test_gpu_configs.py::test_config5_full_rank_share_625_sequences_elites_match_oracle)."""
+    H = W = 128
+    T, M = 2, 160
+    rs = np.random.RandomState(27)
+    ctx = _context(H, W, 2, 6, rs)
+    actions = rs.normal(0, 0.1, (M, T, 6))
+    goal = np.array([[[13, 100], [90, 9]]])
+    outs = []
+    for bs in (M, 70, 30):
+        pred, _ = _predictor(H, W, T, 2, bs=bs)
+        s, pt = pred.score(ctx, {'actions': actions}, goal)
+        got = pred(ctx, {'actions': actions[:20]})
+        outs.append((s, pt, got['predicted_frames'], got['predicted_pixel_distributions']))
+        assert pred.device_status() == 0
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)

@@ -21,7 +21,8 @@ SOURCES = [os.path.join(_HERE, 'csrc', f) for f in
 # every symbol include/vf_hip.h declares
 EXPORTS = ('vf_abi_version', 'vf_last_error', 'vf_weight_count', 'vf_create', 'vf_destroy',
            'vf_load_weights', 'vf_set_context', 'vf_rollout', 'vf_export', 'vf_register',
-           'vf_allgather_scores', 'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile',
+           'vf_allgather_scores', 'vf_comm_init_all', 'vf_comm_destroy', 'vf_allgather_scores_group',
+           'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile',
            'vf_set_dedup', 'vf_set_persistent', 'vf_set_xcd_queues', 'vf_set_fuse_top', 'vf_device_status',
            'vf_set_phase_stats', 'vf_debug_phase_stats', 'vf_debug_poison_status')
 ABI_VERSION = 5
@@ -96,6 +97,10 @@ def load_library():
                                ctypes.POINTER(ctypes.c_float), P, P, P]
     lib.vf_register.argtypes = [P, P, P, P, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, P, P, P, P, P]
     lib.vf_allgather_scores.argtypes = [P, P, P, ctypes.c_int32, P, P]
+    lib.vf_comm_init_all.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(P)]
+    lib.vf_comm_destroy.argtypes = [P]
+    lib.vf_allgather_scores_group.argtypes = [ctypes.c_int32, ctypes.POINTER(P), ctypes.POINTER(P), ctypes.POINTER(P),
+                                              ctypes.c_int32, ctypes.POINTER(P), ctypes.POINTER(P)]
     lib.vf_set_phase_stats.argtypes = [P, ctypes.c_int32]
     lib.vf_debug_phase_stats.argtypes = [P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
                                          ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]
@@ -115,7 +120,8 @@ def load_library():
     lib.vf_set_persistent.restype = lib.vf_device_status.restype = ctypes.c_int
     lib.vf_set_profiling.restype = lib.vf_get_profile.restype = ctypes.c_int
     for name in ('vf_create', 'vf_destroy', 'vf_load_weights', 'vf_set_context', 'vf_rollout',
-                 'vf_export', 'vf_register', 'vf_allgather_scores', 'vf_set_phase_stats',
+                 'vf_export', 'vf_register', 'vf_allgather_scores', 'vf_comm_init_all', 'vf_comm_destroy',
+                 'vf_allgather_scores_group', 'vf_set_phase_stats',
                  'vf_debug_phase_stats', 'vf_debug_poison_status'):
         getattr(lib, name).restype = ctypes.c_int
     if lib.vf_abi_version() != ABI_VERSION:

@@ -455,10 +455,6 @@ struct vf_handle {
     size_t ev_used = 0;
     double prof_flops = 0.0;        // algorithmic FLOPs of the launches bracketed so far
 
-    // RCCL, bound lazily by vf_allgather_scores
-    void *rccl_lib = nullptr;
-    int (*nccl_all_gather)(const void *, void *, size_t, int, void *, void *) = nullptr;
-
 #ifdef VF_HOST_SELFTEST
     char *fake_base = nullptr;
     size_t fake_used = 0, fake_size = 0;
@@ -940,7 +936,6 @@ int vf_destroy(vf_handle *h) {
         if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
     }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-    if (h->rccl_lib) dlclose(h->rccl_lib);
 #endif
     delete h;
     return VF_OK;
@@ -1984,23 +1979,93 @@ int vf_register(vf_handle *h, const float *d_current, const float *d_reference, 
 }
 
 // RCCL is bound at first use (dlopen of the library the process already carries - PyTorch ships
-// its own librccl.so - or the system one), so libvf_hip.so itself has no link dependency on it.
+// its own librccl.so - or the system one), once per process, so libvf_hip.so itself has no link
+// dependency on it and communicators created through vf_comm_init_all are served by the same
+// library instance as the collectives.
+struct RcclApi {
+    void *lib = nullptr;
+    int (*all_gather)(const void *, void *, size_t, int, void *, void *) = nullptr;
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
+    int (*comm_init_all)(void **, int, const int *) = nullptr;
+    int (*comm_destroy)(void *) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int bind_rccl() {
+    if (g_rccl.all_gather) return VF_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *lib = nullptr;
+    for (const char *n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) return fail(VF_ERR_HIP, std::string("cannot load RCCL: ") + dlerror());
+    RcclApi api;
+    api.lib = lib;
+    api.all_gather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, void *)>(dlsym(lib, "ncclAllGather"));
+    api.group_start = reinterpret_cast<int (*)()>(dlsym(lib, "ncclGroupStart"));
+    api.group_end = reinterpret_cast<int (*)()>(dlsym(lib, "ncclGroupEnd"));
+    api.comm_init_all = reinterpret_cast<int (*)(void **, int, const int *)>(dlsym(lib, "ncclCommInitAll"));
+    api.comm_destroy = reinterpret_cast<int (*)(void *)>(dlsym(lib, "ncclCommDestroy"));
+    if (!api.all_gather || !api.group_start || !api.group_end || !api.comm_init_all || !api.comm_destroy)
+        return fail(VF_ERR_HIP, "the RCCL library lacks ncclAllGather / ncclGroup* / ncclCommInitAll / ncclCommDestroy");
+    g_rccl = api;       // (the library stays loaded for the life of the process)
+    return VF_OK;
+}
+
+static const int kNcclFloat64 = 8;      // ncclFloat64 in nccl.h
+
 int vf_allgather_scores(vf_handle *h, void *nccl_comm, const double *d_local, int32_t n_local, double *d_all,
                         void *stream) {
     if (!h || !nccl_comm || !d_local || !d_all || n_local < 1) return fail(VF_ERR_INVALID, "null or empty argument");
-    if (!h->nccl_all_gather) {
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char *n : names)
-            if ((h->rccl_lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!h->rccl_lib) return fail(VF_ERR_HIP, std::string("cannot load RCCL: ") + dlerror());
-        h->nccl_all_gather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, void *)>(
-            dlsym(h->rccl_lib, "ncclAllGather"));
-        if (!h->nccl_all_gather) return fail(VF_ERR_HIP, "ncclAllGather not found in the RCCL library");
-    }
+    int rc = bind_rccl();
+    if (rc) return rc;
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
-    const int nccl_float64 = 8;     // ncclFloat64 in nccl.h
-    const int rc = h->nccl_all_gather(d_local, d_all, (size_t)n_local, nccl_float64, nccl_comm, stream);
+    rc = g_rccl.all_gather(d_local, d_all, (size_t)n_local, kNcclFloat64, nccl_comm, stream);
     if (rc != 0) return fail(VF_ERR_HIP, "ncclAllGather failed with ncclResult_t " + std::to_string(rc));
+    return VF_OK;
+}
+
+int vf_comm_init_all(int32_t n, const int32_t *devices, void **comms) {
+    if (n < 1 || !devices || !comms) return fail(VF_ERR_INVALID, "null or empty argument");
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (devices[i] == devices[j])
+                return fail(VF_ERR_INVALID, "vf_comm_init_all: device " + std::to_string(devices[i]) +
+                                                " listed twice (one communicator rank per GPU)");
+    int rc = bind_rccl();
+    if (rc) return rc;
+    std::vector<int> devs(devices, devices + n);
+    rc = g_rccl.comm_init_all(comms, n, devs.data());
+    if (rc != 0) return fail(VF_ERR_HIP, "ncclCommInitAll failed with ncclResult_t " + std::to_string(rc));
+    return VF_OK;
+}
+
+int vf_comm_destroy(void *comm) {
+    if (!comm) return VF_OK;
+    int rc = bind_rccl();
+    if (rc) return rc;
+    rc = g_rccl.comm_destroy(comm);
+    if (rc != 0) return fail(VF_ERR_HIP, "ncclCommDestroy failed with ncclResult_t " + std::to_string(rc));
+    return VF_OK;
+}
+
+int vf_allgather_scores_group(int32_t n, vf_handle *const *hs, void *const *comms, const double *const *d_local,
+                              int32_t n_local, double *const *d_all, void *const *streams) {
+    if (n < 1 || !hs || !comms || !d_local || !d_all || n_local < 1) return fail(VF_ERR_INVALID, "null or empty argument");
+    for (int i = 0; i < n; ++i)
+        if (!hs[i] || !comms[i] || !d_local[i] || !d_all[i]) return fail(VF_ERR_INVALID, "null entry " + std::to_string(i));
+    int rc = bind_rccl();
+    if (rc) return rc;
+    if ((rc = g_rccl.group_start()) != 0) return fail(VF_ERR_HIP, "ncclGroupStart failed with ncclResult_t " + std::to_string(rc));
+    int first_bad = 0;
+    for (int i = 0; i < n && !first_bad; ++i) {
+        if (hipSetDevice(hs[i]->cfg.device) != hipSuccess) { first_bad = -1; break; }
+        first_bad = g_rccl.all_gather(d_local[i], d_all[i], (size_t)n_local, kNcclFloat64, comms[i],
+                                      streams ? streams[i] : nullptr);
+    }
+    rc = g_rccl.group_end();        // always closes the group
+    if (first_bad) return fail(VF_ERR_HIP, "grouped ncclAllGather failed (" + std::to_string(first_bad) + ")");
+    if (rc != 0) return fail(VF_ERR_HIP, "ncclGroupEnd failed with ncclResult_t " + std::to_string(rc));
     return VF_OK;
 }
 

@@ -26,7 +26,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from visual_foresight_amd.video_prediction.cdna_arch import CdnaWeights, tensor_shapes
+from visual_foresight_amd.video_prediction.cdna_arch import CdnaWeights
 
 _CONV = {'enc0': 'scale1_conv1', 'enc1': 'conv2', 'enc2': 'conv3', 'enc3': 'conv4'}
 _CONVT = {'convt1': 'convt1', 'convt2': 'convt2', 'convt3': 'convt3', 'rgb': 'convt4', 'masks': 'convt7'}
@@ -58,13 +58,35 @@ def match_suffix(wanted, available):
     raise ValueError('did not find variable %s' % wanted)
 
 
-def import_named_arrays(arrays, cfg):
-    """``arrays``: mapping checkpoint-variable-name -> ndarray (e.g. an open ``np.load(...npz)``)."""
+# convolutions that are followed by a LayerNorm: TF-slim builds those WITHOUT a bias variable
+# (``use_bias = not normalizer_fn`` when ``normalizer_fn=layer_norm``), so a real checkpoint dump has no
+# ``<scope>/biases`` for them; the LayerNorm's beta plays that role
+_BIAS_OPTIONAL = ('enc0/b', 'convt3/b')
+
+
+def import_named_arrays(arrays, cfg, log=None):
+    """``arrays``: mapping checkpoint-variable-name -> ndarray (e.g. an open ``np.load(...npz)``).
+
+    Only the CDNA architecture (``CdnaConfig``) has a TensorFlow name table; a ``SavpConfig`` is refused.
+    A missing bias of a LayerNorm-followed convolution (``_BIAS_OPTIONAL``) is filled with zeros and reported
+    through ``log`` (a callable taking one string; default: print)."""
+    if getattr(cfg, 'arch_id', 0) != 0:
+        raise ValueError("only arch 'cdna' checkpoints can be imported (no TensorFlow name table for %s)"
+                         % type(cfg).__name__)
+    log = log or print
     names = list(arrays.keys())
     tensors = OrderedDict()
-    for name, shape in tensor_shapes(cfg).items():
+    for name, shape in cfg.tensor_shapes().items():
         suffix, transposed = tf_name(name)
-        arr = np.asarray(arrays[match_suffix(suffix, names)], dtype=np.float32)
+        try:
+            found = match_suffix(suffix, names)
+        except ValueError:
+            if name not in _BIAS_OPTIONAL:
+                raise
+            log('checkpoint has no %s (convolution built with a normalizer): %s set to zeros' % (suffix, name))
+            tensors[name] = np.zeros(shape, np.float32)
+            continue
+        arr = np.asarray(arrays[found], dtype=np.float32)
         if transposed:                                  # conv2d_transpose: [kh, kw, cout, cin] -> [kh, kw, cin, cout]
             arr = arr.transpose(0, 1, 3, 2)
         if tuple(arr.shape) != tuple(shape):
@@ -94,7 +116,7 @@ def convert_npz(npz_path, model_dir, cfg):
 if __name__ == '__main__':
     import argparse
     from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig
-    ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
+    ap = argparse.ArgumentParser(description=__doc__.split('\n')[0] + "  (arch 'cdna' only)")
     ap.add_argument('npz')
     ap.add_argument('model_dir')
     for k, d in (('height', 64), ('width', 64), ('adim', 4), ('sdim', 5)):

@@ -21,6 +21,16 @@ initialised (rank r evaluates samples ``[r*M/G, (r+1)*M/G)``; reference tower sl
 (RCCL) - the reference instead concatenates full predicted videos on the host
 (``setup_predictor.py:155-162``).
 
+``n_gpus`` / ``first_gpu`` mean what they mean in the reference (``setup_predictor.py:70,117-123``: ``ngpu``
+towers on devices ``gpu_id ..`` inside the ONE policy process that ``sim/run.py:79-82`` creates): outside
+``torch.distributed``, ``n_gpus > 1`` builds one engine per device ``first_gpu .. first_gpu + n_gpus - 1``
+("lanes"), one host thread enqueues every lane's contiguous shard on its device's stream - rank-LOCAL slice
+offsets, not the reference's ``gpu_id * nsmp_per_gpu`` (``setup_predictor.py:38``), which over-runs the batch
+when ``first_gpu != 0`` - and the score rows are gathered with one grouped RCCL all-gather
+(``vf_comm_init_all`` + ``vf_allgather_scores_group``) or, when the lanes share a device (hyper-parameter
+``oversubscribe_gpus``, tests on a one-GPU box), through the host.  Under ``torch.distributed`` every rank
+drives one GPU and ``n_gpus`` must be 1 or the world size.
+
 PyTorch is the buffer carrier only: tensors own the device memory whose pointers cross the
 C ABI of ``include/vf_hip.h``; all arithmetic runs in ``libvf_hip.so``.
 """
@@ -43,6 +53,7 @@ class HipVPredEvaluation(object):
     def __init__(self, model_path, hparams, n_gpus=1, first_gpu=0):
         import torch
         self._torch = torch
+        self._lanes = self._comms = None        # in-process multi-GPU lanes (below), their RCCL communicators
         hp = dict(hparams)
         if isinstance(model_path, (list, tuple)):
             self.model_path = [os.path.expanduser(p) for p in model_path]
@@ -65,9 +76,21 @@ class HipVPredEvaluation(object):
                            sequence_length=self.sequence_length)
         if not torch.cuda.is_available():
             raise _lib.VfError('HipVPredEvaluation needs a ROCm GPU (no CPU fallback)')
-        # one process drives one GPU; under torchrun LOCAL_RANK picks it
-        local_rank = int(os.environ.get('LOCAL_RANK', 0)) if _dist_info()[1] > 1 else 0
-        self.device_index = (int(first_gpu) + local_rank) % max(torch.cuda.device_count(), 1)
+        world = _dist_info()[1]
+        self.n_gpus = int(n_gpus)
+        n_dev = max(torch.cuda.device_count(), 1)
+        if self.n_gpus < 1:
+            raise ValueError('n_gpus must be >= 1, got %r' % (n_gpus,))
+        if world > 1 and self.n_gpus not in (1, world):
+            raise ValueError('under torch.distributed every rank drives one GPU: n_gpus must be 1 or the world size '
+                             '(%d), got %d' % (world, self.n_gpus))
+        oversubscribe = bool(int(hp.get('oversubscribe_gpus', os.environ.get('VF_OVERSUBSCRIBE_GPUS', 0))))
+        if world == 1 and self.n_gpus > n_dev and not oversubscribe:
+            raise ValueError('n_gpus=%d but this host exposes %d GPU(s) (set the predictor hyper-parameter '
+                             "'oversubscribe_gpus' to let the lanes share devices)" % (self.n_gpus, n_dev))
+        # under torchrun LOCAL_RANK picks this rank's GPU; the lanes of the in-process mode follow first_gpu
+        local_rank = int(os.environ.get('LOCAL_RANK', 0)) if world > 1 else 0
+        self.device_index = (int(first_gpu) + local_rank) % n_dev
         self.device = torch.device('cuda', self.device_index)
         self._libh = _lib.load_library()
         c = self.cfg
@@ -92,10 +115,27 @@ class HipVPredEvaluation(object):
         self._ctx_key = None
         self._last_M = 0
         self._last_lo = 0
-        self._scores_dev = None
+        # in-process multi-GPU: this object is lane 0, the others are plain engines on the following devices
+        self.gather = str(hp.get('gather', 'auto'))         # 'auto' | 'rccl' | 'host'
+        if self.gather not in ('auto', 'rccl', 'host'):
+            raise ValueError("gather must be 'auto', 'rccl' or 'host'")
+        if world == 1 and self.n_gpus > 1 and not hp.get('_lane'):
+            lane_hp = dict(hp, _lane=True, oversubscribe_gpus=1)
+            self._lanes = [self] + [HipVPredEvaluation(model_path, lane_hp, n_gpus=1, first_gpu=int(first_gpu) + i)
+                                    for i in range(1, self.n_gpus)]
+            distinct = len({l.device_index for l in self._lanes}) == self.n_gpus
+            if self.gather == 'rccl' and not distinct:
+                raise ValueError("gather='rccl' needs one distinct GPU per lane")
+            self._use_rccl = distinct if self.gather == 'auto' else self.gather == 'rccl'
+
+    def _all_lanes(self):
+        return self._lanes if self._lanes else [self]
 
     def __del__(self):
         try:
+            for comm in (getattr(self, '_comms', None) or []):
+                self._libh.vf_comm_destroy(comm)
+            self._comms = None
             if getattr(self, '_handle', None) and self._handle.value:
                 self._libh.vf_destroy(self._handle)
                 self._handle = ctypes.c_void_p()
@@ -115,36 +155,44 @@ class HipVPredEvaluation(object):
 
     def set_persistent(self, enable):
         """Run each rollout as one persistent launch (bit-identical results; see vf_persistent.h)."""
-        _lib.check(self._libh.vf_set_persistent(self._handle, int(bool(enable))))
-        self.persistent = bool(enable)
+        for lane in self._all_lanes():
+            _lib.check(lane._libh.vf_set_persistent(lane._handle, int(bool(enable))))
+            lane.persistent = bool(enable)
 
     def set_xcd_queues(self, enable):
         """One ticket queue per XCD (default) or plain phase order; placement only, bit-identical results."""
-        _lib.check(self._libh.vf_set_xcd_queues(self._handle, int(bool(enable))))
-        self.xcd_queues = bool(enable)
+        for lane in self._all_lanes():
+            _lib.check(lane._libh.vf_set_xcd_queues(lane._handle, int(bool(enable))))
+            lane.xcd_queues = bool(enable)
 
     def set_fuse_top(self, enable):
         """Top transposed conv + compositing as one item per tile (vf_set_fuse_top); bit-identical results."""
-        _lib.check(self._libh.vf_set_fuse_top(self._handle, int(bool(enable))))
-        self.fuse_top = bool(enable)
+        for lane in self._all_lanes():
+            _lib.check(lane._libh.vf_set_fuse_top(lane._handle, int(bool(enable))))
+            lane.fuse_top = bool(enable)
 
     def device_status(self):
         """Synchronise, return the sticky failure word of the persistent kernel (0 = healthy), re-arm it."""
-        st = ctypes.c_int32()
-        _lib.check(self._libh.vf_device_status(self._handle, ctypes.byref(st)))
-        return st.value
+        worst = 0
+        for lane in self._all_lanes():
+            st = ctypes.c_int32()
+            _lib.check(lane._libh.vf_device_status(lane._handle, ctypes.byref(st)))
+            worst = max(worst, st.value)
+        return worst
 
     def _check_scores(self, scores_np):
         """A rollout whose tiles gave up waiting poisons its scores with NaN (vf_hip.h): never hand
         them to the elite selection."""
         if np.isnan(scores_np).any():
-            self._ctx_key = None    # the engine drops its context-only cache with the status: upload the context again
+            for lane in self._all_lanes():      # the engine drops its context-only cache with the status:
+                lane._ctx_key = None            # upload the context again
             raise _lib.VfError('the persistent rollout kernel reported a failure (device status %d): a tile gave '
                                'up waiting for its producers; scores are invalid' % self.device_status())
 
     def set_dedup(self, enable):
         """Switch context de-duplication (bit-identical results either way; for A/B timing)."""
-        _lib.check(self._libh.vf_set_dedup(self._handle, int(bool(enable))))
+        for lane in self._all_lanes():
+            _lib.check(lane._libh.vf_set_dedup(lane._handle, int(bool(enable))))
 
     # ------------------------------------------------------------------ weights
     def restore(self, weights=None):
@@ -170,6 +218,8 @@ class HipVPredEvaluation(object):
             raise _lib.VfError('weight blob has %d floats, library expects %d' % (blob.size, want))
         _lib.check(self._libh.vf_load_weights(self._handle, blob.ctypes.data_as(ctypes.c_void_p),
                                               blob.size))
+        for lane in (self._lanes or [])[1:]:        # the weights are replicated on every lane's device
+            lane.restore(list(weights))
         return self
 
     # ------------------------------------------------------------------ context
@@ -246,11 +296,15 @@ class HipVPredEvaluation(object):
 
         ``index_base`` is the global index of ``actions[0]`` (what ``fetch_pixel_distributions`` is asked for).
         """
+        context, seqs = self._prepare(context, actions)
+        return self._score_prepared(context, seqs, actions.shape[0], goal_pix, finalweight, index_base, task_weights)
+
+    def _score_prepared(self, context, seqs, n, goal_pix, finalweight, index_base=0, task_weights=None):
+        """Engine half of ``_score_device``: ``seqs [n * n_draws, T, engine adim]`` as ``_prepare`` returns them.
+        Only enqueues work on this engine's device (the uploads of pageable host arrays aside)."""
         torch = self._torch
         ntask = self.n_cam * self.cfg.ndesig
         nd = self.n_draws
-        n = actions.shape[0]
-        context, seqs = self._prepare(context, actions)
         self._set_context(context)
         local = torch.from_numpy(np.ascontiguousarray(seqs, dtype=np.float32)).to(self.device)
         scores = torch.empty(n, dtype=torch.float64, device=self.device)
@@ -274,6 +328,13 @@ class HipVPredEvaluation(object):
         actions = self._check_actions(inputs['actions'])
         M = actions.shape[0]
         rank, world = _dist_info()
+        if self._lanes:
+            scores_np, per_task_np = self._score_lanes(context, actions, goal_pix, finalweight, task_weights)
+            self._check_scores(scores_np)
+            if only_take_first_view:
+                per_task_np = per_task_np[:, :1]
+                scores_np = per_task_np[:, 0].copy()
+            return scores_np, per_task_np
         lo, hi = shard_bounds(M, rank, world)
         with self._torch.cuda.device(self.device):
             scores, per_task = self._score_device(context, actions[lo:hi], goal_pix, finalweight, index_base=lo,
@@ -288,6 +349,57 @@ class HipVPredEvaluation(object):
             scores_np = per_task_np[:, 0].copy()
         return scores_np, per_task_np
 
+    # ------------------------------------------------------------------ in-process multi-GPU (n_gpus > 1)
+    def _score_lanes(self, context, actions, goal_pix, finalweight, task_weights):
+        """Lane i rolls the contiguous shard ``shard_bounds(M, i, n_gpus)`` on its own device; every lane's work is
+        enqueued before anything is waited for, then one gather of the ``[M, 1 + tasks]`` score rows."""
+        torch = self._torch
+        lanes, M, nd = self._lanes, actions.shape[0], self.n_draws
+        context, seqs = self._prepare(context, actions)
+        packed = []
+        for i, lane in enumerate(lanes):
+            lo, hi = shard_bounds(M, i, len(lanes))
+            with torch.cuda.device(lane.device):
+                if hi > lo:
+                    s, pt = lane._score_prepared(context, seqs[lo * nd:hi * nd], hi - lo, goal_pix, finalweight,
+                                                 index_base=lo, task_weights=task_weights)
+                    packed.append(torch.cat([s[:, None], pt], dim=1).contiguous())
+                else:
+                    lane._last_lo, lane._last_M = lo, 0
+                    packed.append(torch.empty((0, 1 + self.n_cam * self.cfg.ndesig), dtype=torch.float64,
+                                              device=lane.device))
+        rows = self._gather_rccl(packed, M) if self._use_rccl else \
+            np.concatenate([p.cpu().numpy() for p in packed], axis=0)
+        return np.ascontiguousarray(rows[:, 0]), np.ascontiguousarray(rows[:, 1:])
+
+    def _gather_rccl(self, packed, M):
+        """One grouped RCCL all-gather over the lanes' devices (padded to equal rows); lane 0's copy goes to the host."""
+        torch, n = self._torch, len(self._lanes)
+        P = ctypes.c_void_p
+        if self._comms is None:
+            devs = (ctypes.c_int32 * n)(*[l.device_index for l in self._lanes])
+            comms = (P * n)()
+            _lib.check(self._libh.vf_comm_init_all(n, devs, comms))
+            self._comms = [P(c) for c in comms]
+        sizes = [p.shape[0] for p in packed]
+        width, cols = max(sizes), packed[0].shape[1]
+        local, full = [], []
+        for lane, p in zip(self._lanes, packed):
+            with torch.cuda.device(lane.device):
+                buf = torch.zeros((width, cols), dtype=torch.float64, device=lane.device)
+                buf[:p.shape[0]] = p
+                local.append(buf)
+                full.append(torch.empty((n * width, cols), dtype=torch.float64, device=lane.device))
+        arr = lambda items: (P * n)(*items)
+        _lib.check(self._libh.vf_allgather_scores_group(
+            n, arr([l._handle for l in self._lanes]), arr(self._comms), arr([P(t.data_ptr()) for t in local]),
+            width * cols, arr([P(t.data_ptr()) for t in full]), arr([l._stream() for l in self._lanes])))
+        with torch.cuda.device(self.device):
+            out = full[0].cpu().numpy().reshape(n, width, cols)
+        for lane in self._lanes[1:]:        # every lane's collective has completed before its buffers are released
+            torch.cuda.synchronize(lane.device)
+        return np.concatenate([out[i, :sizes[i]] for i in range(n)], axis=0)
+
     def _all_gather(self, scores, per_task, M, world):
         """One collective: every rank's [score | per-task scores] rows -> all M rows on every rank."""
         packed = self._torch.cat([scores[:, None], per_task], dim=1).contiguous()
@@ -301,6 +413,9 @@ class HipVPredEvaluation(object):
         torch, c = self._torch, self.cfg
         T = self.sequence_length - self.n_context
         rank, world = _dist_info()
+        for lane in (self._lanes or [])[1:]:        # in-process multi-GPU: the lane that rolled it exports it
+            if 0 <= sample_index - lane._last_lo < lane._last_M:
+                return lane.fetch_pixel_distributions(sample_index)
         local = sample_index - self._last_lo
         have = 0 <= local < self._last_M
         out = torch.zeros((T, self.n_cam, c.height, c.width, c.ndesig), dtype=torch.float32, device=self.device)
@@ -310,12 +425,19 @@ class HipVPredEvaluation(object):
                                                 None, self._stream()))
         if world > 1:
             import torch.distributed as dist
+            # the "somebody holds it" flag travels with the data (one extra element), so a sample no rank has
+            # resident - an index out of range, or a shard larger than run_batch_size - raises on EVERY rank instead
+            # of handing all-zero distributions to the propagation
+            flat = torch.cat([out.reshape(-1), torch.tensor([1.0 if have else 0.0], device=self.device)])
             if dist.get_backend() == 'gloo':
-                host = out.cpu()
+                host = flat.cpu()
                 dist.all_reduce(host)
-                out = host.to(self.device)
+                flat = host.to(self.device)
             else:
-                dist.all_reduce(out)    # exactly one rank holds the sample, the others add zeros
+                dist.all_reduce(flat)   # exactly one rank holds the sample, the others add zeros
+            if float(flat[-1].item()) < 0.5:
+                raise IndexError('sample %d is not resident on any rank' % sample_index)
+            out = flat[:-1].reshape(out.shape)
         elif not have:
             raise IndexError('sample %d is not resident (last chunk holds [%d, %d))'
                              % (sample_index, self._last_lo, self._last_lo + self._last_M))
@@ -403,9 +525,21 @@ class HipVPredEvaluation(object):
     def __call__(self, context, inputs):
         """Reference-compatible path: materialise all predicted frames and distributions on the host
         (``[M, T, ncam, H, W, C]``; with latent draws, the first draw of every action)."""
-        torch, c = self._torch, self.cfg
         actions = self._check_actions(inputs['actions'])
-        M, T = actions.shape[:2]
+        context, seqs = self._prepare(context, actions)
+        if self._lanes:     # lane i materialises its contiguous shard (one lane after the other: the D2H dominates)
+            M, n, nd = actions.shape[0], len(self._lanes), self.n_draws
+            parts = []
+            for i, lane in enumerate(self._lanes):
+                lo, hi = shard_bounds(M, i, n)
+                if hi > lo:
+                    parts.append(lane._materialise(context, seqs[lo * nd:hi * nd], hi - lo, lo))
+            return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+        return self._materialise(context, seqs, actions.shape[0], 0)
+
+    def _materialise(self, context, seqs, M, index_base):
+        torch, c = self._torch, self.cfg
+        T = self.sequence_length - self.n_context
         ncam, nd = self.n_cam, self.n_draws
         frames = np.empty((M, T, ncam, c.height, c.width, 3), np.float32)
         distrib = np.empty((M, T, ncam, c.height, c.width, c.ndesig), np.float32)
@@ -413,7 +547,6 @@ class HipVPredEvaluation(object):
         zero_goal = np.zeros((ncam, c.ndesig, 2), np.int32)
         bs = self.run_batch_size // nd
         with torch.cuda.device(self.device):
-            context, seqs = self._prepare(context, actions)
             self._set_context(context)
             acts = torch.from_numpy(np.ascontiguousarray(seqs, dtype=np.float32)).to(self.device)
             scores = torch.empty(bs, dtype=torch.float64, device=self.device)
@@ -422,7 +555,7 @@ class HipVPredEvaluation(object):
                 c1 = min(c0 + bs, M)
                 n = c1 - c0
                 self._rollout_chunk(acts[c0 * nd:c1 * nd], zero_goal, 1.0, scores[:n], per_task[:n])
-                self._last_lo, self._last_M = c0, n
+                self._last_lo, self._last_M = index_base + c0, n
                 f = torch.empty((n * nd, T, ncam, c.height, c.width, 3), dtype=torch.float32, device=self.device)
                 d = torch.empty((n * nd, T, ncam, c.height, c.width, c.ndesig), dtype=torch.float32,
                                 device=self.device)
