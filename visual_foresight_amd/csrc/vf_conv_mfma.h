@@ -34,6 +34,10 @@
 #define VF_LAUNCH_BOUNDS(...) __launch_bounds__(__VA_ARGS__)
 #endif
 
+#ifndef VF_RING_RB2
+#define VF_RING_RB2 0
+#endif
+
 namespace vf {
 
 #ifdef VF_TILE_STATS
@@ -114,7 +118,60 @@ struct ConvParams {
     int *fuse_ready;
     const int *fuse_status;
     int fuse_view, fuse_nd;
+    // EPI_LSTM inside the persistent launch: "early start".  seg[0] is the RECURRENT input h(s-1), seg[1] the layer
+    // input x(s).  The item is released as soon as h(s-1) exists, runs the recurrent chunks, and only then waits
+    // for the producer of x (completion counters late_cnt: one per sample, or counter 0 when late_mode = 1, done at
+    // late_expect) - the wait that used to idle the slot in front of the item now overlaps half of its K loop.
+    // null: every input is complete at entry (per-layer launches).
+    const int *late_cnt;
+    int late_expect, late_mode;
+    int *late_status;       // the launch's sticky failure word
 };
+
+constexpr unsigned kLateSpinLimit = 1u << 26;   // polls before a mid-item wait gives up (as kSpinLimit)
+
+// Mid-item wait of a conv-LSTM tile for the producer of its layer input (samples [b0, b1)).  One wave polls
+// (relaxed agent-scope loads, s_sleep), acquires, and the result crosses the workgroup through `flag` (LDS).
+// Returns false - uniformly - when the producer never arrived: the launch's status word is raised and word 1 of
+// the persistent kernel's LDS control block tells its scheduler loop not to publish this item.
+template <class PT>
+__device__ __forceinline__ bool late_wait(const PT &p, const int b0, const int b1, int *flag) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) {
+        unsigned spins = 0;
+        bool ok;
+        do {
+            ok = true;
+            if (p.late_mode == 1) {
+                if (lane == 0)
+                    ok = __hip_atomic_load(p.late_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.late_expect;
+            } else {
+                for (int b = b0 + lane; b < b1; b += 64)
+                    ok = ok && (__hip_atomic_load(p.late_cnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.late_expect);
+            }
+            ok = __all(ok);
+            if (!ok) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > kLateSpinLimit ||
+                    __hip_atomic_load(p.late_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    if (lane == 0) {
+                        extern __shared__ __attribute__((aligned(16))) float smem_all[];
+                        atomicExch(p.late_status, 1);
+                        reinterpret_cast<int *>(smem_all)[1] = 0;
+                    }
+                    break;
+                }
+            }
+        } while (!ok);
+        if (lane == 0) {
+            *flag = ok ? 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
@@ -413,7 +470,13 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     // lose more to its per-tap barrier than they gain, so they read B straight from L1/L2
     // (the 256-row conv-LSTM tile reads B directly as well: its input tile needs the LDS, and it must keep the
     // 32-channel chunks of the 128-row tile so that both plans accumulate every output in the same K order)
-    constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1;
+    constexpr bool kBRing = SPLIT && (RB == 1 || VF_RING_RB2);
+    constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1 && !kBRing;
+    // Row-split tiles (32 / 64 rows): a wave only multiplies ITS gates' weight slice, so staging B through LDS
+    // shares nothing (RB 1) or one pair of waves (RB 2) and costs a barrier per tap, while a tap's MFMAs
+    // (16 / 32 per wave) are too short to cover the L2 latency of a one-tap look-ahead.  They read B straight
+    // from L2 into a register ring of one kernel ROW (5 taps x K8 x GA float4): every load is issued five taps
+    // before its use, there is no barrier inside a chunk, and the K order is unchanged (same bits).
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     const int wrow0 = SPLIT ? (wave % RB) * 32 : wave * WROWS;     // first GEMM row of this wave
@@ -441,8 +504,11 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     [[maybe_unused]] const unsigned long long ts0 = VF_TS_NOW();
     [[maybe_unused]] unsigned long long ts1 = 0, ts_stage = 0;
     [[maybe_unused]] const int ts_key = (((p.seg[0].C + (p.nseg > 1 ? p.seg[1].C : 0)) >> 5) & 7) + (p.Hout >= 32 ? 0 : 8);
-    // ---- LayerNorm statistics of the producing layers (this workgroup's samples only)
-    ln_table(p, bimg0, lnTab);
+    // ---- LayerNorm statistics of the producing layers (this workgroup's samples only); an early-started conv-LSTM
+    // item reads them only once the producer of its layer input is known to be done (chunk loop below)
+    bool late = false;
+    if constexpr (EPI == EPI_LSTM) late = p.late_cnt != nullptr;
+    if (!late) ln_table(p, bimg0, lnTab);
 
     // ---- this lane's A rows (GEMM rows wave*WROWS + m*32 + n)
     const int px_per_img = p.TH * p.TW;
@@ -495,6 +561,20 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     if constexpr (kBLds) {
         if (gt0 < gtN) { VF_LOADB(gt0) }
     }
+    constexpr int kRing = 5;                // taps in flight = one row of the 5x5 kernel
+    [[maybe_unused]] f32x4 bring[kBRing ? kRing : 1][kBRing ? 4 : 1][GA];
+    [[maybe_unused]] const float *wring = p.Wp + ((long long)kh * Ntot + (cg * G + gbase) * 32 + n) * 4;
+#define VF_LOADRING(SLOT_, GT_)                                                                 \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                            \
+        _Pragma("unroll") for (int g_ = 0; g_ < GA; ++g_)                                       \
+            bring[SLOT_][q_][g_] = *reinterpret_cast<const f32x4 *>(                            \
+                wring + ((long long)(GT_) * 4 + q_) * wstep + g_ * 128);
+    if constexpr (kBRing) {
+        // (the split plans exist for 5x5 kernels with 32-channel chunks only: half_ok / quarter_ok in vf_engine.hip)
+#pragma unroll
+        for (int d = 0; d < kRing; ++d)
+            if (gt0 + d < gtN) { VF_LOADRING(d, gt0 + d) }
+    }
 
     // Wave priority: everything that is NOT a conv-LSTM K loop - the light tiles, the prologues and epilogues - is a
     // latency chain that others wait for; it runs at priority 2 (set by the persistent kernel) and the long matrix
@@ -506,6 +586,13 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
         const int c0 = (s == 0 ? ci : ci - p.seg[0].nchunk) * KC;
         const bool vec_ok = (sg.C & 3) == 0;
 
+        if constexpr (EPI == EPI_LSTM) {
+            if (late && ci == p.seg[0].nchunk) {     // the recurrent chunks are done: now the layer input is needed
+                const int b1 = p.NI == 1 ? bimg0 + 1 : min(bimg0 + p.NI, p.B);
+                if (!late_wait(p, bimg0, b1, reinterpret_cast<int *>(red))) return;
+                ln_table(p, bimg0, lnTab);
+            }
+        }
         __syncthreads();        // previous chunk fully consumed (and lnTab visible on entry)
         [[maybe_unused]] const unsigned long long ts_s0 = VF_TS_NOW();
         // kConvThreads is a multiple of q4, so a thread stages the same channel quad of every pixel it visits: its
@@ -618,6 +705,33 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
                 }
             }
 #undef VF_FETCH_L
+        } else if constexpr (kBRing) {
+            // ---- K loop of the row-split tiles: B from the register ring, A double-buffered from LDS, no barrier
+            f32x4 aC[4], aN[4];
+            const int a0 = ab4[0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) aC[q] = smem4[a0 + q * 2];
+            for (int ky = 0; ky < 5; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < kRing; ++kx) {
+                    const int gt = ci * ntaps + ky * 5 + kx;
+                    // A of the next tap of this chunk (the last tap re-reads its own: harmless, no branch)
+                    const int kyn = kx == 4 ? min(ky + 1, 4) : ky, kxn = kx == 4 ? (ky == 4 ? 4 : 0) : kx + 1;
+                    const int aon = (kyn * LW + kxn) * kcp4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) aN[q] = smem4[a0 + aon + q * 2];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int g = 0; g < GA; ++g)
+                                acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(aC[q][j], bring[kx][q][g][j], acc[0][g], 0, 0, 0);
+                    if (gt + kRing < gtN) { VF_LOADRING(kx, gt + kRing) }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) aC[q] = aN[q];
+                }
+            }
         } else {
             // ---- K loop over (tap, k8), software pipelined: operands of step it+1 are fetched
             // (A: LDS b128, B: L1/L2 b128) before the MFMAs of step it are issued.
@@ -678,6 +792,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     }
 #undef VF_LOADB
 #undef VF_WRITEB
+#undef VF_LOADRING
 
     if constexpr (EPI == EPI_LSTM) __builtin_amdgcn_s_setprio(2);
     [[maybe_unused]] const unsigned long long ts2 = VF_TS_NOW();

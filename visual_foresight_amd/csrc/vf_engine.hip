@@ -146,6 +146,9 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
     int Hin, Win, Hout, Wout;       // Hout/Wout: GEMM row grid
     int KH, KW, stride, pad;        // kernel geometry as the GEMM sees it
     int segC[2], nseg;
+    int seg_off[2];                 // first canonical input channel of each segment (conv-LSTM: seg 0 is the
+                                    // recurrent input h, which sits BEHIND the layer input x in the canonical
+                                    // [x | h] channel order - the recurrent chunks lead the K order of every plan)
     int KC, nchunk[2];
     int mrep;                       // MFMA row blocks per wave: the workgroup covers 128 * mrep rows;
                                     // 0 / -1 = the 64- / 32-row conv-LSTM tiles (waves split rows x gates)
@@ -231,7 +234,7 @@ static std::vector<float> pack_weights(const ConvLayer &l, const float *w, int K
     for (int ci = 0; ci < nchunks; ++ci) {
         const int s = ci < l.nchunk[0] ? 0 : 1;
         const int c0 = (s == 0 ? ci : ci - l.nchunk[0]) * KC;
-        const int seg_off = s == 0 ? 0 : l.segC[0];
+        const int seg_off = l.seg_off[s];
         for (int ty = 0; ty < l.KH; ++ty)
             for (int tx = 0; tx < l.KW; ++tx)
                 for (int k8 = 0; k8 < K8; ++k8)
@@ -287,7 +290,7 @@ static std::vector<unsigned short> pack_weights_bf16x3(const ConvLayer &l, const
     for (int ci = 0; ci < nchunks; ++ci) {
         const int s = ci < l.nchunk[0] ? 0 : 1;
         const int c0 = (s == 0 ? ci : ci - l.nchunk[0]) * kBfKC;
-        const int seg_off = s == 0 ? 0 : l.segC[0];
+        const int seg_off = l.seg_off[s];
         for (int tap = 0; tap < ntaps; ++tap)
             for (int cgi = 0; cgi < l.ncg; ++cgi)
                 for (int g = 0; g < 4; ++g)
@@ -438,6 +441,7 @@ struct vf_handle {
     int stage_next = 0;
     int *d_sync = nullptr;              // [kQueues ticket heads, one cache line each | counters...]
     int xcd_queues = kQueues;           // ticket queues of the persistent launch (vf_set_xcd_queues): kQueues or 1
+    bool early_start = true;            // conv-LSTM items start on h(s-1) alone and wait for x(s) mid-item (ConvParams::late_cnt)
     bool fuse_top = true;               // vf_set_fuse_top: top transposed conv + compositing as one item (vf_fused_top.h)
     int *d_status = nullptr;            // sticky failure word of the persistent kernel
     unsigned long long *d_stats = nullptr;  // per-phase wait/run ticks (vf_set_phase_stats)
@@ -527,6 +531,11 @@ static void init_layer(ConvLayer &l, const char *name, PackMode mode, int Hin, i
     l.Hin = Hin; l.Win = Win; l.Hout = Hout; l.Wout = Wout;
     l.KH = KH; l.KW = KW; l.stride = stride; l.pad = pad;
     l.segC[0] = c0; l.segC[1] = c1; l.nseg = c1 > 0 ? 2 : 1;
+    l.seg_off[0] = 0; l.seg_off[1] = c0;
+    if (mode == PACK_LSTM) {        // callers pass (Cx, Ch) in canonical order; the recurrent input becomes segment 0
+        l.segC[0] = c1; l.segC[1] = c0;
+        l.seg_off[0] = c0; l.seg_off[1] = 0;
+    }
     l.Cout = Cout; l.ncg = (Cout + 31) / 32;
     l.nsplit = 1; l.n_valid = Cout;
     plan_geometry(l, stats, fc);
@@ -763,17 +772,17 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         h->st_rows[k] = h->lstm[k].stats_nparts;
         if (!h->have_big) continue;
         const ConvLayer &sm = h->lstm[k];
-        init_layer(h->lstm_big[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[0],
-                   sm.segC[1], sm.Cout, true, false, 2, 0);
+        init_layer(h->lstm_big[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[1],
+                   sm.segC[0], sm.Cout, true, false, 2, 0);
         // same chunking = same K order per output (bit-identical results) and the same packed weights
         h->big_ok[k] = h->lstm_big[k].KC == sm.KC;
         if (h->big_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_big[k].stats_nparts);
-        init_layer(h->lstm_half[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[0],
-                   sm.segC[1], sm.Cout, true, false, 0, 0);
+        init_layer(h->lstm_half[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[1],
+                   sm.segC[0], sm.Cout, true, false, 0, 0);
         h->half_ok[k] = h->lstm_half[k].KC == sm.KC && sm.KC == 32;
         if (h->half_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_half[k].stats_nparts);
         init_layer(h->lstm_quarter[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2,
-                   sm.segC[0], sm.segC[1], sm.Cout, true, false, -1, 0);
+                   sm.segC[1], sm.segC[0], sm.Cout, true, false, -1, 0);
         h->quarter_ok[k] = h->lstm_quarter[k].KC == sm.KC && sm.KC == 32;
         if (h->quarter_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_quarter[k].stats_nparts);
     }
@@ -1115,6 +1124,7 @@ struct LaunchSink {
             default: return launch_conv_t<1, EPI_PARTIAL>(l, p, st);
         }
     }
+    int lstm(const ConvLayer &l, const ConvParams &p, int /*u_prev*/, int /*u_x*/) { return conv(PH_LSTM, l, p, {}); }
     int sa(const SaParams &p, std::initializer_list<int>) {
         hipLaunchKernelGGL(sa_kernel, dim3(p.B), dim3(64), 0, st, p);
         return VF_OK;
@@ -1150,6 +1160,21 @@ struct ScheduleSink {
     double flops = 0.0;         // algorithmic FLOPs of all MFMA (conv / FC) phases
     size_t max_lds = 0;
 
+    // how a consumer recognises that producer phase Q is done with a sample
+    static PhaseDep dep_on(const PhaseDesc &Q) {
+        PhaseDep dp;
+        dp.cnt_base = Q.cnt_base;
+        if (Q.whole) { dp.mode = 1; dp.expect = Q.n_items; }
+        else {
+            dp.mode = (Q.B == 1) ? 1 : 0;       // a batch-1 producer is shared by every sample
+            switch (Q.type) {
+                case PH_SA: case PH_CDNA_FIN: dp.expect = 1; break;
+                case PH_COMPOSITE: dp.expect = Q.gx; break;
+                default: dp.expect = (Q.NI == 1 ? Q.tiles_per_img : 1) * Q.gy;
+            }
+        }
+        return dp;
+    }
     int add(PhaseDesc &P, int n_items, int counters, std::initializer_list<int> deps) {
         P.first_ticket = next_ticket; P.n_items = n_items;
         P.cnt_base = next_counter;
@@ -1157,21 +1182,22 @@ struct ScheduleSink {
         P.ndep = 0;
         for (int d : deps) {
             if (d < 0 || d == kSkipped) continue;
-            const PhaseDesc &Q = phases[d];
-            PhaseDep &dp = P.dep[P.ndep++];
-            dp.cnt_base = Q.cnt_base;
-            if (Q.whole) { dp.mode = 1; dp.expect = Q.n_items; }
-            else {
-                dp.mode = (Q.B == 1) ? 1 : 0;       // a batch-1 producer is shared by every sample
-                switch (Q.type) {
-                    case PH_SA: case PH_CDNA_FIN: dp.expect = 1; break;
-                    case PH_COMPOSITE: dp.expect = Q.gx; break;
-                    default: dp.expect = (Q.NI == 1 ? Q.tiles_per_img : 1) * Q.gy;
-                }
-            }
+            P.dep[P.ndep++] = dep_on(phases[d]);
         }
         phases.push_back(P);
         return (int)phases.size() - 1;
+    }
+    bool early_start = true;
+    // conv-LSTM of one step: u_prev = the same cell at the previous step (producer of the recurrent input and of the
+    // cell state), u_x = the producer of the layer input.  Early start: the item is released by u_prev alone and
+    // waits for u_x after its recurrent chunks (ConvParams::late_cnt; the counters' address is patched in at upload).
+    int lstm(const ConvLayer &l, const ConvParams &p, int u_prev, int u_x) {
+        const bool late = early_start && u_x >= 0 && u_x != kSkipped;
+        if (!late) return conv(PH_LSTM, l, p, {u_prev, u_x});
+        const PhaseDep ld = dep_on(phases[u_x]);
+        const int u = conv(PH_LSTM, l, p, {u_prev});
+        if (u >= 0) { phases[u].has_late = 1; phases[u].late = ld; }
+        return u;
     }
     int conv(int type, const ConvLayer &l, const ConvParams &p, std::initializer_list<int> deps) {
         PhaseDesc P;
@@ -1306,6 +1332,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
 #define VF_EMIT_SH(var, shared, expr) VF_EMIT(var, ((shared) && skip_shared) ? Sink::skipped() : (expr))
 
     int last = -1;      // terminal unit of the previous step
+    int u_prev[7] = {-1, -1, -1, -1, -1, -1, -1};   // conv-LSTM k of the previous step
     for (int s = 0; s < h->S; ++s) {
         const int cur = s & 1, nxt = cur ^ 1;
         const bool produce = s >= nc - 1;
@@ -1365,22 +1392,22 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
             const BatchView &O = out_sh ? sh : v, &I = in_sh ? sh : v;
             const long long per = (long long)lh[k] * lw[k] * L[k];
             SegArg hs = plain(I.h_state[k][cur], bs(in_sh, per));
-            ConvParams q = params(lstm_plan(k, out_sh ? 1 : B), out_sh ? 1 : B, x, &hs);
+            ConvParams q = params(lstm_plan(k, out_sh ? 1 : B), out_sh ? 1 : B, hs, &x);     // recurrent input first
             q.out = O.h_state[k][nxt]; q.cstate = O.c_state[k]; q.stats = O.st_h[k];
             q.stats_nparts = h->st_rows[k];
             q.cstate_in = I.c_state[k]; q.cin_bstride = bs(in_sh, per);
             return q;
         };
-        VF_EMIT_SH(u_l1, lstm_shared(0, s), sink.conv(PH_LSTM, lstm_plan(0, lstm_shared(0, s) ? 1 : B), lstm_params(0, enc0_n), {u_enc0}))
-        VF_EMIT_SH(u_l2, lstm_shared(1, s), sink.conv(PH_LSTM, lstm_plan(1, lstm_shared(1, s) ? 1 : B), lstm_params(1, h_normed(0)), {u_l1}))
+        VF_EMIT_SH(u_l1, lstm_shared(0, s), sink.lstm(lstm_plan(0, lstm_shared(0, s) ? 1 : B), lstm_params(0, enc0_n), u_prev[0], u_enc0))
+        VF_EMIT_SH(u_l2, lstm_shared(1, s), sink.lstm(lstm_plan(1, lstm_shared(1, s) ? 1 : B), lstm_params(1, h_normed(0)), u_prev[1], u_l1))
 
         p = params(h->enc1, BE, h_normed(1), nullptr);
         p.out = E.enc1_o;
         VF_EMIT_SH(u_enc1, enc_sh, sink.conv(PH_CONV_RELU, h->enc1, p, {u_l2}))
 
-        VF_EMIT_SH(u_l3, lstm_shared(2, s), sink.conv(PH_LSTM, lstm_plan(2, lstm_shared(2, s) ? 1 : B),
-                                lstm_params(2, plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]))), {u_enc1}))
-        VF_EMIT_SH(u_l4, lstm_shared(3, s), sink.conv(PH_LSTM, lstm_plan(3, lstm_shared(3, s) ? 1 : B), lstm_params(3, h_normed(2)), {u_l3}))
+        VF_EMIT_SH(u_l3, lstm_shared(2, s), sink.lstm(lstm_plan(2, lstm_shared(2, s) ? 1 : B),
+                                lstm_params(2, plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]))), u_prev[2], u_enc1))
+        VF_EMIT_SH(u_l4, lstm_shared(3, s), sink.lstm(lstm_plan(3, lstm_shared(3, s) ? 1 : B), lstm_params(3, h_normed(2)), u_prev[3], u_l3))
 
         const ConvLayer &enc2_l = light_plan(h->enc2, h->enc2_one, BE);
         p = params(enc2_l, BE, h_normed(3), nullptr);
@@ -1392,8 +1419,8 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         p.out = D.enc3_o; p.sbias = D.sbias; p.sbias_ld = L[3];
         VF_EMIT_SH(u_enc3, all_sh, sink.conv(PH_CONV_RELU, enc3_l, p, {u_enc2, u_sa}))
 
-        VF_EMIT_SH(u_l5, lstm_shared(4, s), sink.conv(PH_LSTM, lstm_plan(4, lstm_shared(4, s) ? 1 : B),
-                                lstm_params(4, plain(D.enc3_o, bs(all_sh, (long long)H8 * W8 * L[3]))), {u_enc3}))
+        VF_EMIT_SH(u_l5, lstm_shared(4, s), sink.lstm(lstm_plan(4, lstm_shared(4, s) ? 1 : B),
+                                lstm_params(4, plain(D.enc3_o, bs(all_sh, (long long)H8 * W8 * L[3]))), u_prev[4], u_enc3))
         SegArg h5n = h_normed(4);
 
         // ---- decoder
@@ -1401,8 +1428,8 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         p = params(convt1_l, BD, h5n, nullptr);
         p.out = D.enc4_o;
         VF_EMIT_SH(u_t1, all_sh, sink.conv(PH_CONVT_RELU, convt1_l, p, {u_l5}))
-        VF_EMIT_SH(u_l6, lstm_shared(5, s), sink.conv(PH_LSTM, lstm_plan(5, lstm_shared(5, s) ? 1 : B),
-                                lstm_params(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))), {u_t1}))
+        VF_EMIT_SH(u_l6, lstm_shared(5, s), sink.lstm(lstm_plan(5, lstm_shared(5, s) ? 1 : B),
+                                lstm_params(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))), u_prev[5], u_t1))
 
         // ---- CDNA kernels (only needed when this step's prediction is used).  The FC needs lstm5 of EVERY sample
         // and its only consumer is the compositing at the end of the step: it is emitted here, behind lstm6, where
@@ -1421,9 +1448,13 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         p = params(h->convt2, BD, h_normed(5), &enc1_s);
         p.out = D.enc5_o;
         VF_EMIT_SH(u_t2, all_sh, sink.conv(PH_CONVT_RELU, h->convt2, p, {u_l6}))
-        VF_EMIT_SH(u_l7, lstm_shared(6, s), sink.conv(PH_LSTM, lstm_plan(6, lstm_shared(6, s) ? 1 : B),
-                                lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))), {u_t2}))
+        VF_EMIT_SH(u_l7, lstm_shared(6, s), sink.lstm(lstm_plan(6, lstm_shared(6, s) ? 1 : B),
+                                lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))), u_prev[6], u_t2))
         last = u_l7;
+        {
+            const int now[7] = {u_l1, u_l2, u_l3, u_l4, u_l5, u_l6, u_l7};
+            for (int k = 0; k < 7; ++k) u_prev[k] = now[k];
+        }
         if (produce) {      // the (tiny) finalise step of the CDNA kernels: behind lstm7, by when the FC has long finished
             FinParams fp;
             fp.partial = v.fc_part; fp.nsplit = h->fc.nsplit; fp.B = B; fp.K = h->K;
@@ -1504,6 +1535,7 @@ static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &
     size_t max_lds = 0;
     for (int v = 0; v < h->ncam; ++v) {
         sinks[v].next_counter = counters;
+        sinks[v].early_start = h->early_start;
         rc = emit_rollout(h, v, make_view(h, v, h->actions_buf, 0), h->shared_views[(size_t)v], B, nullptr, sinks[v],
                           skip_shared);
         if (rc < 0) return rc;
@@ -1587,6 +1619,12 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
             for (size_t j = 0; j < i && !found; ++j) found = bs.phases[j].cnt_base == P.dep[d].cnt_base;
             if (!found) return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + " depends on a later phase");
             if (P.dep[d].expect <= 0) return fail(VF_ERR_INVALID, "non-positive expected count");
+        }
+        if (P.has_late) {
+            bool found = false;
+            for (size_t j = 0; j < i && !found; ++j) found = bs.phases[j].cnt_base == P.late.cnt_base;
+            if (!found || P.type != PH_LSTM || P.late.expect <= 0)
+                return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": bad late dependency");
         }
         const int ncnt = P.whole ? 1 : (P.type == PH_TOP_FUSED ? 2 * P.B : P.B);
         if (P.cnt_base < 0 || P.cnt_base + ncnt > bs.counters) return fail(VF_ERR_INVALID, "counter out of range");
@@ -1724,8 +1762,14 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         const int slot = h->stage_next;
         h->stage_next = (slot + 1) % kSchedRing;
         if (h->stage_used[slot]) VF_HIP_CHECK(hipEventSynchronize(h->stage_done[slot]));
-        for (size_t i = 0; i < bs.phases.size(); ++i) {     // device addresses the fused items need
+        for (size_t i = 0; i < bs.phases.size(); ++i) {     // device addresses the fused / early-started items need
             PhaseDesc &P = bs.phases[i];
+            if (P.type == PH_LSTM && P.has_late) {
+                P.conv.late_cnt = h->d_sync + kSyncHead + P.late.cnt_base;
+                P.conv.late_expect = P.late.expect;
+                P.conv.late_mode = P.late.mode;
+                P.conv.late_status = h->d_status;
+            }
             if (P.type != PH_TOP_FUSED) continue;
             P.conv.fuse_comp = &sc_host.d_phases[i].comp;
             P.conv.fuse_ready = h->d_sync + kSyncHead + P.aux_base;
@@ -1846,6 +1890,7 @@ int vf_set_persistent(vf_handle *h, int32_t enable) {
     h->persistent = enable != 0;
 #ifdef VF_DEBUG_KNOBS
     if (const char *e = getenv("VF_PERSIST_WGS_PER_CU")) h->persist_wgs_per_cu = std::max(1, std::min(2, atoi(e)));
+    if (const char *e = getenv("VF_EARLY_START")) h->early_start = atoi(e) != 0;
 #endif
     return VF_OK;
 }

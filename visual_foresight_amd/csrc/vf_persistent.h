@@ -60,6 +60,8 @@ struct PhaseDesc {
     int aux_base;           // PH_TOP_FUSED: first of the per-sample "LayerNorm partial published" counters
     int ndep;
     PhaseDep dep[kMaxDeps];
+    int has_late;           // PH_LSTM: the producer of the layer input is awaited INSIDE the item, after its recurrent
+    PhaseDep late;          // chunks (ConvParams::late_cnt, "early start"); dep[] then only holds the previous step's cell
     ConvParams conv;
     SaParams sa;
     FinParams fin;
