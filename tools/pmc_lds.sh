@@ -18,7 +18,7 @@ for f in glob.glob('$R/gpurun_out/lds_pmc*/*counter_collection.csv'):
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name'].split('(')[0][-60:]
         agg[k][row['Counter_Name']] += float(row['Counter_Value'])
-for k, m in sorted(agg.items(), key=lambda kv: -kv[1].get('SQ_BUSY_CU_CYCLES', 0))[:6]:
+for k, m in sorted(agg.items(), key=lambda kv: -kv[1].get('SQ_BUSY_CU_CYCLES', 0))[:14]:
     print(k)
     for c, v in sorted(m.items()):
         print('   %-28s %16.0f' % (c, v))

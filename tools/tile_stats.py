@@ -2,7 +2,8 @@
 """GPU box diagnostic: time split of conv-LSTM items inside the persistent rollout.
 
 Needs the instrumented library (hipcc ... -DVF_TILE_STATS, tools/ubench/build_variants.sh with
-VARIANTS=TILE_STATS); run as   VF_LIBRARY=tools/ubench/libvf_exp_TILE_STATS.so python tools/tile_stats.py [M]
+VARIANTS=TILE_STATS); run as   VF_LIBRARY=build/ab/tilestats.so python tools/tile_stats.py [M]
+(K loop column = first chunk staged -> epilogue, INCLUDING the staging of later chunks shown in the last column)
 """
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,26 +21,28 @@ ctx = {'context_frames': rs.randint(0, 256, (2, 1, 64, 64, 3)).astype(np.uint8),
 acts = rs.normal(0, 0.05, (M, T, 4))
 lib = _lib.load_library()
 lib.vf_debug_tile_clocks.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int32]
-buf = (ctypes.c_uint64 * 128)()
+buf = (ctypes.c_uint64 * 256)()
 pred.score(ctx, {'actions': acts}, [[[16, 48]]])
 lib.vf_debug_tile_clocks(buf, 1)
 pred.set_profiling(True)
 pred.score(ctx, {'actions': acts}, [[[16, 48]]])
 k_ms = pred.get_profile()[0]
 lib.vf_debug_tile_clocks(buf, 0)
-a = np.array(buf[:], dtype=np.float64).reshape(16, 8)
+a = np.array(buf[:], dtype=np.float64).reshape(32, 8)
 tick_us = 0.01
 names = {2: 'lstm1/2 (Ctot 64 @32)', 3: 'lstm7 (96 @32)', 11: 'lstm3 (96 @16)', 12: 'lstm4 (128 @16)',
-         14: 'lstm6 (192 @16)', 8: 'lstm5 (256 @8)'}
+         14: 'lstm6 (192 @16)', 8: 'lstm5 (256 @8)', 16: 'enc0', 17: 'enc3', 18: 'enc1', 19: 'enc2', 20: 'convt1',
+         21: 'convt2', 22: 'FC', 23: 'fused top', 24: 'unfused top'}
 print('kernel %.2f ms' % k_ms)
 print('%-24s %7s %9s %9s %9s %9s | per-slot ms: pro kloop epi' % ('layer', 'items', 'pro us', 'kloop us', 'epi us', 'stage us'))
 tot = np.zeros(3)
-for key in range(15):
+for key in list(range(15)) + list(range(16, 32)):
     n = a[key, 3]
     if n == 0:
         continue
     pro, kl, ep, st = (a[key, i] * tick_us / n for i in (0, 1, 2, 4))
-    tot += np.array([a[key, 0], a[key, 1], a[key, 2]]) * tick_us / 512 / 1e3
+    if key < 15:
+        tot += np.array([a[key, 0], a[key, 1], a[key, 2]]) * tick_us / 512 / 1e3
     print('%-24s %7d %9.1f %9.1f %9.1f %9.1f | %6.2f %6.2f %6.2f' % (
         names.get(key, 'key %d' % key), n, pro, kl, ep, st, a[key, 0] * tick_us / 512e3, a[key, 1] * tick_us / 512e3,
         a[key, 2] * tick_us / 512e3))

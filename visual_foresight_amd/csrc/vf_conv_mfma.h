@@ -22,6 +22,7 @@
 // persistent rollout kernel.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 // -DVF_HOST_SELFTEST (tools/sanitize/): the file is compiled for the host only and no kernel may be
 // emitted (a translation unit with kernels references the device binary); kernels then degrade to
@@ -44,7 +45,7 @@ namespace vf {
 // Diagnostic build only (hipcc -DVF_TILE_STATS, read by tools/tile_stats.py): where a conv-LSTM item spends
 // its time.  [layer key][0] entry->first MFMA, [1] K loop, [2] epilogue, [3] items, [4] staging of later chunks;
 // row 15: [5] ticket fetch, [6] publish, [7] items of the persistent scheduler.
-__device__ unsigned long long g_tile_clk[16][8];
+__device__ unsigned long long g_tile_clk[32][8];
 #define VF_TS_NOW() (threadIdx.x == 0 ? wall_clock64() : 0ull)
 #define VF_TS_ADD(KEY_, SLOT_, DT_) do { if (threadIdx.x == 0) atomicAdd(&g_tile_clk[KEY_][SLOT_], (unsigned long long)(DT_)); } while (0)
 #else
@@ -503,7 +504,14 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 
     [[maybe_unused]] const unsigned long long ts0 = VF_TS_NOW();
     [[maybe_unused]] unsigned long long ts1 = 0, ts_stage = 0;
-    [[maybe_unused]] const int ts_key = (((p.seg[0].C + (p.nseg > 1 ? p.seg[1].C : 0)) >> 5) & 7) + (p.Hout >= 32 ? 0 : 8);
+    [[maybe_unused]] int ts_key = (((p.seg[0].C + (p.nseg > 1 ? p.seg[1].C : 0)) >> 5) & 7) + (p.Hout >= 32 ? 0 : 8);
+    // light layers: 16 enc0 / enc00, 17 enc3, 18 enc1, 19 enc2, 20 convt1, 21 convt2 (two inputs), 22 FC, 23 fused top, 24 unfused top
+    if constexpr (EPI == EPI_RAW_STATS) ts_key = 16;
+    else if constexpr (EPI == EPI_BIAS_RELU) ts_key = p.KH == 1 ? 17 : (p.seg[0].C == 32 ? 18 : 19);
+    else if constexpr (EPI == EPI_CONVT_RELU) ts_key = p.nseg == 1 ? 20 : 21;
+    else if constexpr (EPI == EPI_PARTIAL) ts_key = 22;
+    else if constexpr (EPI >= EPI_CONVT_FUSED) ts_key = 23;
+    else if constexpr (EPI == EPI_CONVT_RAW_STATS) ts_key = 24;
     // ---- LayerNorm statistics of the producing layers (this workgroup's samples only); an early-started conv-LSTM
     // item reads them only once the producer of its layer input is known to be done (chunk loop below)
     bool late = false;
@@ -576,6 +584,38 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
             if (gt0 + d < gtN) { VF_LOADRING(d, gt0 + d) }
     }
 
+    // Light layers (everything but the conv-LSTM tiles): a K step is 4 - 9 MFMAs (0.1 - 0.25 us) while the weight
+    // operand comes straight from L2 (~1 us away), so with the one-step look-ahead of the pipelined loop below every
+    // step waits for its own loads.  Their B operand therefore travels through a register ring of D steps (D = 4, or
+    // 5 for the 5x5 layers with 8- / 16-channel chunks; D divides the steps of a chunk, so slots are static) that is
+    // refilled D steps ahead - across chunk boundaries: the weights of the next chunk do not depend on its staging.
+    constexpr bool kGRing = EPI != EPI_LSTM;
+    constexpr bool kConvT = (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS || EPI >= EPI_CONVT_FUSED);
+    [[maybe_unused]] f32x4 gring[kGRing ? (G == 1 ? 5 : 4) : 1][G];
+    [[maybe_unused]] const int nit_g = ntaps * K8;
+    [[maybe_unused]] const int ring_d = (nit_g & 3) == 0 ? 4 : ((G == 1 && nit_g % 5 == 0) ? 5 : 0);
+    // live output parities of transposed-conv tap `tap_` (bit g = parity g): see the pipelined loop below
+#define VF_TAPLIVE(TAP_) (kConvT ? ((((TAP_) >= p.KW) ? 15 : 3) & ((((TAP_) % p.KW) != 0) ? 15 : 5)) : 15)
+    // ring slot SLOT_ <- B of step IT_ of chunk CI_ (a transposed conv fetches its dead parity blocks - zeros - too:
+    // unconditional loads keep the ring in plain registers; only the MFMAs on them are skipped)
+#define VF_GLOAD(SLOT_, CI_, IT_)                                                               \
+    {                                                                                           \
+        const float *wp_ = wlane + ((long long)(CI_) * nit_g + (IT_)) * wstep;                  \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_)                                        \
+            gring[SLOT_][g_] = *reinterpret_cast<const f32x4 *>(wp_ + 128 * g_);                \
+    }
+    if constexpr (kGRing) {
+        if (ch_begin < ch_end) {
+            if (ring_d == 4) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) VF_GLOAD(d, ch_begin, d)
+            } else if (G == 1 && ring_d == 5) {
+#pragma unroll
+                for (int d = 0; d < 5; ++d) VF_GLOAD(d, ch_begin, d)
+            }
+        }
+    }
+
     // Wave priority: everything that is NOT a conv-LSTM K loop - the light tiles, the prologues and epilogues - is a
     // latency chain that others wait for; it runs at priority 2 (set by the persistent kernel) and the long matrix
     // loops step down to 0, so a co-resident light item or epilogue gets its few instructions issued first.
@@ -613,45 +653,65 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
                 }
             }
         }
-        for (int it = tid; it < items; it += kConvThreads) {
+        // Staging runs in batches of kStageU elements per thread: the geometry of all of them first, then all their
+        // global loads back to back, then LayerNorm / relu / the LDS stores - one exposed load latency per batch
+        // instead of one per element (a light layer's item is mostly this chain: 17 elements per thread in enc1,
+        // 64 over the eight chunks of an FC item).
+        constexpr int kStageU = 4;
+        for (int it0 = tid; it0 < items; it0 += kConvThreads * kStageU) {
             // q4 is a power of two; tile_px and LW divide through a multiply-high (exact for every index a tile
             // can hold: checked exhaustively for dividends < 70000, divisors 2..600; divisor 1 - the FC - bypasses it)
-            const int pix = it >> q4_log2;
-            const int img = tile_px == 1 ? pix : (int)__umulhi((unsigned)pix, magic_px), r = pix - img * tile_px;
-            const int ly = LW == 1 ? r : (int)__umulhi((unsigned)r, magic_lw), lx = r - ly * LW;
-            const int iy = ty0 * p.stride - p.pad + ly, ix = tx0 * p.stride - p.pad + lx;
-            const int b = bimg0 + img;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && c < sg.C) {
-                const float *src = sg.ptr + (long long)b * sg.bstride +
-                                   ((long long)iy * p.Win + ix) * sg.C + c;
-                if (vec_ok) {
-                    v = *reinterpret_cast<const f32x4 *>(src);
-                } else {
+            f32x4 v[kStageU];
+            int pixs[kStageU], imgs[kStageU];
+            bool oks[kStageU];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (j < nvalid) ? src[j] : 0.f;
-                }
-                if (sg.ln_part) {
-                    const float mean = lnTab[2 * (s * p.NI + img)];
-                    const float rstd = lnTab[2 * (s * p.NI + img) + 1];
+            for (int u = 0; u < kStageU; ++u) {
+                const int it = it0 + u * kConvThreads;
+                const int pix = it >> q4_log2;
+                const int img = tile_px == 1 ? pix : (int)__umulhi((unsigned)pix, magic_px), r = pix - img * tile_px;
+                const int ly = LW == 1 ? r : (int)__umulhi((unsigned)r, magic_lw), lx = r - ly * LW;
+                const int iy = ty0 * p.stride - p.pad + ly, ix = tx0 * p.stride - p.pad + lx;
+                const int b = bimg0 + img;
+                pixs[u] = pix; imgs[u] = img;
+                oks[u] = it < items && b < p.B && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && c < sg.C;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (oks[u]) {
+                    const float *src = sg.ptr + (long long)b * sg.bstride +
+                                       ((long long)iy * p.Win + ix) * sg.C + c;
+                    if (vec_ok) {
+                        v[u] = *reinterpret_cast<const f32x4 *>(src);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if constexpr (kHoistLn) {
-                            v[j] = fmaf((v[j] - mean) * rstd, gam[j], bet[j]);
-                        } else {
-                            const int cc = (c + j) % sg.gamma_mod;
-                            v[j] = fmaf((v[j] - mean) * rstd, sg.gamma[cc], sg.beta[cc]);
-                        }
+                        for (int j = 0; j < 4; ++j) v[u][j] = (j < nvalid) ? src[j] : 0.f;
                     }
                 }
-                if (sg.relu) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (j < nvalid) ? v[j] : 0.f;
             }
-            *reinterpret_cast<f32x4 *>(&smem[pix * KCpad + 4 * q]) = v;
+#pragma unroll
+            for (int u = 0; u < kStageU; ++u) {
+                if (it0 + u * kConvThreads >= items) break;
+                if (oks[u]) {
+                    if (sg.ln_part) {
+                        const float mean = lnTab[2 * (s * p.NI + imgs[u])];
+                        const float rstd = lnTab[2 * (s * p.NI + imgs[u]) + 1];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if constexpr (kHoistLn) {
+                                v[u][j] = fmaf((v[u][j] - mean) * rstd, gam[j], bet[j]);
+                            } else {
+                                const int cc = (c + j) % sg.gamma_mod;
+                                v[u][j] = fmaf((v[u][j] - mean) * rstd, sg.gamma[cc], sg.beta[cc]);
+                            }
+                        }
+                    }
+                    if (sg.relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[u][j] = fmaxf(v[u][j], 0.f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][j] = (j < nvalid) ? v[u][j] : 0.f;
+                }
+                *reinterpret_cast<f32x4 *>(&smem[pixs[u] * KCpad + 4 * q]) = v[u];
+            }
         }
         if constexpr (kBLds) {
             if (ci == ch_begin) { VF_WRITEB(0) }
@@ -732,14 +792,57 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
                     for (int q = 0; q < 4; ++q) aC[q] = aN[q];
                 }
             }
-        } else {
+        } else if (kGRing && (G > 1 || ring_d != 0)) {      // (transposed convs: 4 taps x K8 steps, always ring_d == 4)
+            // ---- K loop of the light layers: B from the register ring (refilled ring_d steps ahead), A one step
+            // ahead from LDS; same (tap, k8, j) order as the pipelined loop below
+            auto kloop = [&](auto dc) {
+                constexpr int D = decltype(dc)::value;
+                f32x4 aC[MREP], aN[MREP];
+                int ky = 0, kx = 0, k8 = 0;         // position of the NEXT A fetch
+                auto fetch_a = [&](f32x4 (&A_)[MREP]) {
+                    const int ao_ = (ky * LW + kx) * kcp4 + k8 * 2;
+#pragma unroll
+                    for (int m = 0; m < MREP; ++m) A_[m] = smem4[ab4[m] + ao_];
+                    if (++k8 == K8) { k8 = 0; if (++kx == p.KW) { kx = 0; ++ky; } }
+                };
+                fetch_a(aC);
+                for (int it0 = 0; it0 < nit_g; it0 += D) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const int it = it0 + j;
+                        if (it + 1 < nit_g) fetch_a(aN);
+                        const int live = VF_TAPLIVE(it / K8);
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            if (g == 0 || (live >> g) & 1) {
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                                    for (int m = 0; m < MREP; ++m)
+                                        acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(aC[m][jj], gring[j][g][jj], acc[m][g], 0, 0, 0);
+                            }
+                        }
+                        const int nx = it + D;
+                        if (nx < nit_g) { VF_GLOAD(j, ci, nx) }
+                        else if (ci + 1 < ch_end) { VF_GLOAD(j, ci + 1, nx - nit_g) }
+#pragma unroll
+                        for (int m = 0; m < MREP; ++m) aC[m] = aN[m];
+                    }
+                }
+            };
+            if constexpr (G == 1) {
+                if (ring_d == 4) kloop(std::integral_constant<int, 4>{});
+                else kloop(std::integral_constant<int, 5>{});
+            } else {
+                kloop(std::integral_constant<int, 4>{});
+            }
+        } else if constexpr (!(kGRing && G > 1)) {
             // ---- K loop over (tap, k8), software pipelined: operands of step it+1 are fetched
             // (A: LDS b128, B: L1/L2 b128) before the MFMAs of step it are issued.
             // Transposed convs: of the 16 (tap, output parity) blocks of the 2x2 view only 9 carry weights -
             // input row tap 0 only reaches even output rows, column tap 0 only even output columns - so a step
             // fetches and multiplies only its tap's live parities (LIVE_: bit g = parity g).  Skipped products are
             // exact zeros: the sums are unchanged.
-            constexpr bool kConvT = (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS || EPI >= EPI_CONVT_FUSED);
             const float *wchunk = wlane + (long long)ci * ntaps * K8 * wstep;
             const int nit = ntaps * K8;
             int ky = 0, kx = 0, k8 = 0;
@@ -793,6 +896,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #undef VF_LOADB
 #undef VF_WRITEB
 #undef VF_LOADRING
+#undef VF_GLOAD
+#undef VF_TAPLIVE
 
     if constexpr (EPI == EPI_LSTM) __builtin_amdgcn_s_setprio(2);
     [[maybe_unused]] const unsigned long long ts2 = VF_TS_NOW();
@@ -802,7 +907,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
         convt_fused_epilogue<(EPI - EPI_CONVT_FUSED) / 2 + 1, ((EPI - EPI_CONVT_FUSED) & 1) != 0>(p, acc, bx, red, smem);
     else conv_epilogue<G, EPI, MREP>(p, acc, bx, by, bz, red);
 #ifdef VF_TILE_STATS
-    if constexpr (EPI == EPI_LSTM) {
+    {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long ts3 = VF_TS_NOW();
         VF_TS_ADD(ts_key, 0, ts1 - ts0); VF_TS_ADD(ts_key, 1, ts2 - ts1); VF_TS_ADD(ts_key, 2, ts3 - ts2);

@@ -1289,15 +1289,32 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
     // the chip has workgroup slots (everything from ~500 64x64-samples on; the two widest layers from ~150)
     auto lstm_plan = [&](int k, int Bp) -> const ConvLayer & {
         if (!h->have_big) return h->lstm[k];
-        // 256 rows once the launch holds many more items than workgroup slots (everything from ~500
-        // 64x64-samples on, the two widest layers from ~150); 64 rows while a layer's phase would not even fill
-        // the 2 x n_cu slots once with 128-row items, 32 rows below half of that (measured:
-        // profiles/r02_ab_experiments.log)
-        const double beff = (double)Bp * Hc * Wc / 4096.0;
+        // Cost model of one phase on S = 2 x n_cu workgroup slots, fitted to the per-item times of the persistent
+        // launch (profiles/r02_phase_stats_*.txt, r03_tile_plan_sweep.txt): an item of a plan with `rows` GEMM rows
+        // costs d = fixed + slope * K microseconds (K = taps x input channels), a phase of n items takes about
+        // max(d, n * d / S) - the per-sample chain, or the slot time.  The plan with the smallest estimate wins; within
+        // 15 % the larger tile is kept (fewer items: less scheduling, staging and epilogue work per FLOP).  With the
+        // early start of the conv-LSTM items (recurrent half under the previous layer) the larger tiles pay off at
+        // smaller batches than they used to: at 125 samples lstm1/2/7 take 256 rows (500 items, one round of slots)
+        // instead of 128 (1000 items), 55.5 -> 52.6 ms per rollout.
         const ConvLayer &mid = h->lstm[k];
-        const long long n128 = (long long)(mid.NI == 1 ? Bp * mid.tilesY * mid.tilesX : (Bp + mid.NI - 1) / mid.NI) * mid.ncg;
-        int want = beff >= 500.0 || (beff >= 150.0 && k < 2) ? 2
-                   : (n128 <= h->n_cu ? 4 : (n128 <= 2 * h->n_cu ? 3 : 1));
+        const double K = 25.0 * (mid.segC[0] + mid.segC[1]);
+        const double S = 2.0 * h->n_cu;
+        struct Cand { int want; const ConvLayer *l; double fixed, slope; };
+        const Cand cands[4] = {{2, h->big_ok[k] ? &h->lstm_big[k] : nullptr, 45.0, 0.228},
+                               {1, &mid, 33.0, 0.114},
+                               {3, h->half_ok[k] ? &h->lstm_half[k] : nullptr, 30.0, 0.057},
+                               {4, h->quarter_ok[k] ? &h->lstm_quarter[k] : nullptr, 28.0, 0.030}};
+        int want = 1;
+        double best = 0.0;
+        for (const Cand &c : cands) {           // largest tile first
+            if (!c.l) continue;
+            const ConvLayer &l = *c.l;
+            const double n = (double)(l.NI == 1 ? (long long)Bp * l.tilesY * l.tilesX : (Bp + l.NI - 1) / l.NI) * l.ncg;
+            const double d = c.fixed + c.slope * K;
+            const double t = std::max(d, n * d / S);
+            if (best == 0.0 || t < 0.85 * best) { best = t; want = c.want; }
+        }
         if (h->mrep_override[k]) want = h->mrep_override[k];
         if (want == 2 && h->big_ok[k]) return h->lstm_big[k];
         if (want == 4 && h->quarter_ok[k]) return h->lstm_quarter[k];
@@ -1949,11 +1966,11 @@ int vf_debug_phase_stats(vf_handle *h, int32_t max_phases, int32_t *types, int32
 }
 
 #ifdef VF_TILE_STATS
-int vf_debug_tile_clocks(uint64_t *out /*[16][8]*/, int32_t reset) {
+int vf_debug_tile_clocks(uint64_t *out /*[32][8]*/, int32_t reset) {
     if (hipDeviceSynchronize() != hipSuccess) return fail(VF_ERR_HIP, "sync failed");
-    VF_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(vf::g_tile_clk), sizeof(uint64_t) * 128));
+    VF_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(vf::g_tile_clk), sizeof(uint64_t) * 256));
     if (reset) {
-        static const uint64_t zeros[128] = {0};
+        static const uint64_t zeros[256] = {0};
         VF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(vf::g_tile_clk), zeros, sizeof(zeros)));
     }
     return VF_OK;
