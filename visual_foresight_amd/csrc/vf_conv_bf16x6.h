@@ -69,7 +69,7 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx,
     }
 
     const bool late = p.late_cnt != nullptr;     // early-started item: see ConvParams::late_cnt
-    if (!late) ln_table(p, bimg0, lnTab);
+    ln_table(p, bimg0, lnTab, 0, late ? 1 : 2);
 
     const int px_per_img = p.TH * p.TW;
     int abase[MREP];                    // 16-B unit of this lane's row inside a plane (+ k-half)
@@ -113,7 +113,7 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx,
         if (late && ci == p.seg[0].nchunk) {         // the recurrent chunks are done: now the layer input is needed
             const int b1 = p.NI == 1 ? bimg0 + 1 : min(bimg0 + p.NI, p.B);
             if (!late_wait(p, bimg0, b1, reinterpret_cast<int *>(red))) return;
-            ln_table(p, bimg0, lnTab);
+            ln_table(p, bimg0, lnTab, 1, 2);
         }
         __syncthreads();
         for (int it = tid; it < items; it += kConvThreads) {

@@ -119,10 +119,11 @@ struct ConvParams {
     int *fuse_ready;
     const int *fuse_status;
     int fuse_view, fuse_nd;
-    // EPI_LSTM inside the persistent launch: "early start".  seg[0] is the RECURRENT input h(s-1), seg[1] the layer
-    // input x(s).  The item is released as soon as h(s-1) exists, runs the recurrent chunks, and only then waits
-    // for the producer of x (completion counters late_cnt: one per sample, or counter 0 when late_mode = 1, done at
-    // late_expect) - the wait that used to idle the slot in front of the item now overlaps half of its K loop.
+    // Two-input tiles inside the persistent launch: "early start".  seg[0] is the input that exists EARLY - the
+    // recurrent h(s-1) of a conv-LSTM, the encoder skip tensor of a decoder's transposed conv - seg[1] the one produced
+    // by the previous layer.  The item is released as soon as seg[0] exists, runs its chunks, and only then waits
+    // for the producer of seg[1] (completion counters late_cnt: one per sample, or counter 0 when late_mode = 1, done
+    // at late_expect) - the wait that used to idle the slot in front of the item now overlaps part of its K loop.
     // null: every input is complete at entry (per-layer launches).
     const int *late_cnt;
     int late_expect, late_mode;
@@ -225,12 +226,14 @@ struct TileDiv {
 // Few entries (conv tiles: 1-8): one WAVE per entry, lanes over the partials (up to 32 per sample at 128x128), so the
 // prologue costs one load latency instead of a serial chain; many entries (the FC: one per GEMM row): one thread
 // each.  The partials are integers: any summation order gives the same bits.
+// (segments [s_begin, s_end): an early-started two-input tile fills the entries of its late segment after the wait)
 template <class PT>
-__device__ __forceinline__ void ln_table(const PT &p, const int bimg0, float *lnTab) {
+__device__ __forceinline__ void ln_table(const PT &p, const int bimg0, float *lnTab, const int s_begin = 0,
+                                         const int s_end = 2) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = p.nseg * p.NI;
-    if (n <= 8) {
-        for (int i = wave; i < n; i += kConvThreads / 64) {
+    const int n = min(s_end, p.nseg) * p.NI, i0 = s_begin * p.NI;
+    if (p.nseg * p.NI <= 8) {
+        for (int i = i0 + wave; i < n; i += kConvThreads / 64) {
             const int s = i / p.NI, img = i - s * p.NI;
             const auto &sg = p.seg[s];
             float mean = 0.f, rstd = 1.f;
@@ -245,7 +248,7 @@ __device__ __forceinline__ void ln_table(const PT &p, const int bimg0, float *ln
             if (lane == 0) { lnTab[2 * i] = mean; lnTab[2 * i + 1] = rstd; }
         }
     } else {
-        for (int i = tid; i < n; i += kConvThreads) {
+        for (int i = i0 + tid; i < n; i += kConvThreads) {
             const int s = i / p.NI, img = i % p.NI;
             const auto &sg = p.seg[s];
             float mean = 0.f, rstd = 1.f;
@@ -514,9 +517,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     else if constexpr (EPI == EPI_CONVT_RAW_STATS) ts_key = 24;
     // ---- LayerNorm statistics of the producing layers (this workgroup's samples only); an early-started conv-LSTM
     // item reads them only once the producer of its layer input is known to be done (chunk loop below)
-    bool late = false;
-    if constexpr (EPI == EPI_LSTM) late = p.late_cnt != nullptr;
-    if (!late) ln_table(p, bimg0, lnTab);
+    const bool late = p.late_cnt != nullptr;
+    ln_table(p, bimg0, lnTab, 0, late ? 1 : 2);
 
     // ---- this lane's A rows (GEMM rows wave*WROWS + m*32 + n)
     const int px_per_img = p.TH * p.TW;
@@ -626,12 +628,10 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
         const int c0 = (s == 0 ? ci : ci - p.seg[0].nchunk) * KC;
         const bool vec_ok = (sg.C & 3) == 0;
 
-        if constexpr (EPI == EPI_LSTM) {
-            if (late && ci == p.seg[0].nchunk) {     // the recurrent chunks are done: now the layer input is needed
-                const int b1 = p.NI == 1 ? bimg0 + 1 : min(bimg0 + p.NI, p.B);
-                if (!late_wait(p, bimg0, b1, reinterpret_cast<int *>(red))) return;
-                ln_table(p, bimg0, lnTab);
-            }
+        if (late && ci == p.seg[0].nchunk) {         // the chunks of the early input are done: now the late one is needed
+            const int b1 = p.NI == 1 ? bimg0 + 1 : min(bimg0 + p.NI, p.B);
+            if (!late_wait(p, bimg0, b1, reinterpret_cast<int *>(red))) return;
+            ln_table(p, bimg0, lnTab, 1, 2);
         }
         __syncthreads();        // previous chunk fully consumed (and lnTab visible on entry)
         [[maybe_unused]] const unsigned long long ts_s0 = VF_TS_NOW();

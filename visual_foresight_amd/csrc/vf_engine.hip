@@ -526,13 +526,15 @@ static int validate(const vf_config *c) {
 
 static void init_layer(ConvLayer &l, const char *name, PackMode mode, int Hin, int Win, int Hout, int Wout,
                        int KH, int KW, int stride, int pad, int c0, int c1, int Cout, bool stats,
-                       bool fc = false, int mrep = 1, int prec = 0) {
+                       bool fc = false, int mrep = 1, int prec = 0, bool second_first = false) {
     l.name = name; l.mode = mode; l.G = (mode == PACK_PLAIN) ? 1 : 4; l.mrep = prec == 1 ? 1 : mrep; l.prec = prec;
     l.Hin = Hin; l.Win = Win; l.Hout = Hout; l.Wout = Wout;
     l.KH = KH; l.KW = KW; l.stride = stride; l.pad = pad;
     l.segC[0] = c0; l.segC[1] = c1; l.nseg = c1 > 0 ? 2 : 1;
     l.seg_off[0] = 0; l.seg_off[1] = c0;
-    if (mode == PACK_LSTM) {        // callers pass (Cx, Ch) in canonical order; the recurrent input becomes segment 0
+    // callers pass the channel counts in canonical (concatenation) order; the recurrent input of a conv-LSTM and the
+    // encoder skip tensor of a decoder conv (second_first) become segment 0: they exist early (ConvParams::late_cnt)
+    if (mode == PACK_LSTM || (second_first && c1 > 0)) {
         l.segC[0] = c1; l.segC[1] = c0;
         l.seg_off[0] = c0; l.seg_off[1] = 0;
     }
@@ -734,7 +736,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
 #endif
     if (h->savp) {
         init_layer(h->enc00, "enc00", PACK_PLAIN, H, W, Hc, Wc, 5, 5, 2, 1, 3, 0, kEnc00Ch, true);
-        init_layer(h->convt4, "convt4", PACK_CONVT, Hc, Wc, Hc, Wc, 2, 2, 1, 1, 32, kEnc00Ch, 32, true);
+        init_layer(h->convt4, "convt4", PACK_CONVT, Hc, Wc, Hc, Wc, 2, 2, 1, 1, 32, kEnc00Ch, 32, true, false, 1, 0, true);
     }
     init_layer(h->enc0, "enc0", PACK_PLAIN, Hc, Wc, H2, W2, 5, 5, 2, 1, h->savp ? kEnc00Ch : 3, 0, 32, true);
     init_layer(h->lstm[0], "lstm1", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, 32, L[0], L[0], true, false, lstm_mrep[0], cfg->precision);
@@ -751,9 +753,9 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     init_layer(h->enc3_one, "enc3", PACK_PLAIN, H8, W8, H8, W8, 1, 1, 1, 0, L[3], 0, L[3], false);
     init_layer(h->convt1_one, "convt1", PACK_CONVT, H8, W8, H8, W8, 2, 2, 1, 1, L[4], 0, L[4], false);
     init_layer(h->lstm[5], "lstm6", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[4], L[5], L[5], true, false, lstm_mrep[5], cfg->precision);
-    init_layer(h->convt2, "convt2", PACK_CONVT, H4, W4, H4, W4, 2, 2, 1, 1, L[5], L[1], L[5], false);
+    init_layer(h->convt2, "convt2", PACK_CONVT, H4, W4, H4, W4, 2, 2, 1, 1, L[5], L[1], L[5], false, false, 1, 0, true);
     init_layer(h->lstm[6], "lstm7", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[5], L[6], L[6], true, false, lstm_mrep[6], cfg->precision);
-    init_layer(h->convt3, "convt3", PACK_CONVT, H2, W2, H2, W2, 2, 2, 1, 1, L[6], 32, 32, true);
+    init_layer(h->convt3, "convt3", PACK_CONVT, H2, W2, H2, W2, 2, 2, 1, 1, L[6], 32, 32, true, false, 1, 0, true);
     // CDNA FC as a K-split GEMM over 1x1 "images"
     init_layer(h->fc, "cdna", PACK_PLAIN, 1, 1, 1, 1, 1, 1, 1, 0, H8 * W8 * L[4], 0, kTaps * h->K, false, true, 2);
     {
@@ -1125,6 +1127,7 @@ struct LaunchSink {
         }
     }
     int lstm(const ConvLayer &l, const ConvParams &p, int /*u_prev*/, int /*u_x*/) { return conv(PH_LSTM, l, p, {}); }
+    int conv_late(int type, const ConvLayer &l, const ConvParams &p, int /*u_early*/, int /*u_late*/) { return conv(type, l, p, {}); }
     int sa(const SaParams &p, std::initializer_list<int>) {
         hipLaunchKernelGGL(sa_kernel, dim3(p.B), dim3(64), 0, st, p);
         return VF_OK;
@@ -1144,9 +1147,9 @@ struct LaunchSink {
         VF_HIP_CHECK(hipGetLastError());
         return VF_OK;
     }
-    int top(const ConvLayer &l, const ConvParams &p, const CompositeParams &cp, int ntiles, int view, int d0, int d1,
-            int dfin, bool /*fuse*/) {      // one launch per layer: never fused
-        int rc = conv(PH_CONVT_RAW, l, p, {d0, d1});
+    int top(const ConvLayer &l, const ConvParams &p, const CompositeParams &cp, int ntiles, int view, int /*d_early*/,
+            int /*d_late*/, int dfin, bool /*fuse*/) {      // one launch per layer: never fused
+        int rc = conv(PH_CONVT_RAW, l, p, {});
         if (rc) return rc;
         return composite(cp, ntiles, view, {dfin});
     }
@@ -1191,11 +1194,14 @@ struct ScheduleSink {
     // conv-LSTM of one step: u_prev = the same cell at the previous step (producer of the recurrent input and of the
     // cell state), u_x = the producer of the layer input.  Early start: the item is released by u_prev alone and
     // waits for u_x after its recurrent chunks (ConvParams::late_cnt; the counters' address is patched in at upload).
-    int lstm(const ConvLayer &l, const ConvParams &p, int u_prev, int u_x) {
-        const bool late = early_start && u_x >= 0 && u_x != kSkipped;
-        if (!late) return conv(PH_LSTM, l, p, {u_prev, u_x});
-        const PhaseDep ld = dep_on(phases[u_x]);
-        const int u = conv(PH_LSTM, l, p, {u_prev});
+    int lstm(const ConvLayer &l, const ConvParams &p, int u_prev, int u_x) { return conv_late(PH_LSTM, l, p, u_prev, u_x); }
+    // a two-input tile whose segment 0 comes from u_early and whose segment 1 from u_late (decoder convs: the encoder
+    // skip tensor first, the previous layer's output late)
+    int conv_late(int type, const ConvLayer &l, const ConvParams &p, int u_early, int u_late) {
+        const bool late = early_start && u_late >= 0 && u_late != kSkipped;
+        if (!late) return conv(type, l, p, {u_early, u_late});
+        const PhaseDep ld = dep_on(phases[u_late]);
+        const int u = conv(type, l, p, {u_early});
         if (u >= 0) { phases[u].has_late = 1; phases[u].late = ld; }
         return u;
     }
@@ -1237,13 +1243,14 @@ struct ScheduleSink {
     // top transposed conv + compositing: one fused item per conv tile where the tile geometry allows it (a region
     // of whole 4 x 16 cost-sum blocks, one image and one channel group per tile, LDS), two phases otherwise
     static bool fusable(const ConvLayer &l, int ND) { return top_fusable(l, ND); }
-    int top(const ConvLayer &l, const ConvParams &p, const CompositeParams &cp, int ntiles, int view, int d0, int d1,
-            int dfin, bool fuse) {
+    int top(const ConvLayer &l, const ConvParams &p, const CompositeParams &cp, int ntiles, int view, int d_early,
+            int d_late, int dfin, bool fuse) {
         if (!fuse || !fusable(l, cp.ND)) {
-            const int u = conv(PH_CONVT_RAW, l, p, {d0, d1});
+            const int u = conv_late(PH_CONVT_RAW, l, p, d_early, d_late);
             if (u < 0) return u;
             return composite(cp, ntiles, view, {u, dfin});
         }
+        const bool late = early_start && d_late >= 0 && d_late != kSkipped;
         PhaseDesc P;
         memset(&P, 0, sizeof(P));
         P.type = PH_TOP_FUSED; P.conv = p; P.comp = cp; P.B = p.B; P.view = view;
@@ -1253,7 +1260,9 @@ struct ScheduleSink {
         P.aux_base = next_counter + p.B;        // behind the completion counters of this phase
         max_lds = std::max(max_lds, std::max(l.lds_bytes, fused_top_lds_floats(l.TH, l.TW, cp.ND) * 4));
         flops += 2.0 * (double)p.B * l.Hout * l.Wout * 9.0 * (l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0)) * l.Cout;
-        return add(P, P.gx, 2 * p.B, {d0, d1, dfin});
+        if (!late) return add(P, P.gx, 2 * p.B, {d_early, d_late, dfin});
+        P.has_late = 1; P.late = dep_on(phases[d_late]);
+        return add(P, P.gx, 2 * p.B, {d_early, dfin});
     }
     static bool failed(int rc) { return rc < 0; }
     static int skipped() { return kSkipped; }
@@ -1461,10 +1470,10 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
             u_fc = u_fc_;
         }
 
-        SegArg enc1_s = plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]));
-        p = params(h->convt2, BD, h_normed(5), &enc1_s);
+        SegArg enc1_s = plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1])), h6n = h_normed(5);
+        p = params(h->convt2, BD, enc1_s, &h6n);        // the skip tensor first: it exists since the encoder (early start)
         p.out = D.enc5_o;
-        VF_EMIT_SH(u_t2, all_sh, sink.conv(PH_CONVT_RELU, h->convt2, p, {u_l6}))
+        VF_EMIT_SH(u_t2, all_sh, sink.conv_late(PH_CONVT_RELU, h->convt2, p, u_enc1, u_l6))
         VF_EMIT_SH(u_l7, lstm_shared(6, s), sink.lstm(lstm_plan(6, lstm_shared(6, s) ? 1 : B),
                                 lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))), u_prev[6], u_t2))
         last = u_l7;
@@ -1483,18 +1492,19 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         if (produce) {      // never an all-shared step
             // the top transposed conv and the compositing go to the sink together: the persistent schedule may
             // fuse them into one item per tile (vf_fused_top.h)
-            p = params(h->convt3, B, h_normed(6), &enc0_n);
+            SegArg h7n = h_normed(6);
+            p = params(h->convt3, B, enc0_n, &h7n);     // skip tensor first (early start)
             p.out = v.enc6_o; p.stats = v.st_enc6;
             const ConvLayer *top_l = &h->convt3;
-            int top_d0 = u_l7, top_d1 = -1;
+            int top_early = u_enc0, top_late = u_l7;
             if (h->savp) {  // extra decoder scale: enc7 = convT(concat[relu(LN9(enc6)), relu(LNa(enc00))]), LNb on use
                 // (an encoder-shared enc00 of a context step is read with batch stride 0)
                 SegArg enc6_n = normed(v.enc6_o, (long long)Hc * Wc * 32, v.st_enc6, h->convt3.stats_nparts,
                                        h->convt3.stats_nparts, false, (long long)Hc * Wc * 32, vd.ln_g[8], vd.ln_b[8], 32, 1);
-                VF_EMIT(u_t3, sink.conv(PH_CONVT_RAW, h->convt3, p, {u_l7}))
-                p = params(h->convt4, B, enc6_n, &enc00_n);
+                VF_EMIT(u_t3, sink.conv_late(PH_CONVT_RAW, h->convt3, p, u_enc0, u_l7))
+                p = params(h->convt4, B, enc00_n, &enc6_n);
                 p.out = v.enc7_o; p.stats = v.st_enc7;
-                top_l = &h->convt4; top_d0 = u_t3; top_d1 = u_enc00;
+                top_l = &h->convt4; top_early = u_enc00; top_late = u_t3;
             }
 
             CompositeParams cp; memset(&cp, 0, sizeof(cp));
@@ -1525,7 +1535,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
             cp.out_sums = v.sums + (long long)t_out * h->sums_step_stride;
             if (goal_pix)
                 for (int d = 0; d < ND; ++d) { cp.goal[d][0] = goal_pix[2 * d]; cp.goal[d][1] = goal_pix[2 * d + 1]; }
-            VF_EMIT(u_comp, sink.top(*top_l, p, cp, h->ntiles, view, top_d0, top_d1, u_fin, h->fuse_top))
+            VF_EMIT(u_comp, sink.top(*top_l, p, cp, h->ntiles, view, top_early, top_late, u_fin, h->fuse_top))
             last = u_comp;
         }
     }
@@ -1640,7 +1650,7 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
         if (P.has_late) {
             bool found = false;
             for (size_t j = 0; j < i && !found; ++j) found = bs.phases[j].cnt_base == P.late.cnt_base;
-            if (!found || P.type != PH_LSTM || P.late.expect <= 0)
+            if (!found || !(P.type <= PH_CONVT_RAW || P.type == PH_TOP_FUSED) || P.late.expect <= 0)
                 return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": bad late dependency");
         }
         const int ncnt = P.whole ? 1 : (P.type == PH_TOP_FUSED ? 2 * P.B : P.B);
@@ -1781,7 +1791,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         if (h->stage_used[slot]) VF_HIP_CHECK(hipEventSynchronize(h->stage_done[slot]));
         for (size_t i = 0; i < bs.phases.size(); ++i) {     // device addresses the fused / early-started items need
             PhaseDesc &P = bs.phases[i];
-            if (P.type == PH_LSTM && P.has_late) {
+            if (P.has_late) {
                 P.conv.late_cnt = h->d_sync + kSyncHead + P.late.cnt_base;
                 P.conv.late_expect = P.late.expect;
                 P.conv.late_mode = P.late.mode;

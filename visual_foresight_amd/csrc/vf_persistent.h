@@ -60,8 +60,8 @@ struct PhaseDesc {
     int aux_base;           // PH_TOP_FUSED: first of the per-sample "LayerNorm partial published" counters
     int ndep;
     PhaseDep dep[kMaxDeps];
-    int has_late;           // PH_LSTM: the producer of the layer input is awaited INSIDE the item, after its recurrent
-    PhaseDep late;          // chunks (ConvParams::late_cnt, "early start"); dep[] then only holds the previous step's cell
+    int has_late;           // two-input conv phases: the producer of segment 1 is awaited INSIDE the item, after the chunks
+    PhaseDep late;          // of segment 0 (ConvParams::late_cnt, "early start"); dep[] then only holds segment 0's producer
     ConvParams conv;
     SaParams sa;
     FinParams fin;
