@@ -177,7 +177,8 @@ def cpu_baseline():
             return time.perf_counter() - t0
 
     plan(12, 2, 1)                                          # warm-up (thread pool, oneDNN primitives)
-    t_c1 = plan(32, 5, 1)
+    c1_calls = sorted(plan(32, 5, 1) for _ in range(5))    # median / p10 / p90 over repeated calls
+    t_c1 = c1_calls[len(c1_calls) // 2]
     t_c2 = plan(200, 13, 1)
     all_cores = None
     if cores > used:
@@ -194,7 +195,9 @@ def cpu_baseline():
                       'on this host; all-cores figure beside it)' % (t_c2, used),
             'cem_iters_per_sec': 1.0 / t_c2, 'at_all_physical_cores': all_cores,
             'c1': {'value': 32 * 5 / t_c1, 'unit': 'predicted frames/s', 'cem_iters_per_sec': 1.0 / t_c1,
-                   'sample': 'C1: the whole planning call (32 samples x horizon 5, 1 iteration), %.2f s' % t_c1},
+                   'calls': len(c1_calls), 'seconds_median_p10_p90': [t_c1, c1_calls[0], c1_calls[-1]],
+                   'sample': 'C1: the whole planning call (32 samples x horizon 5, 1 iteration), median of %d calls '
+                             '%.2f s (min %.2f, max %.2f)' % (len(c1_calls), t_c1, c1_calls[0], c1_calls[-1])},
             'note': 'CPU restatement baseline (oracle/), reported, not the optimisation target; the literal '
                     'TF1-CPU reference cannot run anywhere in this project (no TF, no video_prediction)'}
 
@@ -403,7 +406,7 @@ class Bench(object):
         """HBM bytes per launch cannot be counted from inside the process: they come from the committed
         rocprofv3 PMC passes of this same command (tools/pmc_hbm.sh) and are only quoted when that profile
         was taken from this very library (source hash) on this workload."""
-        path = os.path.join(REPO, 'profiles', 'r02_hbm_traffic.json')
+        path = os.path.join(REPO, 'profiles', 'r03_hbm_traffic.json')
         if not os.path.exists(path):
             return
         with open(path) as f:
@@ -411,7 +414,7 @@ class Bench(object):
         if (prof.get('lib_sources_sha16') == library_hash() and prof.get('workload') == self.args.workload
                 and prof.get('precision') == precision and self.world == 1 and not self.args.samples):
             roof['traffic'] = prof['hbm_bytes_per_launch']
-            roof['traffic_source'] = 'profiles/r02_hbm_traffic.json (rocprofv3 PMC passes of this library, offline)'
+            roof['traffic_source'] = 'profiles/r03_hbm_traffic.json (rocprofv3 PMC passes of this library, offline)'
             roof['traffic_vs_algorithmic'] = prof.get('ratio_to_algorithmic')
 
     def metric_label(self):

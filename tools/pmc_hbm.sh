@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: HBM-side traffic of the persistent rollout kernel for the default bench workload.  FETCH_SIZE and
 # WRITE_SIZE need separate passes (TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots"); units are KiB.
-# Writes gpurun_out/r02_hbm_traffic.json, stamped with the hash of the kernel sources so bench.py only
+# Writes gpurun_out/hbm_traffic.json, stamped with the hash of the kernel sources so bench.py only
 # quotes it for the library it was measured on (copy it to profiles/ to have it reported).
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -27,7 +27,7 @@ total = 1024.0 * (2.0 * res['FETCH_SIZE'][1] + res['WRITE_SIZE'][1])
 # SURVEY 8(d) algorithmic bytes of one C2 rollout: 200 x 14 sample-steps x 2.49 MB of LSTM state round trip
 # + 200 x 13 predicted frames and distributions written + the 33 MB weight set once per step
 algorithmic = 200 * 14 * 2 * 311296 * 4 + 200 * 13 * 64 * 64 * 4 * 4 + 14 * 33.0e6
-json.dump({'kernel': 'rollout_persistent_kernel<1,2>', 'workload': 'c2', 'precision': 'fp32',
+json.dump({'kernel': 'rollout_persistent_kernel<1>', 'workload': 'c2', 'precision': 'fp32',
            'lib_sources_sha16': bench.library_hash(),
            'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py '
                       '--steps 2 --warmup 1 --no-cpu-baseline --no-alt   (tools/pmc_hbm.sh)',
@@ -37,5 +37,5 @@ json.dump({'kernel': 'rollout_persistent_kernel<1,2>', 'workload': 'c2', 'precis
            'correction': 'MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports half the bytes of a wide '
                          'coalesced read, so the read side is doubled; WRITE_SIZE is uncalibrated and taken as is; '
                          'Infinity-Cache hits are included in both'},
-          open('$R/gpurun_out/r02_hbm_traffic.json', 'w'), indent=1)
+          open('$R/gpurun_out/hbm_traffic.json', 'w'), indent=1)
 PY

@@ -3,7 +3,7 @@
 # summaries into profiles/ afterwards).  usage: tools/run_profiles.sh <tag>
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-tag=${1:-r02}
+tag=${1:-r03}
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 cd $R
@@ -18,7 +18,14 @@ db=$(ls $O/ktrace/*.db 2>/dev/null | head -1)
 [ -n "$db" ] && python3 tools/rocprof_summary.py $db > $O/kernel_stats_fp32.txt && head -6 $O/kernel_stats_fp32.txt
 # 3. counters (separate runs, --kernel-trace only)
 bash tools/pmc_mfma.sh > $O/mfma_pmc.txt 2>&1; tail -4 $O/mfma_pmc.txt
-bash tools/pmc_hbm.sh > $O/pmc_hbm.log 2>&1; cp gpurun_out/r02_hbm_traffic.json $O/hbm_traffic.json; tail -3 $O/pmc_hbm.log
+bash tools/pmc_hbm.sh > $O/pmc_hbm.log 2>&1; cp gpurun_out/hbm_traffic.json $O/hbm_traffic.json; tail -3 $O/pmc_hbm.log
+# 3b. the split-bf16 mode: its own kernel trace and MFMA counters
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/ktrace16 -o k -- python3 $R/bench.py --precision bf16x6 --steps 5 --warmup 2 --no-cpu-baseline --no-alt > $O/ktrace_bench_bf16x6.json 2> $O/ktrace16.err
+cd $R
+db=$(ls $O/ktrace16/*.db 2>/dev/null | head -1)
+[ -n "$db" ] && python3 tools/rocprof_summary.py $db > $O/kernel_stats_bf16x6.txt && head -4 $O/kernel_stats_bf16x6.txt
+bash tools/pmc_mfma.sh --precision bf16x6 > $O/mfma_pmc_bf16x6.txt 2>&1; tail -5 $O/mfma_pmc_bf16x6.txt
 # 4. the other BASELINE shapes
 python bench.py --workload c1 --no-alt --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c1.json; python tools/bench_line.py $O/bench_c1.json c1
 python bench.py --workload c3 --no-alt --no-cpu-baseline --steps 4 --warmup 1 2>/dev/null | tail -1 > $O/bench_c3.json; python tools/bench_line.py $O/bench_c3.json c3
@@ -29,6 +36,7 @@ python bench.py --workload c5 --samples 125 --no-cpu-baseline --steps 3 --warmup
 # 5. phase statistics, two-rank dry run
 python tools/persist_stats.py 200 > $O/phase_stats_200.txt 2>&1
 python tools/persist_stats.py 25 > $O/phase_stats_25.txt 2>&1
+python tools/persist_stats.py 125 64 cdna 15 > $O/phase_stats_125.txt 2>&1
 python tools/persist_stats.py 625 128 savp 15 > $O/phase_stats_c5_shard.txt 2>&1
 python bench.py --gpus 2 --no-alt --no-cpu-baseline --steps 4 --warmup 1 2>/dev/null | tail -1 > $O/bench_2ranks_gloo_dryrun.json; python tools/bench_line.py $O/bench_2ranks_gloo_dryrun.json 2ranks-gloo
-rm -rf $O/ktrace gpurun_out/hbm_FETCH_SIZE gpurun_out/hbm_WRITE_SIZE gpurun_out/mfma_pmc
+rm -rf $O/ktrace $O/ktrace16 gpurun_out/hbm_FETCH_SIZE gpurun_out/hbm_WRITE_SIZE gpurun_out/mfma_pmc

@@ -35,6 +35,9 @@
 #define VF_LAUNCH_BOUNDS(...) __launch_bounds__(__VA_ARGS__)
 #endif
 
+#ifndef VF_POLL_SLEEP
+#define VF_POLL_SLEEP 16      // s_sleep units (64 cycles) between two polls of a dependency counter
+#endif
 #ifndef VF_RING_RB2
 #define VF_RING_RB2 0
 #endif
@@ -153,7 +156,7 @@ __device__ __forceinline__ bool late_wait(const PT &p, const int b0, const int b
             }
             ok = __all(ok);
             if (!ok) {
-                __builtin_amdgcn_s_sleep(16);
+                __builtin_amdgcn_s_sleep(VF_POLL_SLEEP);
                 if (++spins > kLateSpinLimit ||
                     __hip_atomic_load(p.late_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     if (lane == 0) {
