@@ -32,7 +32,8 @@ a = np.array(buf[:], dtype=np.float64).reshape(32, 8)
 tick_us = 0.01
 names = {2: 'lstm1/2 (Ctot 64 @32)', 3: 'lstm7 (96 @32)', 11: 'lstm3 (96 @16)', 12: 'lstm4 (128 @16)',
          14: 'lstm6 (192 @16)', 8: 'lstm5 (256 @8)', 16: 'enc0', 17: 'enc3', 18: 'enc1', 19: 'enc2', 20: 'convt1',
-         21: 'convt2', 22: 'FC', 23: 'fused top', 24: 'unfused top'}
+         21: 'convt2', 22: 'FC', 23: 'fused top', 24: 'unfused top',
+         25: 'fused epilogue: stats | halo | wait+LN | (items) | compose'}
 print('kernel %.2f ms' % k_ms)
 print('%-24s %7s %9s %9s %9s %9s | per-slot ms: pro kloop epi' % ('layer', 'items', 'pro us', 'kloop us', 'epi us', 'stage us'))
 tot = np.zeros(3)

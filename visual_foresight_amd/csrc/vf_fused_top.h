@@ -43,6 +43,7 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
     const int ty0 = (tile_id / p.tilesX) * p.TH, tx0 = (tile_id % p.tilesX) * p.TW;    // input coordinates
     const TileDiv div_tw(p.TW);
 
+    [[maybe_unused]] const unsigned long long tf0 = VF_TS_NOW();
     // ---- 2. bias + exact statistics of this tile (as conv_epilogue<4, EPI_CONVT_RAW_STATS>)
     float bias_g[4];
 #pragma unroll
@@ -74,6 +75,7 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
         __hip_atomic_fetch_add(p.fuse_ready + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();                        // red is dead from here on: the LDS below may cover it
+    [[maybe_unused]] const unsigned long long tf1 = VF_TS_NOW();
 
     // ---- LDS layout of the compositing part
     const int RH = 2 * p.TH, RW = 2 * p.TW;             // output region of this tile
@@ -118,6 +120,7 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
         }
     }
 
+    [[maybe_unused]] const unsigned long long tf2 = VF_TS_NOW();
     // ---- 4. wait for the sample's other tiles, then the LayerNorm of the whole image
     if (wave == 0) {
         unsigned spins = 0;
@@ -154,6 +157,7 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
         return;
     }
     const float mean = s_ln[0], rstd = s_ln[1];
+    [[maybe_unused]] const unsigned long long tf3 = VF_TS_NOW();
 
     // ---- 5. four blocks (4 rows x 16 columns, one per wave) at a time through LDS
     const int nbx = RW / kSumBlockW, nby = RH / kSumBlockH, nblk = nbx * nby;
@@ -196,6 +200,9 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
             }
         }
     }
+    // diagnostic build: row 25 = [stats + publish, halo / kernels to LDS, wait for mates + LayerNorm, compose passes]
+    VF_TS_ADD(25, 0, tf1 - tf0); VF_TS_ADD(25, 1, tf2 - tf1); VF_TS_ADD(25, 2, tf3 - tf2); VF_TS_ADD(25, 4, VF_TS_NOW() - tf3);
+    VF_TS_ADD(25, 3, 1);
 }
 
 // epilogue hook of conv_tile<4, fused_epi(ND, FIRST), 1>: the compositing parameters (a device address inside the
