@@ -213,12 +213,24 @@ def library_hash():
     return h.hexdigest()[:16]
 
 
-def identity_warper(current, reference):
-    """Plug-in for the registration controller in the c3 workload: zero flow (the registration network is
-    not part of the reference snapshot; the device side - warp, window medians, warp error - still runs, at its
-    best case: an identity flow samples every pixel at an integer position).  The c3 line says so."""
+_FLOW_CACHE = {}
+
+
+def smooth_flow_warper(current, reference):
+    """Plug-in for the registration controller in the c3 workload (the registration network is not part of the
+    reference snapshot): a fixed smooth flow field of +-2.5 pixels with fractional parts, so the device side -
+    bilinear warp, window medians, warp error - samples between pixels and near the borders instead of running its
+    best case (an identity flow hits every pixel centre)."""
     ncam, H, W = current.shape[:3]
-    return None, np.zeros((ncam, H, W, 2), np.float32), None
+    key = (ncam, H, W)
+    if key not in _FLOW_CACHE:
+        rows, cols = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing='ij')
+        flow = np.zeros((ncam, H, W, 2), np.float32)
+        for c in range(ncam):
+            flow[c, :, :, 0] = 2.5 * np.sin(rows / 7.0 + c) + 0.37
+            flow[c, :, :, 1] = 2.5 * np.cos(cols / 5.0 - c) - 0.21
+        _FLOW_CACHE[key] = flow
+    return None, _FLOW_CACHE[key], None
 
 
 class Bench(object):
@@ -289,7 +301,7 @@ class Bench(object):
         policy = {'type': cls, 'repeat': 1, 'rejection_sampling': False, 'verbose': False,
                   'predictor_class': HipVPredEvaluation}
         if self.args.workload == 'c3':
-            policy.update(registration_warper=identity_warper, register_region=True)
+            policy.update(registration_warper=smooth_flow_warper, register_region=True)
         if self.draws:
             from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
             policy['predictor_class'] = StochasticHipPredictor.with_options(n_latent=self.draws)
@@ -452,8 +464,8 @@ class Bench(object):
                        'designated_pixels_per_view': self.ndesig, 'precision': primary,
                        'latent_draws_per_action': self.draws,
                        'network': getattr(m['pred'], 'arch', 'cdna'),
-                       **({'registration_flow': 'identity (zero) flow plug-in: vf_register runs at its best case'}
-                          if a.workload == 'c3' else {}),
+                       **({'registration_flow': 'synthetic smooth flow of +-2.5 px (plug-in; the registration '
+                                                'network is absent from the reference)'} if a.workload == 'c3' else {}),
                        'sharding': 'samples over %d rank(s), one all-gather of score rows per CEM iteration%s' %
                                    (self.world, ' (gloo dry run: ranks share a GPU, not a scaling measurement)'
                                     if shared_gpus else ' over RCCL' if self.world > 1 else '')},
