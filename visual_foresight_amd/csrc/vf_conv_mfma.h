@@ -35,14 +35,9 @@
 #define VF_LAUNCH_BOUNDS(...) __launch_bounds__(__VA_ARGS__)
 #endif
 
-#ifndef VF_POLL_SLEEP
-#define VF_POLL_SLEEP 16      // s_sleep units (64 cycles) between two polls of a dependency counter
-#endif
-#ifndef VF_RING_RB2
-#define VF_RING_RB2 0
-#endif
-
 namespace vf {
+
+constexpr int kPollSleep = 16;      // s_sleep units (64 cycles) between two polls of a dependency counter (2, 4: no gain)
 
 #ifdef VF_TILE_STATS
 // Diagnostic build only (hipcc -DVF_TILE_STATS, read by tools/tile_stats.py): where a conv-LSTM item spends
@@ -156,7 +151,7 @@ __device__ __forceinline__ bool late_wait(const PT &p, const int b0, const int b
             }
             ok = __all(ok);
             if (!ok) {
-                __builtin_amdgcn_s_sleep(VF_POLL_SLEEP);
+                __builtin_amdgcn_s_sleep(kPollSleep);
                 if (++spins > kLateSpinLimit ||
                     __hip_atomic_load(p.late_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     if (lane == 0) {
@@ -473,17 +468,19 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
                   "the row-split tiles are conv-LSTM tiles");
     constexpr int WROWS = MREP * 32;    // GEMM rows per wave
     constexpr int GA = SPLIT ? RB : G;  // gates (accumulator tiles) per wave
-    // B through LDS pays for the long-K conv-LSTM tiles; the transposed convs (4 taps, 2-4 chunks)
-    // lose more to its per-tap barrier than they gain, so they read B straight from L1/L2
-    // (the 256-row conv-LSTM tile reads B directly as well: its input tile needs the LDS, and it must keep the
-    // 32-channel chunks of the 128-row tile so that both plans accumulate every output in the same K order)
-    constexpr bool kBRing = SPLIT && (RB == 1 || VF_RING_RB2);
+    // Where the weight operand B comes from:
+    //  * 128- and 64-row conv-LSTM tiles: through LDS - wave w fetches gate w's slice one tap ahead, all four waves
+    //    read all four gates, one barrier per tap (a quarter of the L2 loads of the direct path);
+    //  * 32-row conv-LSTM tile (RB 1): every wave multiplies only ITS gate's slice, so LDS staging shares nothing
+    //    and costs a barrier per tap, while a tap's 16 MFMAs are too short to cover the L2 latency of a one-tap
+    //    look-ahead.  B goes straight from L2 into a register ring of one kernel ROW (5 taps x K8 float4): every
+    //    load is issued five taps before its use, no barrier inside a chunk, same K order (same bits).  (For the
+    //    64-row tile the ring measured 1-3 % slower than LDS: profiles/r03_tile_plan_sweep.txt.)
+    //  * 256-row conv-LSTM tile: straight from L2 with a one-step look-ahead (its input tile needs the LDS, and it
+    //    must keep the 32-channel chunks of the other plans so that every plan accumulates in the same K order);
+    //  * light layers: straight from L2 through a ring of 4 (5) K steps, see kGRing below.
+    constexpr bool kBRing = SPLIT && RB == 1;
     constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1 && !kBRing;
-    // Row-split tiles (32 / 64 rows): a wave only multiplies ITS gates' weight slice, so staging B through LDS
-    // shares nothing (RB 1) or one pair of waves (RB 2) and costs a barrier per tap, while a tap's MFMAs
-    // (16 / 32 per wave) are too short to cover the L2 latency of a one-tap look-ahead.  They read B straight
-    // from L2 into a register ring of one kernel ROW (5 taps x K8 x GA float4): every load is issued five taps
-    // before its use, there is no barrier inside a chunk, and the K order is unchanged (same bits).
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     const int wrow0 = SPLIT ? (wave % RB) * 32 : wave * WROWS;     // first GEMM row of this wave

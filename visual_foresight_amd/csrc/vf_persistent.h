@@ -238,7 +238,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                 }
                 ok = __all(ok);
                 if (!ok) {
-                    __builtin_amdgcn_s_sleep(VF_POLL_SLEEP);
+                    __builtin_amdgcn_s_sleep(kPollSleep);
                     if (++spins > kSpinLimit || ld_relaxed(sched.status) != 0) {
                         if (lane == 0) atomicExch(sched.status, 1);
                         break;
