@@ -368,8 +368,19 @@ class HipVPredEvaluation(object):
                     lane._last_lo, lane._last_M = lo, 0
                     packed.append(torch.empty((0, 1 + self.n_cam * self.cfg.ndesig), dtype=torch.float64,
                                               device=lane.device))
-        rows = self._gather_rccl(packed, M) if self._use_rccl else \
-            np.concatenate([p.cpu().numpy() for p in packed], axis=0)
+        rows = None
+        if self._use_rccl:
+            try:
+                rows = self._gather_rccl(packed, M)
+            except _lib.VfError as e:
+                if self.gather != 'auto':
+                    raise
+                # 'auto' promises scores, not a transport: say so once and gather through the host from now on
+                print('HipVPredEvaluation: grouped RCCL all-gather unavailable (%s); gathering score rows through '
+                      'the host' % e)
+                self._use_rccl = False
+        if rows is None:
+            rows = np.concatenate([p.cpu().numpy() for p in packed], axis=0)
         return np.ascontiguousarray(rows[:, 0]), np.ascontiguousarray(rows[:, 1:])
 
     def _gather_rccl(self, packed, M):
