@@ -10,7 +10,7 @@ import sys
 import numpy as np
 
 
-def run(rank, world, port, out_dir, num_samples, stochastic):
+def run(rank, world, port, out_dir, num_samples, stochastic, vpred_batch_size=0):
     import torch.distributed as dist
     from visual_foresight_amd.policy.cem_controllers import PixelCostController
     from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
@@ -21,6 +21,8 @@ def run(rank, world, port, out_dir, num_samples, stochastic):
     cls = StochasticHipPredictor.with_options(n_latent=3, zdim=4, latent_seed=9) if stochastic else HipVPredEvaluation
     pol = {'predictor_class': cls, 'verbose': False, 'rejection_sampling': False, 'repeat': 1, 'nactions': 3,
            'num_samples': num_samples, 'predictor_propagation': True, 'iterations': 2}
+    if vpred_batch_size:        # shards larger than the engine's batch: only a rank's LAST chunk stays resident
+        pol['vpred_batch_size'] = vpred_batch_size
     ag = {'adim': 4, 'sdim': 5, 'image_height': H, 'image_width': W}
     with contextlib.redirect_stdout(io.StringIO()):
         ctrl = PixelCostController(ag, pol, 0, 1)
@@ -48,4 +50,5 @@ def run(rank, world, port, out_dir, num_samples, stochastic):
 if __name__ == '__main__':
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     rank, world, port, out_dir, num_samples, stochastic = sys.argv[1:7]
-    run(int(rank), int(world), int(port), out_dir, int(num_samples), stochastic == '1')
+    run(int(rank), int(world), int(port), out_dir, int(num_samples), stochastic == '1',
+        int(sys.argv[7]) if len(sys.argv) > 7 else 0)

@@ -125,11 +125,11 @@ def _free_port():
     return port
 
 
-def _launch(world, out_dir, num_samples, stochastic):
+def _launch(world, out_dir, num_samples, stochastic, vpred_batch_size=0):
     port = _free_port()
     env = dict(os.environ, PYTHONPATH=REPO, OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), str(out_dir),
-                               str(num_samples), '1' if stochastic else '0'], env=env)
+                               str(num_samples), '1' if stochastic else '0', str(vpred_batch_size)], env=env)
              for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
@@ -149,6 +149,25 @@ def test_two_ranks_of_the_real_predictor_match_one(tmp_path, num_samples, stocha
             np.testing.assert_array_equal(a['action'], b['action'])
             for k in b['plan_stat']:
                 np.testing.assert_array_equal(a['plan_stat'][k], b['plan_stat'][k])
+            for k in ('best', 'chosen'):
+                if b[k] is None:
+                    assert a[k] is None
+                else:
+                    np.testing.assert_array_equal(a[k], b[k])
+    assert single['log'][-1]['chosen'] is not None
+
+
+@pytest.mark.parametrize('stochastic', [False, True])
+def test_propagation_of_a_sample_that_is_no_longer_resident(tmp_path, stochastic):
+    """``num_samples > vpred_batch_size`` (the reference's 600-sample configs with a 200-sample predictor batch):
+    only every rank's last chunk stays on the device, so the propagated winner usually has to be rolled again -
+    alone, on every rank - and the whole closed loop still equals the unchunked single-process run bit for bit."""
+    single = _launch(1, tmp_path, 14, stochastic)[0]
+    chunked = _launch(1, tmp_path, 14, stochastic, 4)[0]
+    ranks = _launch(2, tmp_path, 14, stochastic, 3)
+    for res in [chunked] + ranks:
+        for a, b in zip(res['log'], single['log']):
+            np.testing.assert_array_equal(a['action'], b['action'])
             for k in ('best', 'chosen'):
                 if b[k] is None:
                     assert a[k] is None
@@ -195,10 +214,12 @@ def test_n_gpus_in_process_lanes_match_one_engine():
         np.testing.assert_array_equal(got_pt, want_pt)
         sizes = [l._last_lo for l in lanes._lanes]
         assert sizes == sorted(sizes) and sizes[0] <= sizes[-1]
-        if bs == M:         # every lane's whole shard is resident: any sample can be fetched
-            for idx in (0, M // 2, M - 1):
-                np.testing.assert_array_equal(lanes.fetch_pixel_distributions(idx),
-                                              want_out['predicted_pixel_distributions'][idx])
+        # whole shards resident (bs == M) or only every lane's last chunk (a sample nobody holds is rolled again)
+        for idx in (0, M // 2, M - 1, 3, 3):
+            np.testing.assert_array_equal(lanes.fetch_pixel_distributions(idx),
+                                          want_out['predicted_pixel_distributions'][idx])
+        with pytest.raises(IndexError):
+            lanes.fetch_pixel_distributions(M)
         out = lanes(ctx, {'actions': actions})
         for k in want_out:
             np.testing.assert_array_equal(out[k], want_out[k])

@@ -115,6 +115,7 @@ class HipVPredEvaluation(object):
         self._ctx_key = None
         self._last_M = 0
         self._last_lo = 0
+        self._last_prepared = None      # (engine context, sequences, M) of the last score() / __call__
         # in-process multi-GPU: this object is lane 0, the others are plain engines on the following devices
         self.gather = str(hp.get('gather', 'auto'))         # 'auto' | 'rccl' | 'host'
         if self.gather not in ('auto', 'rccl', 'host'):
@@ -291,17 +292,11 @@ class HipVPredEvaluation(object):
         """(context, actions[n]) -> (engine context, sequences[n * n_draws])."""
         return context, actions
 
-    def _score_device(self, context, actions, goal_pix, finalweight, index_base=0, task_weights=None):
-        """Roll ALL given actions on this rank -> device tensors (scores[n], per_task[n, ncam*nd]).
-
-        ``index_base`` is the global index of ``actions[0]`` (what ``fetch_pixel_distributions`` is asked for).
-        """
-        context, seqs = self._prepare(context, actions)
-        return self._score_prepared(context, seqs, actions.shape[0], goal_pix, finalweight, index_base, task_weights)
-
     def _score_prepared(self, context, seqs, n, goal_pix, finalweight, index_base=0, task_weights=None):
-        """Engine half of ``_score_device``: ``seqs [n * n_draws, T, engine adim]`` as ``_prepare`` returns them.
-        Only enqueues work on this engine's device (the uploads of pageable host arrays aside)."""
+        """Roll ``seqs [n * n_draws, T, engine adim]`` (as ``_prepare`` returns them) on this engine -> device tensors
+        (scores[n], per_task[n, ncam*nd]).  ``index_base`` is the global index of the first action (what
+        ``fetch_pixel_distributions`` is asked for).  Only enqueues work on this engine's device (the uploads of
+        pageable host arrays aside)."""
         torch = self._torch
         ntask = self.n_cam * self.cfg.ndesig
         nd = self.n_draws
@@ -328,8 +323,13 @@ class HipVPredEvaluation(object):
         actions = self._check_actions(inputs['actions'])
         M = actions.shape[0]
         rank, world = _dist_info()
+        # every rank / lane slices the SAME prepared sequences (latent draws included); they are also what a
+        # propagation fetch of a sample that is no longer resident is re-rolled from
+        ctx_p, seqs = self._prepare(context, actions)
+        self._last_prepared = (ctx_p, seqs, M)
+        nd = self.n_draws
         if self._lanes:
-            scores_np, per_task_np = self._score_lanes(context, actions, goal_pix, finalweight, task_weights)
+            scores_np, per_task_np = self._score_lanes(ctx_p, seqs, M, goal_pix, finalweight, task_weights)
             self._check_scores(scores_np)
             if only_take_first_view:
                 per_task_np = per_task_np[:, :1]
@@ -337,8 +337,8 @@ class HipVPredEvaluation(object):
             return scores_np, per_task_np
         lo, hi = shard_bounds(M, rank, world)
         with self._torch.cuda.device(self.device):
-            scores, per_task = self._score_device(context, actions[lo:hi], goal_pix, finalweight, index_base=lo,
-                                                  task_weights=task_weights)
+            scores, per_task = self._score_prepared(ctx_p, seqs[lo * nd:hi * nd], hi - lo, goal_pix, finalweight,
+                                                    index_base=lo, task_weights=task_weights)
             if world > 1:
                 scores, per_task = self._all_gather(scores, per_task, M, world)
             scores_np = scores.cpu().numpy()
@@ -350,12 +350,12 @@ class HipVPredEvaluation(object):
         return scores_np, per_task_np
 
     # ------------------------------------------------------------------ in-process multi-GPU (n_gpus > 1)
-    def _score_lanes(self, context, actions, goal_pix, finalweight, task_weights):
-        """Lane i rolls the contiguous shard ``shard_bounds(M, i, n_gpus)`` on its own device; every lane's work is
-        enqueued before anything is waited for, then one gather of the ``[M, 1 + tasks]`` score rows."""
+    def _score_lanes(self, context, seqs, M, goal_pix, finalweight, task_weights):
+        """Lane i rolls the contiguous shard ``shard_bounds(M, i, n_gpus)`` of the prepared sequences on its own
+        device; every lane's work is enqueued before anything is waited for, then one gather of the
+        ``[M, 1 + tasks]`` score rows."""
         torch = self._torch
-        lanes, M, nd = self._lanes, actions.shape[0], self.n_draws
-        context, seqs = self._prepare(context, actions)
+        lanes, nd = self._lanes, self.n_draws
         packed = []
         for i, lane in enumerate(lanes):
             lo, hi = shard_bounds(M, i, len(lanes))
@@ -418,12 +418,21 @@ class HipVPredEvaluation(object):
         return out[:, 0].contiguous(), out[:, 1:].contiguous()
 
     def fetch_pixel_distributions(self, sample_index):
-        """Normalised distributions ``[T, ncam, H, W, ndesig]`` of one action of the last rollout (its first
-        latent draw).  Under ``torch.distributed`` the owning rank exports it and a tiny all-reduce hands it
-        to the others (everybody else adds zeros)."""
+        """Normalised distributions ``[T, ncam, H, W, ndesig]`` of one action of the last ``score()`` call (its first
+        latent draw) - what ``predictor_propagation`` feeds back as the next context (reference
+        ``pixel_cost_controller.py:161-165``, where all predicted distributions sit on the host).
+
+        Here only the chunk rolled last stays resident per engine.  The engine that still holds the sample exports
+        it (under ``torch.distributed`` a small all-reduce hands it to the other ranks).  A sample nobody holds any
+        more - ``num_samples > vpred_batch_size``, e.g. the reference's 600-sample RoboNet configs - is simply rolled
+        again, alone: a sample's arithmetic does not depend on the batch it is rolled in, so the result is
+        bit-identical to the first pass, and every rank can do it locally without a collective."""
         torch, c = self._torch, self.cfg
         T = self.sequence_length - self.n_context
         rank, world = _dist_info()
+        prepared = getattr(self, '_last_prepared', None)
+        if prepared is not None and not 0 <= sample_index < prepared[2]:
+            raise IndexError('sample %d outside the last scoring call (%d actions)' % (sample_index, prepared[2]))
         for lane in (self._lanes or [])[1:]:        # in-process multi-GPU: the lane that rolled it exports it
             if 0 <= sample_index - lane._last_lo < lane._last_M:
                 return lane.fetch_pixel_distributions(sample_index)
@@ -436,9 +445,7 @@ class HipVPredEvaluation(object):
                                                 None, self._stream()))
         if world > 1:
             import torch.distributed as dist
-            # the "somebody holds it" flag travels with the data (one extra element), so a sample no rank has
-            # resident - an index out of range, or a shard larger than run_batch_size - raises on EVERY rank instead
-            # of handing all-zero distributions to the propagation
+            # the "somebody holds it" flag travels with the data (one extra element)
             flat = torch.cat([out.reshape(-1), torch.tensor([1.0 if have else 0.0], device=self.device)])
             if dist.get_backend() == 'gloo':
                 host = flat.cpu()
@@ -446,13 +453,35 @@ class HipVPredEvaluation(object):
                 flat = host.to(self.device)
             else:
                 dist.all_reduce(flat)   # exactly one rank holds the sample, the others add zeros
-            if float(flat[-1].item()) < 0.5:
-                raise IndexError('sample %d is not resident on any rank' % sample_index)
-            out = flat[:-1].reshape(out.shape)
-        elif not have:
+            if float(flat[-1].item()) >= 0.5:
+                return flat[:-1].reshape(out.shape).cpu().numpy()
+            have = False                # nobody holds it: every rank rolls it again below (identical results)
+        if have:
+            return out.cpu().numpy()
+        if prepared is None:
             raise IndexError('sample %d is not resident (last chunk holds [%d, %d))'
                              % (sample_index, self._last_lo, self._last_lo + self._last_M))
-        return out.cpu().numpy()
+        return self._reroll_one(sample_index, out)
+
+    def _reroll_one(self, sample_index, out):
+        """Roll action ``sample_index`` of the last scoring call again (its ``n_draws`` sequences, alone) and export
+        the first draw's distributions into ``out``."""
+        torch, nd = self._torch, self.n_draws
+        ctx_p, seqs, _ = self._last_prepared
+        ntask = self.n_cam * self.cfg.ndesig
+        with torch.cuda.device(self.device):
+            self._set_context(ctx_p)
+            seq = torch.from_numpy(np.ascontiguousarray(seqs[sample_index * nd:(sample_index + 1) * nd],
+                                                        dtype=np.float32)).to(self.device)
+            scores = torch.empty(1, dtype=torch.float64, device=self.device)
+            per_task = torch.empty((1, ntask), dtype=torch.float64, device=self.device)
+            self._rollout_chunk(seq, np.zeros((self.n_cam, self.cfg.ndesig, 2), np.int32), 1.0, scores, per_task)
+            # under torch.distributed EVERY rank has just rolled it: nobody may claim to be "the" holder afterwards
+            # (the fetch's all-reduce adds the holders' copies), so the ranks keep nothing resident
+            self._last_lo, self._last_M = sample_index, (1 if _dist_info()[1] == 1 else 0)
+            _lib.check(self._libh.vf_export(self._handle, 0, 1, None, out.data_ptr(), None, self._stream()))
+            self._check_scores(scores.cpu().numpy())
+            return out.cpu().numpy()
 
     # ------------------------------------------------------------------ registration
     def register(self, current, reference, flow, pix, region=0, clip_sub=1, want_warped=False):
@@ -538,6 +567,7 @@ class HipVPredEvaluation(object):
         (``[M, T, ncam, H, W, C]``; with latent draws, the first draw of every action)."""
         actions = self._check_actions(inputs['actions'])
         context, seqs = self._prepare(context, actions)
+        self._last_prepared = (context, seqs, actions.shape[0])
         if self._lanes:     # lane i materialises its contiguous shard (one lane after the other: the D2H dominates)
             M, n, nd = actions.shape[0], len(self._lanes), self.n_draws
             parts = []
