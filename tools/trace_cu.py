@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""GPU box diagnostic: what the two resident workgroups of a CU are doing, and how fast the matrix pipe runs meanwhile.
+
+Needs the event-log build of the library:
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC -DVF_TRACE -o build/ab/trace.so \
+          visual_foresight_amd/csrc/vf_engine.hip
+    VF_LIBRARY=build/ab/trace.so python tools/trace_cu.py [M] [precision]
+Every workgroup of the persistent rollout logs (time, event) pairs; this script turns each log into state intervals
+(K loop / staging / mid-item wait / prologue / epilogue / light item / dependency wait), pairs the workgroups that share
+a CU, and reports (a) the share of the launch each JOINT state takes, (b) the MFMA issue rate of a K loop while the
+other workgroup is in its own K loop and while it is not (least squares over all K-loop intervals).
+"""
+import ctypes
+import os
+import sys
+from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from visual_foresight_amd import _lib  # noqa: E402
+from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation  # noqa: E402
+
+M, T = int(sys.argv[1]) if len(sys.argv) > 1 else 200, 13
+prec = sys.argv[2] if len(sys.argv) > 2 else 'fp32'
+WGS, MAXE = 512, 8192
+TICK_US = 0.01
+TR_TICKET, TR_DONE, TR_STAGE, TR_KLOOP, TR_LATE, TR_LATE_END, TR_EPI, TR_MFMAS, TR_HWID, TR_RUN = 1, 3, 10, 11, 12, 13, 14, 15, 20, 32
+PH_LSTM = 0
+PH_NAMES = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED']
+
+pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2, precision=prec)).restore()
+rs = np.random.RandomState(0)
+d = np.zeros((2, 1, 64, 64, 1), np.float32)
+d[:, 0, 32, 32, 0] = 1
+ctx = {'context_frames': rs.randint(0, 256, (2, 1, 64, 64, 3)).astype(np.uint8), 'context_actions': np.zeros((1, 4)),
+       'context_states': np.zeros((2, 5)), 'context_pixel_distributions': d}
+acts = rs.normal(0, 0.05, (M, T, 4))
+lib = _lib.load_library()
+pred.score(ctx, {'actions': acts}, [[[16, 48]]])
+pred.set_profiling(True)
+pred.score(ctx, {'actions': acts}, [[[16, 48]]])
+k_ms = pred.get_profile()[0]
+ev = np.zeros(WGS * MAXE, np.uint64)
+cnt = np.zeros(WGS, np.uint32)
+lib.vf_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+_lib.check(lib.vf_debug_trace(ev.ctypes.data, cnt.ctypes.data))
+ev = ev.reshape(WGS, MAXE)
+print('kernel %.2f ms (event-log build), M = %d, %s; events per workgroup: mean %.0f max %d' % (k_ms, M, prec, cnt.mean(), cnt.max()))
+
+# ---- per workgroup: events -> intervals (t0, t1, state, mfmas)
+wg_cu, wg_iv = {}, {}
+t_min, t_max = None, None
+for w in range(WGS):
+    n = int(cnt[w])
+    if n == 0:
+        continue
+    codes = (ev[w, :n] & np.uint64(255)).astype(np.int64)
+    vals = (ev[w, :n] >> np.uint64(8)).astype(np.int64)
+    iv = []
+    state, t_state, lstm, mf = None, None, False, 0
+
+    def close(t, new_state):
+        global state, t_state
+        if state is not None and t > t_state:
+            iv.append((t_state, t, state, mf if state == 'K' else 0))
+        state, t_state = new_state, t
+
+    for c, v in zip(codes, vals):
+        if c == TR_HWID:
+            wg_cu[w] = (int(v >> 32), int((v >> 8) & 0xFF))
+        elif c == TR_MFMAS:
+            mf = int(v)
+        elif c == TR_TICKET:
+            close(v, 'wait')
+        elif c >= TR_RUN:
+            lstm = (c - TR_RUN) == PH_LSTM
+            close(v, 'pro' if lstm else 'light:' + PH_NAMES[c - TR_RUN])
+        elif c == TR_DONE:
+            close(v, 'sched')
+        elif lstm:
+            if c == TR_STAGE:
+                close(v, 'stage')
+            elif c == TR_KLOOP:
+                close(v, 'K')
+            elif c == TR_LATE:
+                close(v, 'late')
+            elif c == TR_LATE_END:
+                close(v, 'stage')
+            elif c == TR_EPI:
+                close(v, 'epi')
+    wg_iv[w] = iv
+    if iv:
+        t_min = iv[0][0] if t_min is None else min(t_min, iv[0][0])
+        t_max = iv[-1][1] if t_max is None else max(t_max, iv[-1][1])
+
+span = (t_max - t_min) * TICK_US
+print('traced span %.2f ms' % (span / 1e3))
+tot = defaultdict(float)
+for w, iv in wg_iv.items():
+    for t0, t1, s, _ in iv:
+        tot[s.split(':')[0] if s.startswith('light') else s] += (t1 - t0) * TICK_US
+nw = len(wg_iv)
+print('per workgroup slot (mean over %d), ms: ' % nw + '  '.join('%s %.2f' % (k, v / nw / 1e3) for k, v in sorted(tot.items())))
+light = defaultdict(float)
+for w, iv in wg_iv.items():
+    for t0, t1, s, _ in iv:
+        if s.startswith('light:'):
+            light[s[6:]] += (t1 - t0) * TICK_US
+print('   light items by type, ms per slot: ' + '  '.join('%s %.2f' % (k, v / nw / 1e3) for k, v in sorted(light.items())))
+
+# ---- pair the workgroups of a CU
+by_cu = defaultdict(list)
+for w, cu in wg_cu.items():
+    by_cu[cu].append(w)
+pairs = [ws for ws in by_cu.values() if len(ws) == 2]
+print('%d CUs host exactly two workgroups (%d CUs seen)' % (len(pairs), len(by_cu)))
+
+
+def simplify(s):
+    return 'K' if s == 'K' else ('idle' if s in ('wait', 'late', 'sched') else 'other')
+
+
+joint = defaultdict(float)
+X, Y = [], []       # per K interval: (overlap with the partner's K, rest), MFMAs
+for a, b in pairs:
+    for me, other in ((a, b), (b, a)):
+        oiv = wg_iv[other]
+        j = 0
+        for t0, t1, s, mf in wg_iv[me]:
+            # walk the partner's intervals overlapping [t0, t1)
+            while j < len(oiv) and oiv[j][1] <= t0:
+                j += 1
+            k = j
+            ovK = 0
+            cover = 0
+            while k < len(oiv) and oiv[k][0] < t1:
+                lo, hi = max(t0, oiv[k][0]), min(t1, oiv[k][1])
+                if hi > lo:
+                    if me == a:
+                        joint[(simplify(s), simplify(oiv[k][2]))] += (hi - lo) * TICK_US
+                    if oiv[k][2] == 'K':
+                        ovK += hi - lo
+                    cover += hi - lo
+                k += 1
+            if s == 'K' and mf > 0:
+                X.append((ovK * TICK_US, (t1 - t0 - ovK) * TICK_US))
+                Y.append(mf)
+npair = len(pairs)
+print('joint state of a CU, %% of the traced span (K = issuing MFMAs of a conv-LSTM K loop, idle = waiting for a ticket / '
+      'dependency / late input, other = prologue, staging, epilogue, light items):')
+keys = ['K', 'other', 'idle']
+sym = defaultdict(float)
+for (s1, s2), v in joint.items():
+    sym[tuple(sorted((s1, s2)))] += v
+for k, v in sorted(sym.items(), key=lambda kv: -kv[1]):
+    print('   %-14s %5.1f %%' % ('%s + %s' % k, 100.0 * v / npair / span))
+X, Y = np.array(X), np.array(Y, dtype=np.float64)
+r, *_ = np.linalg.lstsq(X, Y, rcond=None)
+GHZ = 2.38
+print('MFMA issue rate of one wave in its K loop (least squares over %d K-loop intervals):' % len(Y))
+print('   partner also in its K loop: %.2f MFMAs/us per wave -> two waves use %.3f of the SIMD\'s matrix pipe' % (r[0], 2 * r[0] * 64 / (GHZ * 1e3)))
+print('   partner NOT in a K loop:    %.2f MFMAs/us per wave -> one wave uses  %.3f of the SIMD\'s matrix pipe' % (r[1], r[1] * 64 / (GHZ * 1e3)))
+print('   (fp32 32x32x2 MFMA = 64 cycles; %.2f GHz -> %.1f MFMAs/us per SIMD at most)' % (GHZ, GHZ * 1e3 / 64))
+tK2 = sym[('K', 'K')] / npair
+tK1 = (sym[('K', 'other')] + sym[('K', 'idle')]) / npair
+print('   pipe time accounted: both-K %.1f ms x %.3f + one-K %.1f ms x %.3f = %.1f ms of MFMA work per SIMD' % (
+    tK2 / 1e3, 2 * r[0] * 64 / (GHZ * 1e3), tK1 / 1e3, r[1] * 64 / (GHZ * 1e3),
+    (tK2 * 2 * r[0] + tK1 * r[1]) * 64 / (GHZ * 1e3) / 1e3))

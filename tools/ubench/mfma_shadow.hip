@@ -72,12 +72,69 @@ static void run(const float *in, float *out, unsigned long long *cyc, int W) {
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return; }
     std::vector<unsigned long long> h(blocks * 4 * W);
     (void)hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
-    double sum = 0;
-    for (auto v : h) sum += (double)v;
+    double sum = 0, mx = 0;
+    for (auto v : h) { sum += (double)v; mx = mx > (double)v ? mx : (double)v; }
     const double per_wave = sum / h.size();                 // cycles of one wave for iters * 4 MFMAs
-    const double cyc_per_mfma = per_wave / (iters * 4.0);
-    printf("  N=%2d W=%d: %7.1f cycles per MFMA per wave, pipe utilisation %.3f\n", N, W, cyc_per_mfma,
-           64.0 * W / cyc_per_mfma);
+    // waves that win the arbitration finish early, so the utilisation is taken from the LAST wave to finish
+    printf("  N=%2d W=%d: %7.1f cycles per MFMA per wave (mean), %7.1f (slowest wave): pipe utilisation %.3f\n", N, W,
+           per_wave / (iters * 4.0), mx / (iters * 4.0), 64.0 * W * iters * 4.0 / mx);
+}
+
+// Two waves per SIMD with different jobs: waves 0-3 (one per SIMD) only issue MFMAs, waves 4-7 only filler
+// instructions; each group is timed alone and together.
+template <int KIND>
+__global__ __launch_bounds__(512) void mix2(const float *in, float *out, unsigned long long *cyc, int itersA, int itersB) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6;
+    const float a = in[threadIdx.x & 255], b = in[256 + (threadIdx.x & 255)];
+    lds[threadIdx.x] = a;
+    const unsigned lds_addr = (threadIdx.x & 63) * 16;
+    const float *gp = in + (threadIdx.x & 63) * 4;
+    float res = 0.f;
+    __syncthreads();
+    const unsigned long long t0 = clock64();
+    if (wave < 4) {
+        f32x16 acc0, acc1, acc2, acc3;
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+        for (int it = 0; it < itersA; ++it) { MFMA(acc0); MFMA(acc1); MFMA(acc2); MFMA(acc3); }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        for (int r = 0; r < 16; ++r) res += acc0[r] + acc1[r] + acc2[r] + acc3[r];
+    } else {
+        float x[8];
+        double xd[4];
+        f32x4 d[4];
+        for (int i = 0; i < 8; ++i) x[i] = a * (i + 1);
+        for (int i = 0; i < 4; ++i) { xd[i] = a * (i + 1); d[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int it = 0; it < itersB; ++it) {
+            if constexpr (KIND == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (KIND == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            filler<KIND, 8>(x, xd, d, a, b, lds_addr, gp);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        for (int i = 0; i < 8; ++i) res += x[i];
+        for (int i = 0; i < 4; ++i) res += (float)xd[i] + d[i][0] + d[i][3];
+    }
+    const unsigned long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = res;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+template <int KIND>
+static void run_mix(const char *name, const float *in, float *out, unsigned long long *cyc) {
+    const int blocks = 256, itA = 4000, itB = 4000;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mix2<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    double res[3][2];
+    for (int c = 0; c < 3; ++c) {           // 0: MFMA waves alone, 1: filler waves alone, 2: together
+        hipLaunchKernelGGL((mix2<KIND>), dim3(blocks), dim3(512), 100 * 1024, 0, in, out, cyc, c == 1 ? 0 : itA, c == 0 ? 0 : itB);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return; }
+        std::vector<unsigned long long> h(blocks * 8);
+        (void)hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+        double sa = 0, sb = 0;
+        for (int i = 0; i < blocks * 8; ++i) ((i & 7) < 4 ? sa : sb) += (double)h[i];
+        res[c][0] = sa / (blocks * 4); res[c][1] = sb / (blocks * 4);
+    }
+    printf("  %-28s MFMA waves: %6.1f -> %6.1f cycles per MFMA;  filler waves: %6.2f -> %6.2f cycles per instruction\n", name,
+           res[0][0] / (itA * 4.0), res[2][0] / (itA * 4.0), res[1][1] / (itB * 8.0), res[2][1] / (itB * 8.0));
 }
 
 template <int KIND>
@@ -110,5 +167,11 @@ int main() {
     sweep<2>("filler global_load_dwordx4 (L2 hit)", in, out, cyc);
     sweep<3>("filler v_exp_f32", in, out, cyc);
     sweep<4>("filler v_fma_f64", in, out, cyc);
+    printf("two waves per SIMD, one issues only MFMAs, the other only filler instructions (alone -> together)\n");
+    run_mix<0>("v_fma_f32", in, out, cyc);
+    run_mix<1>("ds_read_b128", in, out, cyc);
+    run_mix<2>("global_load_dwordx4 (L2 hit)", in, out, cyc);
+    run_mix<3>("v_exp_f32", in, out, cyc);
+    run_mix<4>("v_fma_f64", in, out, cyc);
     return 0;
 }

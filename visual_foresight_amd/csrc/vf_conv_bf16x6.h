@@ -43,7 +43,8 @@ __host__ __device__ inline size_t bf16x6_lds_bytes(int NI, int LH, int LW) {
 }
 
 template <int MREP, class PT>
-__device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx, const int by, float *smem) {
+__device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx_, const int by_, float *smem) {
+    const int bx = __builtin_amdgcn_readfirstlane(bx_), by = __builtin_amdgcn_readfirstlane(by_);   // (see conv_tile)
     constexpr int G = 4;
     constexpr int WROWS = MREP * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

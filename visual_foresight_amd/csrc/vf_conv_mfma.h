@@ -51,6 +51,35 @@ __device__ unsigned long long g_tile_clk[32][8];
 #define VF_TS_ADD(KEY_, SLOT_, DT_) do { } while (0)
 #endif
 
+#ifdef VF_TRACE
+// Diagnostic build only (hipcc -DVF_TRACE, read by tools/trace_cu.py): a per-workgroup event log of the persistent
+// rollout - what every resident workgroup is doing when (ticket, dependency wait, prologue, staging, K loop, mid-item
+// wait, epilogue, publish) - from which the co-residency statistics of a CU (both workgroups in their K loops / one /
+// none, and the MFMA rate in each case) are reconstructed.  One 64-bit word per event: (wall_clock64 << 8) | code, or
+// (value << 8) | code for the value-carrying codes.  The event count lives in word 5 of the LDS control block.
+constexpr int kTraceMax = 8192;
+constexpr int kTraceWgs = 512;
+__device__ unsigned long long g_trace[(size_t)kTraceWgs * kTraceMax];
+__device__ unsigned g_trace_n[kTraceWgs];
+enum TraceCode { TR_TICKET = 1, TR_DONE = 3, TR_STAGE = 10, TR_KLOOP = 11, TR_LATE = 12, TR_LATE_END = 13, TR_EPI = 14,
+                 TR_MFMAS = 15 /* value: MFMAs per wave per chunk */, TR_HWID = 20 /* value: xcc << 16 | hw_id */,
+                 TR_RUN = 32 /* + phase type */ };
+__device__ __forceinline__ void vf_trace(const unsigned code, const unsigned long long val = ~0ull) {
+    if (threadIdx.x == 0 && blockIdx.x < kTraceWgs) {
+        extern __shared__ __attribute__((aligned(16))) float smem_all[];
+        int *ctl = reinterpret_cast<int *>(smem_all);
+        const int n = ctl[5];
+        if (n < kTraceMax) {
+            g_trace[(size_t)blockIdx.x * kTraceMax + n] = ((val == ~0ull ? wall_clock64() : val) << 8) | code;
+            ctl[5] = n + 1;
+        }
+    }
+}
+#define VF_TRACE_EVT(...) vf_trace(__VA_ARGS__)
+#else
+#define VF_TRACE_EVT(...) do { } while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -173,11 +202,27 @@ __device__ __forceinline__ bool late_wait(const PT &p, const int b0, const int b
 }
 
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// Gate non-linearities.  The quotients use the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division: a
+// correctly rounded division is a ten-instruction sequence (two v_div_scale, v_rcp, four fmas, v_div_fmas, v_div_fixup),
+// five of them per cell were a third of the conv-LSTM epilogue's instructions, and an epilogue next to a K loop runs
+// at about one VALU instruction per 40 cycles (tools/ubench/mfma_shadow.hip).  The exponential is the hardware one
+// (v_exp_f32) either way, so the gate math was never correctly rounded; tools/precision_check.py has the distances
+// to the float64 oracle.  Every tile plan and launch strategy shares these two functions: results stay bit-identical
+// among themselves.
+#ifdef VF_GATE_DIV
+__device__ __forceinline__ float rcpf_(float x) { return 1.0f / x; }
+#else
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
-    // tanh via exp; exact enough in fp32 (|err| ~ 1 ulp of the quotient), saturates cleanly
+    // tanh via exp; saturates cleanly
     float e = __expf(-2.0f * fabsf(x));
+#ifdef VF_GATE_DIV
     float t = (1.0f - e) / (1.0f + e);
+#else
+    float t = (1.0f - e) * rcpf_(1.0f + e);
+#endif
     return copysignf(t, x);
 }
 
@@ -201,6 +246,20 @@ __device__ __forceinline__ long long wave_sum(long long v) {
 constexpr double kStatScale = 4294967296.0;         // 2^32
 __device__ __forceinline__ long long stat_q(const float v) { return (long long)((double)v * kStatScale); }
 __device__ __forceinline__ long long stat_q2(const float v) { return (long long)((double)v * (double)v * kStatScale); }
+// The same integers summed in float64: trunc(v * 2^32) and trunc(v^2 * 2^32) are integers below 2^32 * max(|v|, v^2),
+// and float64 adds integers exactly below 2^53 - so for bounded outputs (|v| <= 1: a conv-LSTM's h = tanh(c) * sigmoid(o))
+// a lane can add its terms as doubles (4 instructions each) and convert the lane total to an integer once, instead
+// of one emulated float64 -> int64 conversion (~10 instructions) per term.  Same integers, hence the same bits.
+struct StatSumD {
+    double s = 0.0, q = 0.0;
+    __device__ __forceinline__ void add(const float v) {
+        const double d = (double)v;
+        s += __builtin_trunc(d * kStatScale);
+        q += __builtin_trunc(d * d * kStatScale);
+    }
+    __device__ __forceinline__ long long sum() const { return (long long)s; }
+    __device__ __forceinline__ long long sumsq() const { return (long long)q; }
+};
 // mean / rstd from the integer totals of n = 1 / inv_n elements
 __device__ __forceinline__ void ln_from_totals(const long long su, const long long sq, const float inv_n,
                                                float &mean, float &rstd) {
@@ -263,6 +322,52 @@ __device__ __forceinline__ void ln_table(const PT &p, const int bimg0, float *ln
     }
 }
 
+// One conv-LSTM cell: gate pre-activations (bias added) + previous cell state -> new cell state, new hidden state.
+// The ONE place the gate math lives: every tile plan, both precision modes and both launch strategies call it with the
+// same values, hence produce the same bits.
+__device__ __forceinline__ void lstm_cell(const float gi, const float gj, const float gf, const float go,
+                                          const float c_old, float &c_new, float &h_new) {
+    c_new = fmaf(c_old, sigmoidf_(gf + 1.0f), sigmoidf_(gi) * tanhf_(gj));
+    h_new = tanhf_(c_new) * sigmoidf_(go);
+}
+
+// Where GEMM row `row` of a tile lands, for the cell update of the conv-LSTM epilogues.  One image per workgroup
+// (NI == 1, every conv-LSTM tile of a 16x16 or larger layer): the sample is wave-uniform, so the three state pointers are
+// scalar bases and a lane only computes a 32-bit in-image offset; several whole images per workgroup (the 8x8 layer):
+// the sample index is per lane and its stride is applied with one wide multiply.
+struct LstmRowAddr {
+    bool ok;
+    const float *cin;
+    float *cst, *hout;
+    unsigned off;
+};
+template <bool NI1, class PT>
+__device__ __forceinline__ LstmRowAddr lstm_row_addr(const PT &p, const int row, const int ch, const int bimg0,
+                                                      const int ty0, const int tx0, const long long img_elems,
+                                                      const TileDiv &div_rpi, const TileDiv &div_tw) {
+    LstmRowAddr a;
+    if constexpr (NI1) {
+        const int yy = div_tw.div(row);
+        const int y = ty0 + yy, x = tx0 + row - yy * p.TW;
+        a.ok = row < p.TH * p.TW && bimg0 < p.B && y < p.Hout && x < p.Wout;
+        a.off = (unsigned)((y * p.Wout + x) * p.Cout + ch);
+        a.cin = p.cstate_in + (long long)bimg0 * p.cin_bstride;
+        a.cst = p.cstate + (long long)bimg0 * img_elems;
+        a.hout = p.out + (long long)bimg0 * img_elems;
+    } else {
+        const int img = div_rpi.div(row), rem = row - img * p.RPI;
+        const int yy = div_tw.div(rem);
+        const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
+        const int b = bimg0 + img;
+        a.ok = img < p.NI && rem < p.TH * p.TW && b < p.B && y < p.Hout && x < p.Wout;
+        a.off = (unsigned)((y * p.Wout + x) * p.Cout + ch);
+        a.cin = p.cstate_in + (long long)b * p.cin_bstride;
+        a.cst = p.cstate + (long long)b * img_elems;
+        a.hout = p.out + (long long)b * img_elems;
+    }
+    return a;
+}
+
 // Shared epilogue of the fp32 and the split-bf16 tiles: accumulators (MFMA 32x32 C layout) ->
 // bias / activation / cell update / stores + deterministic LayerNorm partial sums.
 template <int G, int EPI, int MREP, class PT>
@@ -290,10 +395,34 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
     for (int g = 0; g < G; ++g) bias_g[g] = (EPI == EPI_PARTIAL) ? 0.f : p.bias[(cg * G + g) * 32 + n];
 
     long long ssum = 0, ssq = 0;            // exact LayerNorm partials over this lane's outputs
+    [[maybe_unused]] StatSumD hstat;        // (conv-LSTM: the same integers, summed in float64)
+    [[maybe_unused]] const long long img_elems = (long long)p.Hout * p.Wout * p.Cout;
     const TileDiv div_rpi(p.RPI), div_tw(p.TW);
 
+    if constexpr (EPI == EPI_LSTM) {
+        auto cells = [&](auto ni1) {
 #pragma unroll
-    for (int m = 0; m < MREP; ++m) {
+            for (int m = 0; m < MREP; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wave * WROWS + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const LstmRowAddr a = lstm_row_addr<decltype(ni1)::value>(p, row, ch, bimg0, ty0, tx0, img_elems,
+                                                                              div_rpi, div_tw);
+                    if (!a.ok) continue;
+                    float c_new, h_new;
+                    lstm_cell(acc[m][0][r] + bias_g[0], acc[m][1 % G][r] + bias_g[1 % G],
+                              acc[m][2 % G][r] + bias_g[2 % G], acc[m][3 % G][r] + bias_g[3 % G], a.cin[a.off],
+                              c_new, h_new);
+                    a.cst[a.off] = c_new;
+                    a.hout[a.off] = h_new;
+                    hstat.add(h_new);
+                }
+            }
+        };
+        if (p.NI == 1) cells(std::true_type{}); else cells(std::false_type{});
+    }
+#pragma unroll
+    for (int m = 0; m < (EPI == EPI_LSTM ? 0 : MREP); ++m) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wave * WROWS + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -304,18 +433,7 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
             const bool ok = img < p.NI && rem < px_per_img && b < p.B && y < p.Hout && x < p.Wout;
             if (!ok) continue;
             if constexpr (EPI == EPI_LSTM) {
-                const long long o = (((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch;
-                const float gi = acc[m][0][r] + bias_g[0];
-                const float gj = acc[m][1 % G][r] + bias_g[1 % G];
-                const float gf = acc[m][2 % G][r] + bias_g[2 % G];
-                const float go = acc[m][3 % G][r] + bias_g[3 % G];
-                const float c_old = p.cstate_in[(long long)b * p.cin_bstride +
-                                                ((long long)y * p.Wout + x) * p.Cout + ch];
-                const float c_new = fmaf(c_old, sigmoidf_(gf + 1.0f), sigmoidf_(gi) * tanhf_(gj));
-                const float h_new = tanhf_(c_new) * sigmoidf_(go);
-                p.cstate[o] = c_new;
-                p.out[o] = h_new;
-                ssum += stat_q(h_new); ssq += stat_q2(h_new);
+                // (handled by the dedicated loop above)
             } else if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_RAW_STATS) {
                 if (ch < p.Cout) {
                     float v = acc[m][0][r] + bias_g[0];
@@ -342,6 +460,7 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
         }
     }
 
+    if constexpr (EPI == EPI_LSTM) { ssum = hstat.sum(); ssq = hstat.sumsq(); }
     if constexpr (EPI == EPI_LSTM || EPI == EPI_RAW_STATS || EPI == EPI_CONVT_RAW_STATS) {
         // exact integer reduction: lane -> wave (xor butterfly) -> waves -> one partial per tile
         const long long wsum = wave_sum(ssum), wsq = wave_sum(ssq);
@@ -388,7 +507,6 @@ __device__ __forceinline__ void lstm_split_epilogue(const PT &p, f32x16 (&acc)[1
     const int rb = wave % RB, gg = wave / RB;       // row block, gate group
     const int cg = by;
     const int tiles_per_img = p.tilesY * p.tilesX;
-    const int px_per_img = p.TH * p.TW;
     int bimg0, ty0, tx0, tile_id;
     if (p.NI == 1) {
         bimg0 = bx / tiles_per_img;
@@ -409,29 +527,28 @@ __device__ __forceinline__ void lstm_split_epilogue(const PT &p, f32x16 (&acc)[1
         for (int r = 0; r < 16; ++r) xch[((rb * 4 + gate) * 16 + r) * 64 + lane] = acc[0][g][r] + bias;
     }
     __syncthreads();
-    long long ssum = 0, ssq = 0;
+    StatSumD hstat;
+    const long long img_elems = (long long)p.Hout * p.Wout * p.Cout;
     const TileDiv div_rpi(p.RPI), div_tw(p.TW);
+    auto cells = [&](auto ni1) {
 #pragma unroll
-    for (int rr = 0; rr < RSTEP; ++rr) {
-        const int r = gg * RSTEP + rr;
-        const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const int img = div_rpi.div(row), rem = row - img * p.RPI;
-        const int yy = div_tw.div(rem);
-        const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
-        const int b = bimg0 + img;
-        const bool ok = img < p.NI && rem < px_per_img && b < p.B && y < p.Hout && x < p.Wout;
-        if (!ok) continue;
-        const long long o = (((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch;
-        const float gi = xch[((rb * 4 + 0) * 16 + r) * 64 + lane], gj = xch[((rb * 4 + 1) * 16 + r) * 64 + lane];
-        const float gf = xch[((rb * 4 + 2) * 16 + r) * 64 + lane], go = xch[((rb * 4 + 3) * 16 + r) * 64 + lane];
-        const float c_old = p.cstate_in[(long long)b * p.cin_bstride + ((long long)y * p.Wout + x) * p.Cout + ch];
-        const float c_new = fmaf(c_old, sigmoidf_(gf + 1.0f), sigmoidf_(gi) * tanhf_(gj));
-        const float h_new = tanhf_(c_new) * sigmoidf_(go);
-        p.cstate[o] = c_new;
-        p.out[o] = h_new;
-        ssum += stat_q(h_new); ssq += stat_q2(h_new);
-    }
-    const long long wsum = wave_sum(ssum), wsq = wave_sum(ssq);
+        for (int rr = 0; rr < RSTEP; ++rr) {
+            const int r = gg * RSTEP + rr;
+            const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const LstmRowAddr a = lstm_row_addr<decltype(ni1)::value>(p, row, ch, bimg0, ty0, tx0, img_elems, div_rpi,
+                                                                      div_tw);
+            if (!a.ok) continue;
+            const float gi = xch[((rb * 4 + 0) * 16 + r) * 64 + lane], gj = xch[((rb * 4 + 1) * 16 + r) * 64 + lane];
+            const float gf = xch[((rb * 4 + 2) * 16 + r) * 64 + lane], go = xch[((rb * 4 + 3) * 16 + r) * 64 + lane];
+            float c_new, h_new;
+            lstm_cell(gi, gj, gf, go, a.cin[a.off], c_new, h_new);
+            a.cst[a.off] = c_new;
+            a.hout[a.off] = h_new;
+            hstat.add(h_new);
+        }
+    };
+    if (p.NI == 1) cells(std::true_type{}); else cells(std::false_type{});
+    const long long wsum = wave_sum(hstat.sum()), wsq = wave_sum(hstat.sumsq());
     if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
     __syncthreads();
     if (tid == 0) {
@@ -461,8 +578,13 @@ template <int ND, bool FIRST, class PT>
 __device__ __forceinline__ void convt_fused_epilogue(const PT &p, f32x16 (&acc)[1][4], int bx, long long *red, float *smem);
 
 template <int G, int EPI, int MREP, class PT, int RB = 4>
-__device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int by, const int bz,
+__device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int by_, const int bz_,
                                           float *smem) {
+    // the item coordinates are wave-uniform but reach an out-of-line tile body in vector registers: made scalar,
+    // the tile origin, sample index and every bound derived from them are computed on the scalar unit (VALU
+    // instructions do not overlap with the issuing wave's MFMAs - tools/ubench/mfma_shadow.hip - so they are not free)
+    const int bx = __builtin_amdgcn_readfirstlane(bx_), by = __builtin_amdgcn_readfirstlane(by_),
+              bz = __builtin_amdgcn_readfirstlane(bz_);
     constexpr bool SPLIT = RB < 4;
     static_assert(!SPLIT || (G == 4 && EPI == EPI_LSTM && MREP == 1 && (RB == 1 || RB == 2)),
                   "the row-split tiles are conv-LSTM tiles");
@@ -479,6 +601,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     //  * 256-row conv-LSTM tile: straight from L2 with a one-step look-ahead (its input tile needs the LDS, and it
     //    must keep the 32-channel chunks of the other plans so that every plan accumulates in the same K order);
     //  * light layers: straight from L2 through a ring of 4 (5) K steps, see kGRing below.
+    [[maybe_unused]] constexpr bool kInLaunch = !std::is_same<PT, ConvParams>::value;     // tile of the persistent rollout
     constexpr bool kBRing = SPLIT && RB == 1;
     constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1 && !kBRing;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -558,7 +681,25 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
     // gate w's slice (a quarter of the global loads of the direct path, whose 4 waves each pull
     // the whole block through L1) one tap ahead, parks it in registers during the tap's MFMAs,
     // then writes it to the other LDS buffer; one barrier per tap.
-    f32x4 *bsm = reinterpret_cast<f32x4 *>(smem + tile_floats + 4 * p.NI + 16);  // [2][K8][4][64]
+    // conv-LSTM tiles: LayerNorm gain and offset of every input channel, [gamma: gbC][beta: gbC] (recurrent
+    // segment first), filled once per item - the staging loop below reads a thread's channel quad with two
+    // ds_read_b128 per chunk instead of a modulo and two global loads per element and channel
+    constexpr bool kGbTab = EPI == EPI_LSTM;
+    const int gbC = kGbTab ? ((p.seg[0].C + (p.nseg > 1 ? p.seg[1].C : 0) + 3) & ~3) : 0;
+    float *gbTab = lnTab + 4 * p.NI + 16;
+    if constexpr (kGbTab) {
+        for (int i = tid; i < gbC; i += kConvThreads) {
+            const int sgi = i < p.seg[0].C ? 0 : 1;
+            const int cc = sgi ? i - p.seg[0].C : i;
+            float g = 1.f, b = 0.f;
+            if (sgi < p.nseg && cc < p.seg[sgi].C && p.seg[sgi].ln_part) {
+                const int m = cc % p.seg[sgi].gamma_mod;
+                g = p.seg[sgi].gamma[m]; b = p.seg[sgi].beta[m];
+            }
+            gbTab[i] = g; gbTab[gbC + i] = b;
+        }
+    }
+    f32x4 *bsm = reinterpret_cast<f32x4 *>(gbTab + 2 * gbC);    // [2][K8][4][64]
     const float *wgate = p.Wp + ((long long)kh * Ntot + (cg * G + (wave & (G - 1))) * 32 + n) * 4;
     const int gt0 = ch_begin * ntaps, gtN = ch_end * ntaps;
     f32x4 breg[4];
@@ -630,10 +771,13 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 
         if (late && ci == p.seg[0].nchunk) {         // the chunks of the early input are done: now the late one is needed
             const int b1 = p.NI == 1 ? bimg0 + 1 : min(bimg0 + p.NI, p.B);
+            if constexpr (kInLaunch) VF_TRACE_EVT(TR_LATE);
             if (!late_wait(p, bimg0, b1, reinterpret_cast<int *>(red))) return;
+            if constexpr (kInLaunch) VF_TRACE_EVT(TR_LATE_END);
             ln_table(p, bimg0, lnTab, 1, 2);
         }
         __syncthreads();        // previous chunk fully consumed (and lnTab visible on entry)
+        if constexpr (kInLaunch) VF_TRACE_EVT(TR_STAGE);
         [[maybe_unused]] const unsigned long long ts_s0 = VF_TS_NOW();
         // kConvThreads is a multiple of q4, so a thread stages the same channel quad of every pixel it visits: its
         // channel range and LayerNorm gain / offset are loop invariants.  The light layers load them once per chunk
@@ -658,7 +802,86 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
         // instead of one per element (a light layer's item is mostly this chain: 17 elements per thread in enc1,
         // 64 over the eight chunks of an FC item).
         constexpr int kStageU = 4;
-        for (int it0 = tid; it0 < items; it0 += kConvThreads * kStageU) {
+        // Conv-LSTM tiles with whole channel quads (always, for the plans of vf_engine.hip): the lean loop.  A starved
+        // wave - the other workgroup of the CU is in its K loop - gets about one VALU instruction issued per 40
+        // cycles (tools/ubench/mfma_shadow.hip), so the staging time IS its instruction count: ~30 per element here
+        // (pixel -> row / column by one multiply-high, unsigned bounds checks, 32-bit in-image offset on a scalar or
+        // per-image base, gain / offset from the LDS table) against ~110 in the general loop below.  Same values,
+        // same expressions on them: the same bits.
+        bool staged = false;
+        if constexpr (EPI == EPI_LSTM) {
+            if (vec_ok && sg.C % KC == 0) {
+                staged = true;
+                auto stage_fast = [&](auto ni1c) {
+                    constexpr bool NI1 = decltype(ni1c)::value;
+                    const int pl = tid >> q4_log2, ppp = kConvThreads >> q4_log2;       // pixel lane, pixels per pass
+                    const bool has_ln = sg.ln_part != nullptr;
+                    f32x4 gq = {1.f, 1.f, 1.f, 1.f}, bq = {0.f, 0.f, 0.f, 0.f};
+                    if (has_ln) {
+                        const int gi = (s == 0 ? 0 : p.seg[0].C) + c;
+                        gq = *reinterpret_cast<const f32x4 *>(gbTab + gi);
+                        bq = *reinterpret_cast<const f32x4 *>(gbTab + gbC + gi);
+                    }
+                    const int y0 = ty0 * p.stride - p.pad, x0 = tx0 * p.stride - p.pad;
+                    const int npix = p.NI * tile_px;
+                    const unsigned Cs = (unsigned)sg.C;
+                    float mean1 = 0.f, rstd1 = 1.f;
+                    if (NI1 && has_ln) { mean1 = lnTab[2 * s * p.NI]; rstd1 = lnTab[2 * s * p.NI + 1]; }
+                    // The images of this workgroup as ONE raw buffer (base and size are wave-uniform): a load whose
+                    // offset lies beyond it returns zeros, so padding pixels and samples past the batch cost one
+                    // select of the offset - no branch, no zero-initialised registers
+                    const unsigned img_bytes = (unsigned)(p.Hin * p.Win) * Cs * 4u;
+                    const unsigned img_step = (unsigned)sg.bstride * 4u;        // 0: one image broadcast to every sample
+                    const int n_here = min(p.NI, p.B - bimg0);                   // images of this workgroup inside the batch
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float *>(sg.ptr + (long long)bimg0 * sg.bstride), 0,
+                        n_here > 0 ? (int)((unsigned)(n_here - 1) * img_step + img_bytes) : 0, 0x00020000);
+                    float *dst = smem + 4 * q;
+                    for (int pix0 = pl; pix0 < npix; pix0 += ppp * kStageU) {
+                        f32x4 v[kStageU];
+                        bool oks[kStageU];
+                        [[maybe_unused]] int imgs[kStageU];
+#pragma unroll
+                        for (int u = 0; u < kStageU; ++u) {
+                            const int pix = pix0 + u * ppp;
+                            int img = 0, r = pix;
+                            if constexpr (!NI1) { img = (int)__umulhi((unsigned)pix, magic_px); r = pix - img * tile_px; }
+                            const int ly = LW == 1 ? r : (int)__umulhi((unsigned)r, magic_lw), lx = r - ly * LW;
+                            const int iy = y0 + ly, ix = x0 + lx;
+                            const bool ok = pix < npix && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win &&
+                                            img < n_here;
+                            imgs[u] = img; oks[u] = ok;
+                            unsigned off = ((unsigned)(iy * p.Win + ix) * Cs + (unsigned)c) * 4u;
+                            if constexpr (!NI1) off += (unsigned)img * img_step;
+                            v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : 0xFFFFFFFFu, 0, 0));
+                        }
+#pragma unroll
+                        for (int u = 0; u < kStageU; ++u) {
+                            const int pix = pix0 + u * ppp;
+                            if (pix >= npix) break;
+                            if (oks[u]) {
+                                if (has_ln) {
+                                    float mean = mean1, rstd = rstd1;
+                                    if constexpr (!NI1) {
+                                        mean = lnTab[2 * (s * p.NI + imgs[u])];
+                                        rstd = lnTab[2 * (s * p.NI + imgs[u]) + 1];
+                                    }
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[u][j] = fmaf((v[u][j] - mean) * rstd, gq[j], bq[j]);
+                                }
+                                if (sg.relu) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[u][j] = fmaxf(v[u][j], 0.f);
+                                }
+                            }
+                            *reinterpret_cast<f32x4 *>(dst + pix * KCpad) = v[u];
+                        }
+                    }
+                };
+                if (p.NI == 1) stage_fast(std::true_type{}); else stage_fast(std::false_type{});
+            }
+        }
+        for (int it0 = tid; !staged && it0 < items; it0 += kConvThreads * kStageU) {
             // q4 is a power of two; tile_px and LW divide through a multiply-high (exact for every index a tile
             // can hold: checked exhaustively for dividends < 70000, divisors 2..600; divisor 1 - the FC - bypasses it)
             f32x4 v[kStageU];
@@ -720,6 +943,10 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #ifdef VF_TILE_STATS
         if (ci == ch_begin) ts1 = VF_TS_NOW(); else ts_stage += VF_TS_NOW() - ts_s0;
 #endif
+        if constexpr (kInLaunch) {
+            if (ci == ch_begin) VF_TRACE_EVT(TR_MFMAS, (unsigned long long)(ntaps * K8 * 4 * GA * MREP));
+            VF_TRACE_EVT(TR_KLOOP);
+        }
 
         const f32x4 *smem4 = reinterpret_cast<const f32x4 *>(smem);
         int ab4[MREP];                                              // in float4 units
@@ -736,6 +963,70 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
         }
 
         if constexpr (kBLds) {
+          if (K8 == 4) {
+            // ---- K loop, B through LDS, 32-channel chunks (every conv-LSTM plan of vf_engine.hip): the k8 steps are
+            // unrolled with immediate LDS offsets and the next tap's weight slice comes through a raw buffer load
+            // (lane offset in one VGPR, tap offset in an SGPR), so a tap costs three VALU instructions besides its 64
+            // MFMAs.  A wave's own VALU / VMEM instructions do not overlap with its MFMAs (each costs the matrix pipe
+            // 17 / 37 cycles when the wave has the SIMD to itself, tools/ubench/mfma_shadow.hip): the generic loop
+            // below spends ~20 VALU instructions per tap on 64-bit addresses and K8-dependent selects, which is what
+            // held a K loop whose partner workgroup is outside its own to 0.78 of the pipe (tools/trace_cu.py).
+            // Same (chunk, tap, k8, j) order: the same bits.
+            const unsigned wl_off = (unsigned)(((kh * Ntot + (cg * G + (wave & (G - 1))) * 32 + n) * 4) * 4);
+            const unsigned wstep_b = (unsigned)wstep * 4u;                      // bytes per (tap, k8) block
+            const __amdgpu_buffer_rsrc_t wrsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.Wp), 0, 0x7FFFFFFF, 0x00020000);
+            const f32x4 *a_lane = smem4 + ab4[0];
+            const f32x4 *b_rd0 = bsm + gbase * 64 + lane;
+            f32x4 *b_wr0 = bsm + wave * 64 + lane;
+            int ky = 0, kx = 0;
+            for (int tap = 0; tap < ntaps; ++tap) {
+                const int gt = ci * ntaps + tap;
+                const int buf = (gt - gt0) & 1;
+                const bool more = gt + 1 < gtN;
+                const f32x4 *ap = a_lane + (ky * LW + kx) * kcp4;
+                const f32x4 *bp = b_rd0 + buf * (4 * 4 * 64);
+#define VF_FETCH_4(A_, B_, Q_)                                                                  \
+                {                                                                               \
+                    A_[0] = ap[(Q_) * 2];                                                       \
+                    _Pragma("unroll") for (int g = 0; g < GA; ++g) B_[g] = bp[((Q_) * 4 + g) * 64]; \
+                }
+                // (sched_barrier: the operands of step q + 1 are fetched BEFORE the MFMAs of step q are issued - left
+                // to itself the scheduler sinks every fetch behind the previous step's MFMAs to save registers and
+                // exposes the LDS latency four times per tap)
+                VF_FETCH_4(aP, bP, 0)
+                VF_FETCH_4(aQ, bQ, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                // (the weight loads of the next tap are issued behind the first operand fetches: any wait the compiler
+                // attaches to those fetches then never covers loads that were only just issued)
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        breg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            wrsrc, wl_off, (unsigned)((gt + 1) * 4 + q) * wstep_b, 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                VF_MFMA(aP, bP)
+                __builtin_amdgcn_sched_barrier(0);
+                VF_FETCH_4(aP, bP, 2)
+                __builtin_amdgcn_sched_barrier(0);
+                VF_MFMA(aQ, bQ)
+                __builtin_amdgcn_sched_barrier(0);
+                VF_FETCH_4(aQ, bQ, 3)
+                __builtin_amdgcn_sched_barrier(0);
+                VF_MFMA(aP, bP)
+                VF_MFMA(aQ, bQ)
+                __builtin_amdgcn_sched_barrier(0);
+#undef VF_FETCH_4
+                if (more) {
+                    f32x4 *bw = b_wr0 + (buf ^ 1) * (4 * 4 * 64);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bw[q * 4 * 64] = breg[q];
+                }
+                __syncthreads();
+                if (++kx == p.KW) { kx = 0; ++ky; }
+            }
+          } else {
             // ---- K loop, B through LDS: taps outer (one barrier each), k8 inner (ping-pong)
 #define VF_FETCH_L(A_, B_, Q_)                                                                  \
             {                                                                                   \
@@ -765,6 +1056,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
                 }
             }
 #undef VF_FETCH_L
+          }
         } else if constexpr (kBRing) {
             // ---- K loop of the row-split tiles: B from the register ring, A double-buffered from LDS, no barrier
             f32x4 aC[4], aN[4];
@@ -900,6 +1192,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx, const int b
 #undef VF_TAPLIVE
 
     if constexpr (EPI == EPI_LSTM) __builtin_amdgcn_s_setprio(2);
+    if constexpr (kInLaunch) VF_TRACE_EVT(TR_EPI);
     [[maybe_unused]] const unsigned long long ts2 = VF_TS_NOW();
     // (xch = the double-buffered B area: 32 KiB at 32-channel chunks, disjoint from lnTab / red)
     if constexpr (SPLIT) lstm_split_epilogue<RB>(p, acc, bx, by, red, reinterpret_cast<float *>(bsm));

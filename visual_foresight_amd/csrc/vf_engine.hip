@@ -183,7 +183,9 @@ static size_t conv_lds_bytes(const ConvLayer &l, int KC) {
     // A tile + LayerNorm table + reduction scratch (+ for 4-gate layers the double-buffered
     // per-tap B blocks: 2 x KC/8 x [4 gates][64 lanes] float4)
     const size_t b_lds = (l.mode == PACK_LSTM && l.mrep <= 1) ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
-    return ((size_t)l.NI * LH * LW * (KC + 4) + 4 * (size_t)l.NI) * 4 + 64 + b_lds;
+    // conv-LSTM tiles: LayerNorm gain / offset of every input channel (conv_tile's gbTab)
+    const size_t gb_lds = l.mode == PACK_LSTM ? (size_t)2 * round_up(l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0), 4) * 4 : 0;
+    return ((size_t)l.NI * LH * LW * (KC + 4) + 4 * (size_t)l.NI) * 4 + 64 + gb_lds + b_lds;
 }
 
 // choose tile shape and chunk size for a layer whose GEMM row grid is Hout x Wout
@@ -1983,6 +1985,16 @@ int vf_debug_tile_clocks(uint64_t *out /*[32][8]*/, int32_t reset) {
         static const uint64_t zeros[256] = {0};
         VF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(vf::g_tile_clk), zeros, sizeof(zeros)));
     }
+    return VF_OK;
+}
+#endif
+
+#ifdef VF_TRACE
+// diagnostic build: the event log of the last persistent launch, [512 workgroups][8192] words + the event counts
+extern "C" int vf_debug_trace(uint64_t *events, uint32_t *counts) {
+    if (hipDeviceSynchronize() != hipSuccess) return fail(VF_ERR_HIP, "sync failed");
+    VF_HIP_CHECK(hipMemcpyFromSymbol(events, HIP_SYMBOL(vf::g_trace), sizeof(uint64_t) * vf::kTraceWgs * vf::kTraceMax));
+    VF_HIP_CHECK(hipMemcpyFromSymbol(counts, HIP_SYMBOL(vf::g_trace_n), sizeof(uint32_t) * vf::kTraceWgs));
     return VF_OK;
 }
 #endif

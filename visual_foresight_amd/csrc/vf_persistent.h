@@ -170,6 +170,15 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
     int ph = 0;
     __builtin_amdgcn_s_setprio(2);      // default priority of this launch; conv-LSTM K loops step down to 0 (vf_conv_mfma.h)
     if (tid < kMaxCam * kMaxDesig * 2) s_ctl[kCtlGoal + tid] = sched.goal[tid];    // visible after the first barrier
+#ifdef VF_TRACE
+    if (tid == 0) {
+        s_ctl[5] = 0;
+        unsigned hwid, xcc_;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+        VF_TRACE_EVT(TR_HWID, ((unsigned long long)(xcc_ & 15u) << 32) | hwid);
+    }
+#endif
 
     // XCD-aware ticketing.  A phase's items are dealt to sched.nq queues so that all items of one output-channel
     // group and all tiles of one sample land in the same queue; a workgroup draws from the queue of the XCD it
@@ -186,6 +195,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
     for (;;) {
         [[maybe_unused]] const unsigned long long ts_top = VF_TS_NOW();
         __syncthreads();                    // previous item fully retired (LDS reusable)
+        VF_TRACE_EVT(TR_TICKET);
         if (tid == 0) {
             int t = -1, qq = q_own;
             for (int tries = 0; tries < nq; ++tries) {
@@ -255,6 +265,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
         __syncthreads();
         if (s_ctl[1] == 0) break;           // a producer never arrived: abandon the rollout
         const unsigned long long t_run = sched.stats ? wall_clock64() : 0ull;
+        VF_TRACE_EVT(TR_RUN + (unsigned)P.type);
 
         // ---- run the item
         {
@@ -319,7 +330,11 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
             }
         }
         VF_TS_ADD(15, 6, VF_TS_NOW() - ts_pub);         // drain + barrier + release fence + counters (tid 0's view)
+        VF_TRACE_EVT(TR_DONE);
     }
+#ifdef VF_TRACE
+    if (tid == 0 && blockIdx.x < kTraceWgs) g_trace_n[blockIdx.x] = (unsigned)s_ctl[5];
+#endif
 }
 
 }  // namespace vf
