@@ -78,6 +78,11 @@ for w in range(WGS):
             close(v, 'pro' if lstm else 'light:' + PH_NAMES[c - TR_RUN])
         elif c == TR_DONE:
             close(v, 'sched')
+        elif not lstm and state is not None and state.startswith('light:'):
+            base = ':'.join(state.split(':')[:2])
+            sub = {TR_STAGE: 'stage', TR_KLOOP: 'K', TR_EPI: 'epi', TR_LATE: 'late', TR_LATE_END: 'stage'}.get(int(c))
+            if sub:
+                close(v, base + ':' + sub)
         elif lstm:
             if c == TR_STAGE:
                 close(v, 'stage')
@@ -102,12 +107,20 @@ for w, iv in wg_iv.items():
         tot[s.split(':')[0] if s.startswith('light') else s] += (t1 - t0) * TICK_US
 nw = len(wg_iv)
 print('per workgroup slot (mean over %d), ms: ' % nw + '  '.join('%s %.2f' % (k, v / nw / 1e3) for k, v in sorted(tot.items())))
-light = defaultdict(float)
+light, lightn = defaultdict(float), defaultdict(int)
 for w, iv in wg_iv.items():
     for t0, t1, s, _ in iv:
         if s.startswith('light:'):
-            light[s[6:]] += (t1 - t0) * TICK_US
-print('   light items by type, ms per slot: ' + '  '.join('%s %.2f' % (k, v / nw / 1e3) for k, v in sorted(light.items())))
+            parts = s.split(':')
+            light[(parts[1], parts[2] if len(parts) > 2 else 'pro')] += (t1 - t0) * TICK_US
+            if len(parts) == 2:
+                lightn[parts[1]] += 1
+print('   light items: type, items per slot, ms per slot (us per item) by part')
+for ty in sorted(set(k[0] for k in light)):
+    n = max(lightn[ty], 1)
+    tot_ty = sum(v for k, v in light.items() if k[0] == ty)
+    print('   %-11s %6.1f items  %5.2f ms (%6.1f us):  ' % (ty, n / nw, tot_ty / nw / 1e3, tot_ty / n) +
+          '  '.join('%s %.1f' % (part, light[(ty, part)] / n) for part in ('pro', 'stage', 'K', 'late', 'epi') if (ty, part) in light))
 
 # ---- pair the workgroups of a CU
 by_cu = defaultdict(list)
@@ -167,3 +180,25 @@ tK1 = (sym[('K', 'other')] + sym[('K', 'idle')]) / npair
 print('   pipe time accounted: both-K %.1f ms x %.3f + one-K %.1f ms x %.3f = %.1f ms of MFMA work per SIMD' % (
     tK2 / 1e3, 2 * r[0] * 64 / (GHZ * 1e3), tK1 / 1e3, r[1] * 64 / (GHZ * 1e3),
     (tK2 * 2 * r[0] + tK1 * r[1]) * 64 / (GHZ * 1e3) / 1e3))
+
+# ---- time-resolved: share of the workgroups in each state, in bins over the middle of the launch
+if os.environ.get('VF_TRACE_TIMELINE'):
+    nb = 400
+    lo_t, hi_t = t_min + (t_max - t_min) * 0.40, t_min + (t_max - t_min) * 0.56       # ~ two steps
+    edges = np.linspace(lo_t, hi_t, nb + 1)
+    occ = defaultdict(lambda: np.zeros(nb))
+    for w, iv in wg_iv.items():
+        for t0, t1, s, _ in iv:
+            if t1 <= lo_t or t0 >= hi_t:
+                continue
+            key = 'K' if s == 'K' else ('idle' if s in ('wait', 'late', 'sched') or s.endswith(':late') else
+                                        (s.split(':')[1] if s.startswith('light') else 'lstm-other'))
+            a, b = max(t0, lo_t), min(t1, hi_t)
+            i0, i1 = int((a - lo_t) / (hi_t - lo_t) * nb), min(nb - 1, int((b - lo_t) / (hi_t - lo_t) * nb))
+            for i in range(i0, i1 + 1):
+                occ[key][i] += (min(b, edges[i + 1]) - max(a, edges[i])) / (edges[i + 1] - edges[i])
+    keys = sorted(occ, key=lambda k: -occ[k].sum())
+    print('timeline: %% of the %d workgroups per state, bins of %.1f us' % (nw, (hi_t - lo_t) / nb * TICK_US))
+    print('  t_us ' + ' '.join('%10s' % k[:10] for k in keys))
+    for i in range(nb):
+        print('%6.0f ' % ((edges[i] - lo_t) * TICK_US) + ' '.join('%10.1f' % (100.0 * occ[k][i] / nw) for k in keys))

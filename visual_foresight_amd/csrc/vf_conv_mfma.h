@@ -421,43 +421,56 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
         };
         if (p.NI == 1) cells(std::true_type{}); else cells(std::false_type{});
     }
+    // Every other layer type.  One image per workgroup (NI1): the sample is wave-uniform, so the output pointer is a
+    // scalar base plus a 32-bit in-image offset per lane; several images: the sample's stride enters through one wide
+    // multiply.  (An epilogue next to a K loop pays ~40 cycles per VALU instruction: 64-bit address chains per stored
+    // element were most of a transposed conv's item time.)
+    if constexpr (EPI != EPI_LSTM) {
+        auto rows = [&](auto ni1c) {
+            constexpr bool NI1 = decltype(ni1c)::value;
+            constexpr bool kT = EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS;
+            const long long out_elems = (long long)(kT ? 4 : 1) * p.Hout * p.Wout * p.Cout;    // floats per output image
 #pragma unroll
-    for (int m = 0; m < (EPI == EPI_LSTM ? 0 : MREP); ++m) {
+            for (int m = 0; m < MREP; ++m) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave * WROWS + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int img = div_rpi.div(row), rem = row - img * p.RPI;
-            const int yy = div_tw.div(rem);
-            const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
-            const int b = bimg0 + img;
-            const bool ok = img < p.NI && rem < px_per_img && b < p.B && y < p.Hout && x < p.Wout;
-            if (!ok) continue;
-            if constexpr (EPI == EPI_LSTM) {
-                // (handled by the dedicated loop above)
-            } else if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_RAW_STATS) {
-                if (ch < p.Cout) {
-                    float v = acc[m][0][r] + bias_g[0];
-                    if (p.sbias) v += p.sbias[(long long)b * p.sbias_ld + ch];
-                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                    p.out[(((long long)b * p.Hout + y) * p.Wout + x) * p.Cout + ch] = v;
-                    if constexpr (EPI == EPI_RAW_STATS) { ssum += stat_q(v); ssq += stat_q2(v); }
-                }
-            } else if constexpr (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS) {
-                if (ch < p.Cout) {
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wave * WROWS + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    int img = 0, rem = row;
+                    if constexpr (!NI1) { img = div_rpi.div(row); rem = row - img * p.RPI; }
+                    const int yy = div_tw.div(rem);
+                    const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
+                    const int b = bimg0 + img;
+                    const bool ok = img < p.NI && rem < px_per_img && b < p.B && y < p.Hout && x < p.Wout;
+                    if (!ok) continue;
+                    if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_RAW_STATS) {
+                        if (ch < p.Cout) {
+                            float v = acc[m][0][r] + bias_g[0];
+                            if (p.sbias) v += p.sbias[(long long)b * p.sbias_ld + ch];
+                            if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                            float *ob = p.out + (long long)b * out_elems;
+                            ob[(unsigned)((y * p.Wout + x) * p.Cout + ch)] = v;
+                            if constexpr (EPI == EPI_RAW_STATS) { ssum += stat_q(v); ssq += stat_q2(v); }
+                        }
+                    } else if constexpr (kT) {
+                        if (ch < p.Cout) {
+                            float *ob = p.out + (long long)b * out_elems;
+                            const unsigned o00 = (unsigned)(((2 * y) * (2 * p.Wout) + 2 * x) * p.Cout + ch);
 #pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        const int oy = 2 * y + (g >> 1), ox = 2 * x + (g & 1);
-                        float v = acc[m][g][r] + bias_g[g];
-                        if (EPI == EPI_CONVT_RELU) v = fmaxf(v, 0.f);
-                        p.out[(((long long)b * (2 * p.Hout) + oy) * (2 * p.Wout) + ox) * p.Cout + ch] = v;
-                        if constexpr (EPI == EPI_CONVT_RAW_STATS) { ssum += stat_q(v); ssq += stat_q2(v); }
+                            for (int g = 0; g < G; ++g) {
+                                float v = acc[m][g][r] + bias_g[g];
+                                if (EPI == EPI_CONVT_RELU) v = fmaxf(v, 0.f);
+                                ob[o00 + (unsigned)(((g >> 1) * (2 * p.Wout) + (g & 1)) * p.Cout)] = v;
+                                if constexpr (EPI == EPI_CONVT_RAW_STATS) { ssum += stat_q(v); ssq += stat_q2(v); }
+                            }
+                        }
+                    } else {    // EPI_PARTIAL: [split][B][n_valid]
+                        if (ch < p.n_valid)
+                            p.out[((long long)bz * p.B + b) * p.n_valid + ch] = acc[m][0][r];
                     }
                 }
-            } else {    // EPI_PARTIAL: [split][B][n_valid]
-                if (ch < p.n_valid)
-                    p.out[((long long)bz * p.B + b) * p.n_valid + ch] = acc[m][0][r];
             }
-        }
+        };
+        if (p.NI == 1) rows(std::true_type{}); else rows(std::false_type{});
     }
 
     if constexpr (EPI == EPI_LSTM) { ssum = hstat.sum(); ssq = hstat.sumsq(); }
@@ -565,6 +578,86 @@ __device__ __forceinline__ void lstm_split_epilogue(const PT &p, f32x16 (&acc)[1
     }
 }
 
+// Epilogue of the gate-split 128-row conv-LSTM tile (conv_tile<4, EPI_LSTM, 1, PT, 0>): wave w holds gate w of all four
+// row blocks.  The gate pre-activations cross through LDS (xch: [4 row blocks][4 gates][16][64 lanes] floats = 64 KiB
+// over the dead operand tile) and wave w finishes row block w with all four gates at hand; the reduction scratch lies
+// behind xch.  Same expressions on the same values, hence the same bits, as conv_epilogue.
+constexpr int kGsXchFloats = 4 * 4 * 16 * 64;
+template <class PT>
+__device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[4][1], const int bx, const int by,
+                                                     float *smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    const int cg = by;
+    const int tiles_per_img = p.tilesY * p.tilesX;
+    int bimg0, ty0, tx0, tile_id;
+    if (p.NI == 1) {
+        bimg0 = bx / tiles_per_img;
+        tile_id = bx % tiles_per_img;
+        ty0 = (tile_id / p.tilesX) * p.TH;
+        tx0 = (tile_id % p.tilesX) * p.TW;
+    } else {
+        bimg0 = bx * p.NI;
+        tile_id = 0; ty0 = 0; tx0 = 0;
+    }
+    const int ch = cg * 32 + n;
+    float *xch = smem;
+    long long *red = reinterpret_cast<long long *>(smem + kGsXchFloats);
+    __syncthreads();                        // the operand tile is no longer read: its LDS becomes xch
+    {
+        const float bias = p.bias[(cg * 4 + wave) * 32 + n];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[((m * 4 + wave) * 16 + r) * 64 + lane] = acc[m][0][r] + bias;
+    }
+    __syncthreads();
+    StatSumD hstat;
+    const long long img_elems = (long long)p.Hout * p.Wout * p.Cout;
+    const TileDiv div_rpi(p.RPI), div_tw(p.TW);
+    const float *xw = xch + wave * 4 * 16 * 64 + lane;      // this wave's row block: [gate][r][lane]
+    auto cells = [&](auto ni1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const LstmRowAddr a = lstm_row_addr<decltype(ni1)::value>(p, row, ch, bimg0, ty0, tx0, img_elems, div_rpi,
+                                                                      div_tw);
+            if (!a.ok) continue;
+            float c_new, h_new;
+            lstm_cell(xw[(0 * 16 + r) * 64], xw[(1 * 16 + r) * 64], xw[(2 * 16 + r) * 64], xw[(3 * 16 + r) * 64],
+                      a.cin[a.off], c_new, h_new);
+            a.cst[a.off] = c_new;
+            a.hout[a.off] = h_new;
+            hstat.add(h_new);
+        }
+    };
+    if (p.NI == 1) cells(std::true_type{}); else cells(std::false_type{});
+    // exact integer reduction, as conv_epilogue (wave w = GEMM rows [32 w, 32 w + 32))
+    const long long wsum = wave_sum(hstat.sum()), wsq = wave_sum(hstat.sumsq());
+    if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
+    __syncthreads();
+    if (p.NI == 1) {
+        if (tid == 0 && bimg0 < p.B) {
+            long long su = 0, sq = 0;
+            for (int w = 0; w < 4; ++w) { su += red[2 * w]; sq += red[2 * w + 1]; }
+            long long *dst = p.stats + ((long long)bimg0 * p.stats_nparts + tile_id * p.ncg + cg) * 2;
+            dst[0] = su; dst[1] = sq;
+        }
+    } else {
+        const int waves_per_img = p.RPI / 32;
+        if (lane == 0 && (wave % waves_per_img) == 0) {
+            const int img = wave / waves_per_img;
+            const int b = bimg0 + img;
+            if (img < p.NI && b < p.B) {
+                long long su = 0, sq = 0;
+                for (int w = 0; w < waves_per_img; ++w) { su += red[2 * (wave + w)]; sq += red[2 * (wave + w) + 1]; }
+                long long *dst = p.stats + ((long long)b * p.stats_nparts + cg) * 2;
+                dst[0] = su; dst[1] = sq;
+            }
+        }
+    }
+}
+
 // One workgroup tile.  (bx, by, bz) = (row tile, channel group, K split); smem = the workgroup's
 // dynamic LDS (conv_lds_bytes).  Called by the per-layer kernel below and, item by item, by the
 // persistent rollout kernel (vf_persistent.h).
@@ -585,11 +678,13 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     // instructions do not overlap with the issuing wave's MFMAs - tools/ubench/mfma_shadow.hip - so they are not free)
     const int bx = __builtin_amdgcn_readfirstlane(bx_), by = __builtin_amdgcn_readfirstlane(by_),
               bz = __builtin_amdgcn_readfirstlane(bz_);
-    constexpr bool SPLIT = RB < 4;
-    static_assert(!SPLIT || (G == 4 && EPI == EPI_LSTM && MREP == 1 && (RB == 1 || RB == 2)),
-                  "the row-split tiles are conv-LSTM tiles");
-    constexpr int WROWS = MREP * 32;    // GEMM rows per wave
-    constexpr int GA = SPLIT ? RB : G;  // gates (accumulator tiles) per wave
+    constexpr bool SPLIT = RB == 1 || RB == 2;
+    constexpr bool GSPLIT = RB == 0;    // gate-split 128-row conv-LSTM tile: wave w = gate w of all four row blocks
+    static_assert(RB == 4 || ((SPLIT || GSPLIT) && G == 4 && EPI == EPI_LSTM && MREP == 1),
+                  "the row-split and gate-split tiles are conv-LSTM tiles");
+    constexpr int MR = GSPLIT ? 4 : MREP;       // MFMA row blocks (accumulator tiles along the rows) per wave
+    constexpr int WROWS = MR * 32;      // GEMM rows per wave
+    constexpr int GA = GSPLIT ? 1 : (SPLIT ? RB : G);   // gates (accumulator tiles along the columns) per wave
     // Where the weight operand B comes from:
     //  * 128- and 64-row conv-LSTM tiles: through LDS - wave w fetches gate w's slice one tap ahead, all four waves
     //    read all four gates, one barrier per tap (a quarter of the L2 loads of the direct path);
@@ -602,12 +697,15 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     //    must keep the 32-channel chunks of the other plans so that every plan accumulates in the same K order);
     //  * light layers: straight from L2 through a ring of 4 (5) K steps, see kGRing below.
     [[maybe_unused]] constexpr bool kInLaunch = !std::is_same<PT, ConvParams>::value;     // tile of the persistent rollout
+    //  * gate-split 128-row conv-LSTM tile (RB 0): wave w multiplies gate w's slice with all 128 rows, so nothing
+    //    is shared and a tap is long (64 MFMAs): the slice of the NEXT tap goes straight from L2 into registers, no
+    //    LDS staging, no barrier and no VALU instruction inside a kernel row (see the K loop).
     constexpr bool kBRing = SPLIT && RB == 1;
-    constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1 && !kBRing;
+    constexpr bool kBLds = (EPI == EPI_LSTM) && MREP == 1 && !kBRing && !GSPLIT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
-    const int wrow0 = SPLIT ? (wave % RB) * 32 : wave * WROWS;     // first GEMM row of this wave
-    const int gbase = SPLIT ? (wave / RB) * GA : 0;                 // first gate of this wave
+    const int wrow0 = GSPLIT ? 0 : (SPLIT ? (wave % RB) * 32 : wave * WROWS);     // first GEMM row of this wave
+    const int gbase = GSPLIT ? wave : (SPLIT ? (wave / RB) * GA : 0);            // first gate of this wave
     const int KC = p.KC, KCpad = KC + 4, K8 = KC >> 3;
     const int LH = (p.TH - 1) * p.stride + p.KH, LW = (p.TW - 1) * p.stride + p.KW;
     const int tile_px = LH * LW;
@@ -645,9 +743,9 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
 
     // ---- this lane's A rows (GEMM rows wave*WROWS + m*32 + n)
     const int px_per_img = p.TH * p.TW;
-    int abase[MREP];
+    int abase[MR];
 #pragma unroll
-    for (int m = 0; m < MREP; ++m) {
+    for (int m = 0; m < MR; ++m) {
         const int row = wrow0 + m * 32 + n;
         const int img = row / p.RPI, rem = row % p.RPI;
         const bool ok = img < p.NI && rem < px_per_img;
@@ -655,9 +753,9 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
         abase[m] = (ok ? (img * tile_px + y * p.stride * LW + x * p.stride) * KCpad : 0) + kh * 4;
     }
 
-    f32x16 acc[MREP][GA];
+    f32x16 acc[MR][GA];
 #pragma unroll
-    for (int m = 0; m < MREP; ++m)
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int g = 0; g < GA; ++g)
 #pragma unroll
@@ -711,6 +809,23 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
         if (q < K8) bsm[(((BUF_) * K8 + q) * 4 + wave) * 64 + lane] = breg[q];
     if constexpr (kBLds) {
         if (gt0 < gtN) { VF_LOADB(gt0) }
+    }
+    // gate-split tile: two register sets for the weight slice of the current / the next tap, filled by raw buffer loads
+    // (lane offset in one VGPR, (tap, k8) offset in an SGPR); the first tap's slice is requested here and lands during
+    // the prologue and the first staging
+    [[maybe_unused]] f32x4 gsA[GSPLIT ? 4 : 1], gsB[GSPLIT ? 4 : 1];
+    [[maybe_unused]] int gs_par = 0;
+    [[maybe_unused]] const unsigned gs_loff = (unsigned)(((kh * Ntot + (cg * G + wave) * 32 + n) * 4) * 4);
+    [[maybe_unused]] const unsigned gs_wstep_b = (unsigned)wstep * 4u;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t gs_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.Wp), 0, 0x7FFFFFFF, 0x00020000);
+    if constexpr (GSPLIT) {
+        if (gt0 < gtN) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                gsA[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    gs_rsrc, gs_loff, (unsigned)(gt0 * 4 + q) * gs_wstep_b, 0));
+        }
     }
     constexpr int kRing = 5;                // taps in flight = one row of the 5x5 kernel
     [[maybe_unused]] f32x4 bring[kBRing ? kRing : 1][kBRing ? 4 : 1][GA];
@@ -787,9 +902,10 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
         const int q = tid & (q4 - 1);
         const int c = c0 + 4 * q;
         const int nvalid = min(4, sg.C - c);
+        const bool lean = vec_ok && sg.C % KC == 0;     // whole channel quads in whole chunks: the lean loop below
         [[maybe_unused]] float gam[4] = {1.f, 1.f, 1.f, 1.f}, bet[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (kHoistLn) {
-            if (sg.ln_part && c < sg.C) {
+            if (sg.ln_part && c < sg.C && !(kGbTab && lean)) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int cc = (c + j) % sg.gamma_mod;
@@ -802,15 +918,15 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
         // instead of one per element (a light layer's item is mostly this chain: 17 elements per thread in enc1,
         // 64 over the eight chunks of an FC item).
         constexpr int kStageU = 4;
-        // Conv-LSTM tiles with whole channel quads (always, for the plans of vf_engine.hip): the lean loop.  A starved
+        // Segments with whole channel quads in whole chunks (every layer but the 3-channel frame input): the lean loop.  A starved
         // wave - the other workgroup of the CU is in its K loop - gets about one VALU instruction issued per 40
         // cycles (tools/ubench/mfma_shadow.hip), so the staging time IS its instruction count: ~30 per element here
         // (pixel -> row / column by one multiply-high, unsigned bounds checks, 32-bit in-image offset on a scalar or
         // per-image base, gain / offset from the LDS table) against ~110 in the general loop below.  Same values,
         // same expressions on them: the same bits.
         bool staged = false;
-        if constexpr (EPI == EPI_LSTM) {
-            if (vec_ok && sg.C % KC == 0) {
+        {
+            if (lean) {
                 staged = true;
                 auto stage_fast = [&](auto ni1c) {
                     constexpr bool NI1 = decltype(ni1c)::value;
@@ -818,9 +934,14 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
                     const bool has_ln = sg.ln_part != nullptr;
                     f32x4 gq = {1.f, 1.f, 1.f, 1.f}, bq = {0.f, 0.f, 0.f, 0.f};
                     if (has_ln) {
-                        const int gi = (s == 0 ? 0 : p.seg[0].C) + c;
-                        gq = *reinterpret_cast<const f32x4 *>(gbTab + gi);
-                        bq = *reinterpret_cast<const f32x4 *>(gbTab + gbC + gi);
+                        if constexpr (kGbTab) {
+                            const int gi = (s == 0 ? 0 : p.seg[0].C) + c;
+                            gq = *reinterpret_cast<const f32x4 *>(gbTab + gi);
+                            bq = *reinterpret_cast<const f32x4 *>(gbTab + gbC + gi);
+                        } else {
+                            gq = f32x4{gam[0], gam[1], gam[2], gam[3]};
+                            bq = f32x4{bet[0], bet[1], bet[2], bet[3]};
+                        }
                     }
                     const int y0 = ty0 * p.stride - p.pad, x0 = tx0 * p.stride - p.pad;
                     const int npix = p.NI * tile_px;
@@ -845,7 +966,10 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
                         for (int u = 0; u < kStageU; ++u) {
                             const int pix = pix0 + u * ppp;
                             int img = 0, r = pix;
-                            if constexpr (!NI1) { img = (int)__umulhi((unsigned)pix, magic_px); r = pix - img * tile_px; }
+                            if constexpr (!NI1) {
+                                img = tile_px == 1 ? pix : (int)__umulhi((unsigned)pix, magic_px);
+                                r = pix - img * tile_px;
+                            }
                             const int ly = LW == 1 ? r : (int)__umulhi((unsigned)r, magic_lw), lx = r - ly * LW;
                             const int iy = y0 + ly, ix = x0 + lx;
                             const bool ok = pix < npix && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win &&
@@ -944,25 +1068,87 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
         if (ci == ch_begin) ts1 = VF_TS_NOW(); else ts_stage += VF_TS_NOW() - ts_s0;
 #endif
         if constexpr (kInLaunch) {
-            if (ci == ch_begin) VF_TRACE_EVT(TR_MFMAS, (unsigned long long)(ntaps * K8 * 4 * GA * MREP));
+            if (ci == ch_begin) VF_TRACE_EVT(TR_MFMAS, (unsigned long long)(ntaps * K8 * 4 * GA * MR));
             VF_TRACE_EVT(TR_KLOOP);
         }
 
         const f32x4 *smem4 = reinterpret_cast<const f32x4 *>(smem);
-        int ab4[MREP];                                              // in float4 units
+        int ab4[MR];                                                // in float4 units
 #pragma unroll
-        for (int m = 0; m < MREP; ++m) ab4[m] = abase[m] >> 2;
+        for (int m = 0; m < MR; ++m) ab4[m] = abase[m] >> 2;
         const int kcp4 = KCpad >> 2;
-        f32x4 aP[MREP], aQ[MREP], bP[GA], bQ[GA];
+        f32x4 aP[MR], aQ[MR];
+        [[maybe_unused]] f32x4 bP[GA], bQ[GA];
 #define VF_MFMA(A_, B_)                                                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
             _Pragma("unroll") for (int g = 0; g < GA; ++g) {                                    \
-                _Pragma("unroll") for (int m = 0; m < MREP; ++m)                                \
+                _Pragma("unroll") for (int m = 0; m < MR; ++m)                                  \
                     acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m][j], B_[g][j], acc[m][g], 0, 0, 0); \
             }                                                                                   \
         }
 
-        if constexpr (kBLds) {
+        if constexpr (GSPLIT) {
+            // ---- K loop of the gate-split tile (5x5 kernel, 32-channel chunks): one kernel ROW = 5 taps = 20 k8 steps
+            // of 16 MFMAs, statically unrolled.  Per step the wave reads its four A row blocks (one ds_read_b128 each,
+            // immediate offsets off four row pointers that are set up once per kernel row), one step ahead of the
+            // MFMAs that use them and across tap boundaries; per tap it issues the four buffer loads of the NEXT tap's
+            // weight slice into the idle one of two register sets (a tap is 64 MFMAs = 4096 cycles, several times the
+            // L2 latency).  No barrier, no LDS store, no VALU instruction inside a row: what a K loop costs the matrix
+            // pipe besides its MFMAs is 4 VMEM + 16 LDS issues per tap.  Same (chunk, tap, k8, j) order per output as
+            // every other plan: the same bits.
+            const f32x4 *ar[4];
+#define VF_GS_FETCH(A_, KX_, Q_)                                                                \
+            _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) A_[m_] = ar[m_][(KX_) * 9 + (Q_) * 2];
+#define VF_GS_MFMA(A_, BQ_)                                                                     \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                  \
+                _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                \
+                    acc[m_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m_][j_], BQ_[j_], acc[m_][0], 0, 0, 0); \
+            }
+            // (unconditional: behind the item's last tap the last slice is simply fetched again - a branch around the
+            // loads makes the compiler copy the register set on the path that skips them)
+#define VF_GS_LOADB(DST_, GT_)                                                                  \
+            {                                                                                   \
+                const unsigned so_ = (unsigned)(min((GT_), gtN - 1) * 4) * gs_wstep_b;          \
+                _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                \
+                    DST_[q_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(  \
+                        gs_rsrc, gs_loff, so_ + (unsigned)q_ * gs_wstep_b, 0));                 \
+            }
+            // one tap: A of its k8 step 0 is already in aP; CUR_ = this tap's weight slice, NXT_ <- the next tap's
+#define VF_GS_TAP(KX_, CUR_, NXT_)                                                              \
+            VF_GS_FETCH(aQ, KX_, 1)                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+            VF_GS_LOADB(NXT_, gt_row + (KX_) + 1)                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+            VF_GS_MFMA(aP, CUR_[0])                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+            VF_GS_FETCH(aP, KX_, 2)                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+            VF_GS_MFMA(aQ, CUR_[1])                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+            VF_GS_FETCH(aQ, KX_, 3)                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+            VF_GS_MFMA(aP, CUR_[2])                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+            if constexpr ((KX_) < 4) { VF_GS_FETCH(aP, (KX_) + 1, 0) }                          \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+            VF_GS_MFMA(aQ, CUR_[3])                                                             \
+            __builtin_amdgcn_sched_barrier(0);
+#define VF_GS_ROW(X_, Y_)                                                                       \
+            VF_GS_FETCH(aP, 0, 0)                                                               \
+            VF_GS_TAP(0, X_, Y_) VF_GS_TAP(1, Y_, X_) VF_GS_TAP(2, X_, Y_) VF_GS_TAP(3, Y_, X_) VF_GS_TAP(4, X_, Y_)
+            for (int ky = 0; ky < 5; ++ky) {
+                const int gt_row = ci * 25 + ky * 5;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) ar[m] = smem4 + ab4[m] + ky * LW * 9;
+                if (gs_par == 0) { VF_GS_ROW(gsA, gsB) } else { VF_GS_ROW(gsB, gsA) }
+                gs_par ^= 1;                // five taps: the slice of the next row's first tap sits in the other set
+            }
+#undef VF_GS_ROW
+#undef VF_GS_TAP
+#undef VF_GS_LOADB
+#undef VF_GS_MFMA
+#undef VF_GS_FETCH
+        } else if constexpr (kBLds) {
           if (K8 == 4) {
             // ---- K loop, B through LDS, 32-channel chunks (every conv-LSTM plan of vf_engine.hip): the k8 steps are
             // unrolled with immediate LDS offsets and the next tap's weight slice comes through a raw buffer load
@@ -1195,7 +1381,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     if constexpr (kInLaunch) VF_TRACE_EVT(TR_EPI);
     [[maybe_unused]] const unsigned long long ts2 = VF_TS_NOW();
     // (xch = the double-buffered B area: 32 KiB at 32-channel chunks, disjoint from lnTab / red)
-    if constexpr (SPLIT) lstm_split_epilogue<RB>(p, acc, bx, by, red, reinterpret_cast<float *>(bsm));
+    if constexpr (GSPLIT) lstm_gsplit_epilogue(p, acc, bx, by, smem);
+    else if constexpr (SPLIT) lstm_split_epilogue<RB>(p, acc, bx, by, red, reinterpret_cast<float *>(bsm));
     else if constexpr (EPI >= EPI_CONVT_FUSED)
         convt_fused_epilogue<(EPI - EPI_CONVT_FUSED) / 2 + 1, ((EPI - EPI_CONVT_FUSED) & 1) != 0>(p, acc, bx, red, smem);
     else conv_epilogue<G, EPI, MREP>(p, acc, bx, by, bz, red);
@@ -1215,6 +1402,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_mfma_kernel(const ConvPara
     conv_tile<G, EPI, MREP>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
+// RB = 2 / 1: the 64- / 32-row tiles; RB = 0: the gate-split 128-row tile
 template <int RB>
 VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_lstm_split_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -153,6 +153,8 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
     int mrep;                       // MFMA row blocks per wave: the workgroup covers 128 * mrep rows;
                                     // 0 / -1 = the 64- / 32-row conv-LSTM tiles (waves split rows x gates)
     int prec = 0;                   // 1: split-bf16 tile (conv-LSTM only)
+    bool gsplit = false;            // 128-row fp32 conv-LSTM tile with 32-channel chunks: the gate-split tile (wave w =
+                                    // gate w of all four row blocks, weights from L2 into registers, no barrier per tap)
     int NI, TH, TW, RPI, tilesY, tilesX;
     int ni_cap = 0;                 // > 0: at most this many whole images per workgroup (plans for narrow phases)
     int ncg, Cout;
@@ -220,6 +222,12 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
     l.KC = KC;
     for (int s = 0; s < 2; ++s) l.nchunk[s] = s < l.nseg ? (l.segC[s] + KC - 1) / KC : 0;
     l.lds_bytes = conv_lds_bytes(l, KC);
+    l.gsplit = l.mode == PACK_LSTM && l.mrep == 1 && l.prec == 0 && KC == 32 && l.KH == 5 && l.KW == 5;
+    if (l.gsplit) {
+        // no weight buffers in LDS, but the epilogue's gate exchange (64 KiB over the dead operand tile) + its scratch
+        const size_t b_lds = (size_t)2 * (KC / 8) * 4 * 64 * 16;
+        l.lds_bytes = std::max(l.lds_bytes - b_lds, (size_t)vf::kGsXchFloats * 4 + 64);
+    }
     if (l.prec == 1) {
         const int LH = (l.TH - 1) * l.stride + l.KH, LW = (l.TW - 1) * l.stride + l.KW;
         l.lds_bytes = bf16x6_lds_bytes(l.NI, LH, LW);
@@ -571,6 +579,7 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_CONVT_RAW_STATS, 1>, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_PARTIAL, 2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_bf16x6_kernel<1>, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_split_kernel<0>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_split_kernel<2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_split_kernel<1>, n))) return rc;
     const size_t np = n + kCtlWords * sizeof(int);
@@ -592,7 +601,9 @@ static int launch_conv_m(const ConvLayer &l, const ConvParams &p, hipStream_t st
 
 static int launch_lstm_split(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
-    if (l.mrep == 0)
+    if (l.gsplit)
+        hipLaunchKernelGGL(conv_lstm_split_kernel<0>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
+    else if (l.mrep == 0)
         hipLaunchKernelGGL(conv_lstm_split_kernel<2>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     else
         hipLaunchKernelGGL(conv_lstm_split_kernel<1>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
@@ -614,7 +625,7 @@ template <int G, int EPI>
 static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     if constexpr (EPI == EPI_LSTM) {
         if (l.prec == 1) return launch_lstm_bf16x6<1>(l, p, st);        // 128-row tiles only
-        if (l.mrep <= 0) return launch_lstm_split(l, p, st);
+        if (l.mrep <= 0 || l.gsplit) return launch_lstm_split(l, p, st);
         return l.mrep == 1 ? launch_conv_m<G, EPI, 1>(l, p, st) : launch_conv_m<G, EPI, 2>(l, p, st);
     } else if constexpr (EPI == EPI_PARTIAL) {
         return launch_conv_m<G, EPI, 2>(l, p, st);
@@ -1215,7 +1226,7 @@ struct ScheduleSink {
         P.gx = l.NI == 1 ? p.B * P.tiles_per_img : (p.B + l.NI - 1) / l.NI;
         P.gy = l.ncg;
         P.whole = type == PH_FC_PARTIAL;
-        P.mrep = l.mrep;
+        P.mrep = l.gsplit ? 3 : l.mrep;
         P.prec = p.tile_variant;
         max_lds = std::max(max_lds, l.lds_bytes);
         const double rows = (double)p.B * l.Hout * l.Wout;

@@ -53,7 +53,8 @@ struct PhaseDesc {
     int B;                  // samples this phase covers
     int NI, tiles_per_img;  // conv phases: how an item maps to samples
     int whole;              // 1: completion is counted once per item on counter 0
-    int mrep;               // MFMA row blocks per wave of this conv phase (1 or 2; 0 / -1: the 64- / 32-row conv-LSTM tiles)
+    int mrep;               // MFMA row blocks per wave of this conv phase (1 or 2; 0 / -1: the 64- / 32-row conv-LSTM
+                            // tiles; 3: the gate-split 128-row conv-LSTM tile)
     int prec;               // conv-LSTM tile: 0 exact fp32, 1 split-bf16
     int view;               // camera view this phase belongs to (selects the goal pixels of PH_COMPOSITE)
     int cnt_base;
@@ -132,24 +133,24 @@ __device__ __forceinline__ float *tile_lds() {
 }
 
 template <int G, int EPI, int MREP>
-__device__ __noinline__ void conv_tile_call(const ConvParams *p, int bx, int by, int bz) {
+static __device__ __noinline__ void conv_tile_call(const ConvParams *p, int bx, int by, int bz) {
     conv_tile<G, EPI, MREP>(const_params(p), bx, by, bz, tile_lds());
 }
 template <int RB>
-__device__ __noinline__ void lstm_split_tile_call(const ConvParams *p, int bx, int by) {
+static __device__ __noinline__ void lstm_split_tile_call(const ConvParams *p, int bx, int by) {
     conv_tile<4, EPI_LSTM, 1, const VF_CONST_AS ConvParams, RB>(const_params(p), bx, by, 0, tile_lds());
 }
 template <int MREP>
-__device__ __noinline__ void lstm_bf16x6_tile_call(const ConvParams *p, int bx, int by) {
+static __device__ __noinline__ void lstm_bf16x6_tile_call(const ConvParams *p, int bx, int by) {
     conv_lstm_bf16x6_tile<MREP>(const_params(p), bx, by, tile_lds());
 }
 template <int ND, bool FIRST>
-__device__ __noinline__ void composite_tile_call(const CompositeParams *p, int tile, int b, int view) {
+static __device__ __noinline__ void composite_tile_call(const CompositeParams *p, int tile, int b, int view) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
     composite_tile<ND, 10, FIRST>(const_params(p), tile, b, goal, tile_lds());
 }
-__device__ __noinline__ void small_item_call(const PhaseDesc *P, int type, int b0, int b1) {
+static __device__ __noinline__ void small_item_call(const PhaseDesc *P, int type, int b0, int b1) {
     float *smem = tile_lds();
     if (type == PH_SA) {
         const int wave = threadIdx.x >> 6, b = b0 + wave;
@@ -277,6 +278,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                     if (P.prec == 1) lstm_bf16x6_tile_call<1>(&P.conv, bx, by);         // 128-row tiles only
                     else if (P.mrep == 0) lstm_split_tile_call<2>(&P.conv, bx, by);
                     else if (P.mrep < 0) lstm_split_tile_call<1>(&P.conv, bx, by);
+                    else if (P.mrep == 3) lstm_split_tile_call<0>(&P.conv, bx, by);        // gate-split 128-row tile
                     else if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
                     else conv_tile_call<4, EPI_LSTM, 2>(&P.conv, bx, by, 0);
                     break;
