@@ -82,6 +82,7 @@ __device__ __forceinline__ void vf_trace(const unsigned code, const unsigned lon
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 
 constexpr int kConvThreads = 256;
 constexpr int kConvRows = 256;      // GEMM rows per workgroup at MREP = 2 (128 at MREP = 1)
@@ -603,6 +604,47 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
     const int ch = cg * 32 + n;
     float *xch = smem;
     long long *red = reinterpret_cast<long long *>(smem + kGsXchFloats);
+
+    // ---- Wave w finishes row block w: 32 pixels x 32 channels.  After the exchange a lane owns FOUR pixels x FOUR
+    // consecutive channels (pixel lane / 8 + 8 k, channels 4 (lane % 8) ..): the gates come out of xch as float4 (the
+    // MFMA layout keeps a pixel's 32 channels in 32 consecutive lanes), the previous cell state is one 16-byte load and
+    // c / h two 16-byte stores per pixel - 12 memory instructions per lane instead of 48, and the pixel geometry is
+    // computed 4 times instead of 16.  The three state tensors of this workgroup's images are raw buffers (wave-uniform
+    // base and size): a pixel outside the image / batch gets the offset ~0, its load returns zero and its stores are
+    // dropped - no branch anywhere, so the loads are issued before the gate exchange and have landed when the gate
+    // math needs them.  Per cell the same expressions on the same values as conv_epilogue, and the statistics are
+    // exact integers: the same bits.
+    const long long img_elems = (long long)p.Hout * p.Wout * p.Cout;
+    const TileDiv div_rpi(p.RPI), div_tw(p.TW);
+    const int n_here = min(p.NI, p.B - bimg0);
+    const unsigned img_bytes = (unsigned)img_elems * 4u;
+    const unsigned cin_step = (unsigned)p.cin_bstride * 4u;     // 0: one state shared by every sample (context steps)
+    const int span_out = n_here > 0 ? (int)((unsigned)(n_here - 1) * img_bytes + img_bytes) : 0;
+    const int span_cin = n_here > 0 ? (int)((unsigned)(n_here - 1) * cin_step + img_bytes) : 0;
+    const __amdgpu_buffer_rsrc_t r_cin = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.cstate_in + (long long)bimg0 * p.cin_bstride), 0, span_cin, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_cst =
+        __builtin_amdgcn_make_buffer_rsrc(p.cstate + (long long)bimg0 * img_elems, 0, span_out, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out =
+        __builtin_amdgcn_make_buffer_rsrc(p.out + (long long)bimg0 * img_elems, 0, span_out, 0x00020000);
+    const int pl = lane >> 3, cq = lane & 7;            // pixel lane, channel quad
+    unsigned off_o[4];
+    f32x4 c_old[4];
+    const bool ni1 = p.NI == 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = wave * 32 + pl + 8 * k;
+        int img = 0, rem = row;
+        if (!ni1) { img = div_rpi.div(row); rem = row - img * p.RPI; }
+        const int yy = div_tw.div(rem);
+        const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
+        const bool ok = img < n_here && rem < p.TH * p.TW && y < p.Hout && x < p.Wout;
+        const unsigned in_img = (unsigned)((y * p.Wout + x) * p.Cout + cg * 32 + 4 * cq) * 4u;
+        off_o[k] = ok ? (unsigned)img * img_bytes + in_img : 0xFFFFFFFFu;
+        const unsigned off_c = ok ? (unsigned)img * cin_step + in_img : 0xFFFFFFFFu;
+        c_old[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_cin, off_c, 0, 0));
+    }
+
     __syncthreads();                        // the operand tile is no longer read: its LDS becomes xch
     {
         const float bias = p.bias[(cg * 4 + wave) * 32 + n];
@@ -613,25 +655,24 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
     }
     __syncthreads();
     StatSumD hstat;
-    const long long img_elems = (long long)p.Hout * p.Wout * p.Cout;
-    const TileDiv div_rpi(p.RPI), div_tw(p.TW);
-    const float *xw = xch + wave * 4 * 16 * 64 + lane;      // this wave's row block: [gate][r][lane]
-    auto cells = [&](auto ni1) {
+    // GEMM row R = pl + 8 k of the block sits in accumulator row r = (R & 3) + 4 (R >> 3) of lane half (R >> 2) & 1
+    const float *xw = xch + ((wave * 4) * 16 + (pl & 3)) * 64 + 32 * ((pl >> 2) & 1) + 4 * cq;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const LstmRowAddr a = lstm_row_addr<decltype(ni1)::value>(p, row, ch, bimg0, ty0, tx0, img_elems, div_rpi,
-                                                                      div_tw);
-            if (!a.ok) continue;
+    for (int k = 0; k < 4; ++k) {
+        f32x4 gate[4], cn, hn;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gate[g] = *reinterpret_cast<const f32x4 *>(xw + (g * 16 + 4 * k) * 64);
+        const bool live = off_o[k] != 0xFFFFFFFFu;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
             float c_new, h_new;
-            lstm_cell(xw[(0 * 16 + r) * 64], xw[(1 * 16 + r) * 64], xw[(2 * 16 + r) * 64], xw[(3 * 16 + r) * 64],
-                      a.cin[a.off], c_new, h_new);
-            a.cst[a.off] = c_new;
-            a.hout[a.off] = h_new;
-            hstat.add(h_new);
+            lstm_cell(gate[0][e], gate[1][e], gate[2][e], gate[3][e], c_old[k][e], c_new, h_new);
+            cn[e] = c_new; hn[e] = h_new;
+            hstat.add(live ? h_new : 0.f);          // (a dropped pixel adds the integer 0)
         }
-    };
-    if (p.NI == 1) cells(std::true_type{}); else cells(std::false_type{});
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, cn), r_cst, off_o[k], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, hn), r_out, off_o[k], 0, 0);
+    }
     // exact integer reduction, as conv_epilogue (wave w = GEMM rows [32 w, 32 w + 32))
     const long long wsum = wave_sum(hstat.sum()), wsq = wave_sum(hstat.sumsq());
     if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
@@ -917,6 +958,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
         // global loads back to back, then LayerNorm / relu / the LDS stores - one exposed load latency per batch
         // instead of one per element (a light layer's item is mostly this chain: 17 elements per thread in enc1,
         // 64 over the eight chunks of an FC item).
+        // (all ~9 loads of a thread in flight at once, or the element geometry computed once per item instead of per
+        // chunk: measured in the gate-split tile, no gain - the extra live registers spill)
         constexpr int kStageU = 4;
         // Segments with whole channel quads in whole chunks (every layer but the 3-channel frame input): the lean loop.  A starved
         // wave - the other workgroup of the CU is in its K loop - gets about one VALU instruction issued per 40

@@ -133,24 +133,24 @@ __device__ __forceinline__ float *tile_lds() {
 }
 
 template <int G, int EPI, int MREP>
-static __device__ __noinline__ void conv_tile_call(const ConvParams *p, int bx, int by, int bz) {
+static __device__ __noinline__ __attribute__((not_tail_called)) void conv_tile_call(const ConvParams *p, int bx, int by, int bz) {
     conv_tile<G, EPI, MREP>(const_params(p), bx, by, bz, tile_lds());
 }
 template <int RB>
-static __device__ __noinline__ void lstm_split_tile_call(const ConvParams *p, int bx, int by) {
+static __device__ __noinline__ __attribute__((not_tail_called)) void lstm_split_tile_call(const ConvParams *p, int bx, int by) {
     conv_tile<4, EPI_LSTM, 1, const VF_CONST_AS ConvParams, RB>(const_params(p), bx, by, 0, tile_lds());
 }
 template <int MREP>
-static __device__ __noinline__ void lstm_bf16x6_tile_call(const ConvParams *p, int bx, int by) {
+static __device__ __noinline__ __attribute__((not_tail_called)) void lstm_bf16x6_tile_call(const ConvParams *p, int bx, int by) {
     conv_lstm_bf16x6_tile<MREP>(const_params(p), bx, by, tile_lds());
 }
 template <int ND, bool FIRST>
-static __device__ __noinline__ void composite_tile_call(const CompositeParams *p, int tile, int b, int view) {
+static __device__ __noinline__ __attribute__((not_tail_called)) void composite_tile_call(const CompositeParams *p, int tile, int b, int view) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
     composite_tile<ND, 10, FIRST>(const_params(p), tile, b, goal, tile_lds());
 }
-static __device__ __noinline__ void small_item_call(const PhaseDesc *P, int type, int b0, int b1) {
+static __device__ __noinline__ __attribute__((not_tail_called)) void small_item_call(const PhaseDesc *P, int type, int b0, int b1) {
     float *smem = tile_lds();
     if (type == PH_SA) {
         const int wave = threadIdx.x >> 6, b = b0 + wave;
