@@ -169,6 +169,11 @@ for (s1, s2), v in joint.items():
 for k, v in sorted(sym.items(), key=lambda kv: -kv[1]):
     print('   %-14s %5.1f %%' % ('%s + %s' % k, 100.0 * v / npair / span))
 X, Y = np.array(X), np.array(Y, dtype=np.float64)
+for mfc in sorted(set(Y.tolist())):
+    sel = Y == mfc
+    rr, *_ = np.linalg.lstsq(X[sel], Y[sel], rcond=None)
+    print('   tiles with %5d MFMAs per wave and chunk (%6d chunks): both in K %.3f of the pipe, alone %.3f' % (
+        int(mfc), int(sel.sum()), 2 * rr[0] * 64 / 2380.0, rr[1] * 64 / 2380.0))
 r, *_ = np.linalg.lstsq(X, Y, rcond=None)
 GHZ = 2.38
 print('MFMA issue rate of one wave in its K loop (least squares over %d K-loop intervals):' % len(Y))

@@ -579,13 +579,22 @@ __device__ __forceinline__ void lstm_split_epilogue(const PT &p, f32x16 (&acc)[1
     }
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // Epilogue of the gate-split 128-row conv-LSTM tile (conv_tile<4, EPI_LSTM, 1, PT, 0>): wave w holds gate w of all four
 // row blocks.  The gate pre-activations cross through LDS (xch: [4 row blocks][4 gates][16][64 lanes] floats = 64 KiB
 // over the dead operand tile) and wave w finishes row block w with all four gates at hand; the reduction scratch lies
 // behind xch.  Same expressions on the same values, hence the same bits, as conv_epilogue.
+// (MR = 8, the 256-row tile: the same in two rounds of four row blocks - wave w finishes row blocks w and 4 + w)
 constexpr int kGsXchFloats = 4 * 4 * 16 * 64;
-template <class PT>
-__device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[4][1], const int bx, const int by,
+template <int MR, class PT>
+__device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[MR][1], const int bx, const int by,
                                                      float *smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
@@ -628,52 +637,54 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
     const __amdgpu_buffer_rsrc_t r_out =
         __builtin_amdgcn_make_buffer_rsrc(p.out + (long long)bimg0 * img_elems, 0, span_out, 0x00020000);
     const int pl = lane >> 3, cq = lane & 7;            // pixel lane, channel quad
-    unsigned off_o[4];
-    f32x4 c_old[4];
     const bool ni1 = p.NI == 1;
+    const float bias = p.bias[(cg * 4 + wave) * 32 + n];
+    StatSumD hstat;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int row = wave * 32 + pl + 8 * k;
-        int img = 0, rem = row;
-        if (!ni1) { img = div_rpi.div(row); rem = row - img * p.RPI; }
-        const int yy = div_tw.div(rem);
-        const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
-        const bool ok = img < n_here && rem < p.TH * p.TW && y < p.Hout && x < p.Wout;
-        const unsigned in_img = (unsigned)((y * p.Wout + x) * p.Cout + cg * 32 + 4 * cq) * 4u;
-        off_o[k] = ok ? (unsigned)img * img_bytes + in_img : 0xFFFFFFFFu;
-        const unsigned off_c = ok ? (unsigned)img * cin_step + in_img : 0xFFFFFFFFu;
-        c_old[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_cin, off_c, 0, 0));
-    }
-
-    __syncthreads();                        // the operand tile is no longer read: its LDS becomes xch
-    {
-        const float bias = p.bias[(cg * 4 + wave) * 32 + n];
+    for (int half = 0; half < MR / 4; ++half) {
+        const int rb = half * 4 + wave;                  // the row block this wave finishes in this round
+        unsigned off_o[4];
+        f32x4 c_old[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = rb * 32 + pl + 8 * k;
+            int img = 0, rem = row;
+            if (!ni1) { img = div_rpi.div(row); rem = row - img * p.RPI; }
+            const int yy = div_tw.div(rem);
+            const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
+            const bool ok = img < n_here && rem < p.TH * p.TW && y < p.Hout && x < p.Wout;
+            const unsigned in_img = (unsigned)((y * p.Wout + x) * p.Cout + cg * 32 + 4 * cq) * 4u;
+            off_o[k] = ok ? (unsigned)img * img_bytes + in_img : 0xFFFFFFFFu;
+            const unsigned off_c = ok ? (unsigned)img * cin_step + in_img : 0xFFFFFFFFu;
+            c_old[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_cin, off_c, 0, 0));
+        }
+        __syncthreads();                    // the operand tile / the previous round's gates are no longer read
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xch[((m * 4 + wave) * 16 + r) * 64 + lane] = acc[m][0][r] + bias;
-    }
-    __syncthreads();
-    StatSumD hstat;
-    // GEMM row R = pl + 8 k of the block sits in accumulator row r = (R & 3) + 4 (R >> 3) of lane half (R >> 2) & 1
-    const float *xw = xch + ((wave * 4) * 16 + (pl & 3)) * 64 + 32 * ((pl >> 2) & 1) + 4 * cq;
+            for (int r = 0; r < 16; ++r) xch[((m * 4 + wave) * 16 + r) * 64 + lane] = acc[half * 4 + m][0][r] + bias;
+        __syncthreads();
+        // GEMM row R = pl + 8 k of the block sits in accumulator row r = (R & 3) + 4 (R >> 3) of lane half (R >> 2) & 1
+        const float *xw = xch + ((wave * 4) * 16 + (pl & 3)) * 64 + 32 * ((pl >> 2) & 1) + 4 * cq;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        f32x4 gate[4], cn, hn;
+        for (int k = 0; k < 4; ++k) {
+            f32x4 gate[4], cn, hn;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gate[g] = *reinterpret_cast<const f32x4 *>(xw + (g * 16 + 4 * k) * 64);
-        const bool live = off_o[k] != 0xFFFFFFFFu;
+            for (int g = 0; g < 4; ++g) gate[g] = *reinterpret_cast<const f32x4 *>(xw + (g * 16 + 4 * k) * 64);
+            const bool live = off_o[k] != 0xFFFFFFFFu;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float c_new, h_new;
-            lstm_cell(gate[0][e], gate[1][e], gate[2][e], gate[3][e], c_old[k][e], c_new, h_new);
-            cn[e] = c_new; hn[e] = h_new;
-            hstat.add(live ? h_new : 0.f);          // (a dropped pixel adds the integer 0)
+            for (int e = 0; e < 4; ++e) {
+                float c_new, h_new;
+                lstm_cell(gate[0][e], gate[1][e], gate[2][e], gate[3][e], c_old[k][e], c_new, h_new);
+                cn[e] = c_new; hn[e] = h_new;
+                hstat.add(live ? h_new : 0.f);          // (a dropped pixel adds the integer 0)
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, cn), r_cst, off_o[k], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, hn), r_out, off_o[k], 0, 0);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, cn), r_cst, off_o[k], 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, hn), r_out, off_o[k], 0, 0);
     }
-    // exact integer reduction, as conv_epilogue (wave w = GEMM rows [32 w, 32 w + 32))
+    // exact integer reduction, as conv_epilogue (MR = 4: wave w = GEMM rows [32 w, 32 w + 32); the 256-row tile always
+    // holds ONE image - plan_geometry - so only the per-tile total is needed there)
     const long long wsum = wave_sum(hstat.sum()), wsq = wave_sum(hstat.sumsq());
     if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
     __syncthreads();
@@ -720,10 +731,10 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     const int bx = __builtin_amdgcn_readfirstlane(bx_), by = __builtin_amdgcn_readfirstlane(by_),
               bz = __builtin_amdgcn_readfirstlane(bz_);
     constexpr bool SPLIT = RB == 1 || RB == 2;
-    constexpr bool GSPLIT = RB == 0;    // gate-split 128-row conv-LSTM tile: wave w = gate w of all four row blocks
-    static_assert(RB == 4 || ((SPLIT || GSPLIT) && G == 4 && EPI == EPI_LSTM && MREP == 1),
+    constexpr bool GSPLIT = RB == 0;    // gate-split conv-LSTM tile: wave w = gate w of ALL 4 * MREP row blocks (128 / 256 rows)
+    static_assert(RB == 4 || (G == 4 && EPI == EPI_LSTM && ((SPLIT && MREP == 1) || GSPLIT)),
                   "the row-split and gate-split tiles are conv-LSTM tiles");
-    constexpr int MR = GSPLIT ? 4 : MREP;       // MFMA row blocks (accumulator tiles along the rows) per wave
+    constexpr int MR = GSPLIT ? 4 * MREP : MREP;    // MFMA row blocks (accumulator tiles along the rows) per wave
     constexpr int WROWS = MR * 32;      // GEMM rows per wave
     constexpr int GA = GSPLIT ? 1 : (SPLIT ? RB : G);   // gates (accumulator tiles along the columns) per wave
     // Where the weight operand B comes from:
@@ -1120,12 +1131,12 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
 #pragma unroll
         for (int m = 0; m < MR; ++m) ab4[m] = abase[m] >> 2;
         const int kcp4 = KCpad >> 2;
-        f32x4 aP[MR], aQ[MR];
+        [[maybe_unused]] f32x4 aP[GSPLIT ? 1 : MR], aQ[GSPLIT ? 1 : MR];
         [[maybe_unused]] f32x4 bP[GA], bQ[GA];
 #define VF_MFMA(A_, B_)                                                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
             _Pragma("unroll") for (int g = 0; g < GA; ++g) {                                    \
-                _Pragma("unroll") for (int m = 0; m < MR; ++m)                                  \
+                _Pragma("unroll") for (int m = 0; m < (GSPLIT ? 1 : MR); ++m)                   \
                     acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m][j], B_[g][j], acc[m][g], 0, 0, 0); \
             }                                                                                   \
         }
@@ -1139,58 +1150,64 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
             // L2 latency).  No barrier, no LDS store, no VALU instruction inside a row: what a K loop costs the matrix
             // pipe besides its MFMAs is 4 VMEM + 16 LDS issues per tap.  Same (chunk, tap, k8, j) order per output as
             // every other plan: the same bits.
-            const f32x4 *ar[4];
-#define VF_GS_FETCH(A_, KX_, Q_)                                                                \
-            _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) A_[m_] = ar[m_][(KX_) * 9 + (Q_) * 2];
-#define VF_GS_MFMA(A_, BQ_)                                                                     \
-            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                  \
-                _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                \
-                    acc[m_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m_][j_], BQ_[j_], acc[m_][0], 0, 0, 0); \
-            }
-            // (unconditional: behind the item's last tap the last slice is simply fetched again - a branch around the
-            // loads makes the compiler copy the register set on the path that skips them)
-#define VF_GS_LOADB(DST_, GT_)                                                                  \
-            {                                                                                   \
-                const unsigned so_ = (unsigned)(min((GT_), gtN - 1) * 4) * gs_wstep_b;          \
-                _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                \
-                    DST_[q_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(  \
-                        gs_rsrc, gs_loff, so_ + (unsigned)q_ * gs_wstep_b, 0));                 \
-            }
-            // one tap: A of its k8 step 0 is already in aP; CUR_ = this tap's weight slice, NXT_ <- the next tap's
-#define VF_GS_TAP(KX_, CUR_, NXT_)                                                              \
-            VF_GS_FETCH(aQ, KX_, 1)                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                  \
-            VF_GS_LOADB(NXT_, gt_row + (KX_) + 1)                                               \
-            __builtin_amdgcn_sched_barrier(0);                                                  \
-            VF_GS_MFMA(aP, CUR_[0])                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                  \
-            VF_GS_FETCH(aP, KX_, 2)                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                  \
-            VF_GS_MFMA(aQ, CUR_[1])                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                  \
-            VF_GS_FETCH(aQ, KX_, 3)                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                  \
-            VF_GS_MFMA(aP, CUR_[2])                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                  \
-            if constexpr ((KX_) < 4) { VF_GS_FETCH(aP, (KX_) + 1, 0) }                          \
-            __builtin_amdgcn_sched_barrier(0);                                                  \
-            VF_GS_MFMA(aQ, CUR_[3])                                                             \
-            __builtin_amdgcn_sched_barrier(0);
-#define VF_GS_ROW(X_, Y_)                                                                       \
-            VF_GS_FETCH(aP, 0, 0)                                                               \
-            VF_GS_TAP(0, X_, Y_) VF_GS_TAP(1, Y_, X_) VF_GS_TAP(2, X_, Y_) VF_GS_TAP(3, Y_, X_) VF_GS_TAP(4, X_, Y_)
+            // (MREP 2: eight row blocks per wave, worked through in two groups of four per k8 step - a "substep" is one
+            // group's 16 MFMAs; the operands of substep s + 1 are fetched before the MFMAs of substep s are issued)
+            constexpr int NG = MR / 4, NS = 4 * NG;         // row-block groups, substeps per tap
+            const f32x4 *ar[MR];
+            f32x4 aP4[4], aQ4[4];
+            auto gs_fetch = [&](f32x4 (&A_)[4], const int kx, const int sub) {
+#pragma unroll
+                for (int m_ = 0; m_ < 4; ++m_) A_[m_] = ar[(sub % NG) * 4 + m_][kx * 9 + (sub / NG) * 2];
+            };
+            auto gs_loadb = [&](f32x4 (&D_)[4], const int gt) {
+                // (unconditional: behind the item's last tap the last slice is simply fetched again - a branch around
+                // the loads makes the compiler copy the register set on the path that skips them)
+                const unsigned so_ = (unsigned)(min(gt, gtN - 1) * 4) * gs_wstep_b;
+#pragma unroll
+                for (int q_ = 0; q_ < 4; ++q_)
+                    D_[q_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        gs_rsrc, gs_loff, so_ + (unsigned)q_ * gs_wstep_b, 0));
+            };
+            // one tap: the operands of its substep 0 are already in aP; cur = this tap's weight slice, nxt <- the next tap's
+            auto gs_tap = [&](auto kxc, f32x4 (&cur)[4], f32x4 (&nxt)[4], const int gt_next) {
+                constexpr int KX = decltype(kxc)::value;
+                static_for<NS>([&](auto sc) {
+                    constexpr int S = decltype(sc)::value;
+                    f32x4 (&a_cur)[4] = (S & 1) ? aQ4 : aP4;
+                    f32x4 (&a_nxt)[4] = (S & 1) ? aP4 : aQ4;
+                    if constexpr (S + 1 < NS) gs_fetch(a_nxt, KX, S + 1);
+                    else if constexpr (KX < 4) gs_fetch(a_nxt, KX + 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (S == 0) {
+                        gs_loadb(nxt, gt_next);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const f32x4 bq = cur[S / NG];
+#pragma unroll
+                    for (int j_ = 0; j_ < 4; ++j_) {
+#pragma unroll
+                        for (int m_ = 0; m_ < 4; ++m_)
+                            acc[(S % NG) * 4 + m_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                a_cur[m_][j_], bq[j_], acc[(S % NG) * 4 + m_][0], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            };
+            auto gs_row = [&](f32x4 (&X_)[4], f32x4 (&Y_)[4], const int gt_row) {
+                gs_fetch(aP4, 0, 0);
+                gs_tap(std::integral_constant<int, 0>{}, X_, Y_, gt_row + 1);
+                gs_tap(std::integral_constant<int, 1>{}, Y_, X_, gt_row + 2);
+                gs_tap(std::integral_constant<int, 2>{}, X_, Y_, gt_row + 3);
+                gs_tap(std::integral_constant<int, 3>{}, Y_, X_, gt_row + 4);
+                gs_tap(std::integral_constant<int, 4>{}, X_, Y_, gt_row + 5);
+            };
             for (int ky = 0; ky < 5; ++ky) {
                 const int gt_row = ci * 25 + ky * 5;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) ar[m] = smem4 + ab4[m] + ky * LW * 9;
-                if (gs_par == 0) { VF_GS_ROW(gsA, gsB) } else { VF_GS_ROW(gsB, gsA) }
+                for (int m = 0; m < MR; ++m) ar[m] = smem4 + ab4[m] + ky * LW * 9;
+                if (gs_par == 0) gs_row(gsA, gsB, gt_row); else gs_row(gsB, gsA, gt_row);
                 gs_par ^= 1;                // five taps: the slice of the next row's first tap sits in the other set
             }
-#undef VF_GS_ROW
-#undef VF_GS_TAP
-#undef VF_GS_LOADB
-#undef VF_GS_MFMA
-#undef VF_GS_FETCH
         } else if constexpr (kBLds) {
           if (K8 == 4) {
             // ---- K loop, B through LDS, 32-channel chunks (every conv-LSTM plan of vf_engine.hip): the k8 steps are
@@ -1424,7 +1441,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     if constexpr (kInLaunch) VF_TRACE_EVT(TR_EPI);
     [[maybe_unused]] const unsigned long long ts2 = VF_TS_NOW();
     // (xch = the double-buffered B area: 32 KiB at 32-channel chunks, disjoint from lnTab / red)
-    if constexpr (GSPLIT) lstm_gsplit_epilogue(p, acc, bx, by, smem);
+    if constexpr (GSPLIT) lstm_gsplit_epilogue<MR>(p, acc, bx, by, smem);
     else if constexpr (SPLIT) lstm_split_epilogue<RB>(p, acc, bx, by, red, reinterpret_cast<float *>(bsm));
     else if constexpr (EPI >= EPI_CONVT_FUSED)
         convt_fused_epilogue<(EPI - EPI_CONVT_FUSED) / 2 + 1, ((EPI - EPI_CONVT_FUSED) & 1) != 0>(p, acc, bx, red, smem);
@@ -1445,11 +1462,18 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_mfma_kernel(const ConvPara
     conv_tile<G, EPI, MREP>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
-// RB = 2 / 1: the 64- / 32-row tiles; RB = 0: the gate-split 128-row tile
+// RB = 2 / 1: the 64- / 32-row tiles
 template <int RB>
 VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_lstm_split_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     conv_tile<4, EPI_LSTM, 1, ConvParams, RB>(p, blockIdx.x, blockIdx.y, 0, smem);
+}
+
+// the gate-split tiles: 128 (MREP 1) / 256 (MREP 2) rows per workgroup
+template <int MREP>
+VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_lstm_gsplit_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_tile<4, EPI_LSTM, MREP, ConvParams, 0>(p, blockIdx.x, blockIdx.y, 0, smem);
 }
 
 }  // namespace vf

@@ -222,10 +222,18 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
     l.KC = KC;
     for (int s = 0; s < 2; ++s) l.nchunk[s] = s < l.nseg ? (l.segC[s] + KC - 1) / KC : 0;
     l.lds_bytes = conv_lds_bytes(l, KC);
-    l.gsplit = l.mode == PACK_LSTM && l.mrep == 1 && l.prec == 0 && KC == 32 && l.KH == 5 && l.KW == 5;
+    // (the device code also has the 256-row variant - conv_lstm_gsplit_kernel<2>, eight row blocks per wave - but its
+    // 128 accumulator registers + two weight sets + two operand sets spill inside the K loop: 75.1 vs 67.1 ms at C2,
+    // so 256-row plans keep the weights-from-L2 tile; VF_GSPLIT256=1 in a -DVF_DEBUG_KNOBS build selects it)
+    bool gs256 = false;
+#ifdef VF_DEBUG_KNOBS
+    if (const char *e = getenv("VF_GSPLIT256")) gs256 = atoi(e) != 0;
+#endif
+    l.gsplit = l.mode == PACK_LSTM && (l.mrep == 1 || (gs256 && l.mrep == 2 && l.NI == 1)) && l.prec == 0 && KC == 32 &&
+               l.KH == 5 && l.KW == 5;
     if (l.gsplit) {
         // no weight buffers in LDS, but the epilogue's gate exchange (64 KiB over the dead operand tile) + its scratch
-        const size_t b_lds = (size_t)2 * (KC / 8) * 4 * 64 * 16;
+        const size_t b_lds = l.mrep == 1 ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
         l.lds_bytes = std::max(l.lds_bytes - b_lds, (size_t)vf::kGsXchFloats * 4 + 64);
     }
     if (l.prec == 1) {
@@ -579,7 +587,8 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_CONVT_RAW_STATS, 1>, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_PARTIAL, 2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_bf16x6_kernel<1>, n))) return rc;
-    if ((rc = allow_lds(&conv_lstm_split_kernel<0>, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_gsplit_kernel<1>, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_gsplit_kernel<2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_split_kernel<2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_split_kernel<1>, n))) return rc;
     const size_t np = n + kCtlWords * sizeof(int);
@@ -601,8 +610,10 @@ static int launch_conv_m(const ConvLayer &l, const ConvParams &p, hipStream_t st
 
 static int launch_lstm_split(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
-    if (l.gsplit)
-        hipLaunchKernelGGL(conv_lstm_split_kernel<0>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
+    if (l.gsplit && l.mrep == 2)
+        hipLaunchKernelGGL(conv_lstm_gsplit_kernel<2>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
+    else if (l.gsplit)
+        hipLaunchKernelGGL(conv_lstm_gsplit_kernel<1>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     else if (l.mrep == 0)
         hipLaunchKernelGGL(conv_lstm_split_kernel<2>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     else
@@ -1226,7 +1237,7 @@ struct ScheduleSink {
         P.gx = l.NI == 1 ? p.B * P.tiles_per_img : (p.B + l.NI - 1) / l.NI;
         P.gy = l.ncg;
         P.whole = type == PH_FC_PARTIAL;
-        P.mrep = l.gsplit ? 3 : l.mrep;
+        P.mrep = l.gsplit ? (l.mrep == 2 ? 4 : 3) : l.mrep;
         P.prec = p.tile_variant;
         max_lds = std::max(max_lds, l.lds_bytes);
         const double rows = (double)p.B * l.Hout * l.Wout;
@@ -1323,7 +1334,11 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         const double K = 25.0 * (mid.segC[0] + mid.segC[1]);
         const double S = 2.0 * h->n_cu;
         struct Cand { int want; const ConvLayer *l; double fixed, slope; };
-        const Cand cands[4] = {{2, h->big_ok[k] ? &h->lstm_big[k] : nullptr, 45.0, 0.228},
+        // (round 3: the 128-row tile is the gate-split one now - 0.91 of the matrix pipe with the CU to itself against
+        // 0.84 for the 256-row tile, tools/trace_cu.py - and wins at every batch size from 100 to 1000 samples,
+        // profiles/r03_plan_sweep_gsplit.txt; the 256-row entry is priced so that the 15 % preference for the larger tile below
+        // no longer selects it)
+        const Cand cands[4] = {{2, h->big_ok[k] ? &h->lstm_big[k] : nullptr, 50.0, 0.300},
                                {1, &mid, 33.0, 0.114},
                                {3, h->half_ok[k] ? &h->lstm_half[k] : nullptr, 30.0, 0.057},
                                {4, h->quarter_ok[k] ? &h->lstm_quarter[k] : nullptr, 28.0, 0.030}};
