@@ -26,6 +26,7 @@ prec = sys.argv[2] if len(sys.argv) > 2 else 'fp32'
 WGS, MAXE = 512, 8192
 TICK_US = 0.01
 TR_TICKET, TR_DONE, TR_STAGE, TR_KLOOP, TR_LATE, TR_LATE_END, TR_EPI, TR_MFMAS, TR_HWID, TR_RUN = 1, 3, 10, 11, 12, 13, 14, 15, 20, 32
+TR_ST_LOADED, TR_ST_WRITTEN = 16, 17
 PH_LSTM = 0
 PH_NAMES = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED']
 
@@ -88,6 +89,10 @@ for w in range(WGS):
                 close(v, 'stage')
             elif c == TR_KLOOP:
                 close(v, 'K')
+            elif c == TR_ST_LOADED:
+                close(v, 'stage:ln+write')
+            elif c == TR_ST_WRITTEN:
+                close(v, 'stage:barrier')
             elif c == TR_LATE:
                 close(v, 'late')
             elif c == TR_LATE_END:
@@ -131,7 +136,7 @@ print('%d CUs host exactly two workgroups (%d CUs seen)' % (len(pairs), len(by_c
 
 
 def simplify(s):
-    return 'K' if s == 'K' else ('idle' if s in ('wait', 'late', 'sched') else 'other')
+    return 'K' if s == 'K' else ('idle' if s in ('wait', 'late', 'sched', 'stage:barrier') else 'other')
 
 
 joint = defaultdict(float)

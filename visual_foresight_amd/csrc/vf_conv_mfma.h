@@ -62,7 +62,7 @@ constexpr int kTraceWgs = 512;
 __device__ unsigned long long g_trace[(size_t)kTraceWgs * kTraceMax];
 __device__ unsigned g_trace_n[kTraceWgs];
 enum TraceCode { TR_TICKET = 1, TR_DONE = 3, TR_STAGE = 10, TR_KLOOP = 11, TR_LATE = 12, TR_LATE_END = 13, TR_EPI = 14,
-                 TR_MFMAS = 15 /* value: MFMAs per wave per chunk */, TR_HWID = 20 /* value: xcc << 16 | hw_id */,
+                 TR_MFMAS = 15 /* value: MFMAs per wave per chunk */, TR_ST_LOADED = 16, TR_ST_WRITTEN = 17, TR_HWID = 20 /* value: xcc << 16 | hw_id */,
                  TR_RUN = 32 /* + phase type */ };
 __device__ __forceinline__ void vf_trace(const unsigned code, const unsigned long long val = ~0ull) {
     if (threadIdx.x == 0 && blockIdx.x < kTraceWgs) {
@@ -1033,6 +1033,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
                             if constexpr (!NI1) off += (unsigned)img * img_step;
                             v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : 0xFFFFFFFFu, 0, 0));
                         }
+                        if constexpr (kInLaunch) { if (pix0 == pl) VF_TRACE_EVT(TR_ST_LOADED); }
 #pragma unroll
                         for (int u = 0; u < kStageU; ++u) {
                             const int pix = pix0 + u * ppp;
@@ -1117,6 +1118,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
         if constexpr (kBLds) {
             if (ci == ch_begin) { VF_WRITEB(0) }
         }
+        if constexpr (kInLaunch) VF_TRACE_EVT(TR_ST_WRITTEN);
         __syncthreads();
 #ifdef VF_TILE_STATS
         if (ci == ch_begin) ts1 = VF_TS_NOW(); else ts_stage += VF_TS_NOW() - ts_s0;
