@@ -640,14 +640,19 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
     const bool ni1 = p.NI == 1;
     const float bias = p.bias[(cg * 4 + wave) * 32 + n];
     StatSumD hstat;
+    // rounds of RBR row blocks through xch; in a round a wave finishes NK of the four 8-pixel groups of ONE row block:
+    // MR 4 / 8: row block (round * 4 + wave), all four groups; MR 2: row block (wave & 1), groups 2 (wave >> 1) + {0, 1}
+    constexpr int RBR = MR < 4 ? MR : 4, NK = RBR, ROUNDS = MR / RBR;
 #pragma unroll
-    for (int half = 0; half < MR / 4; ++half) {
-        const int rb = half * 4 + wave;                  // the row block this wave finishes in this round
-        unsigned off_o[4];
-        f32x4 c_old[4];
+    for (int half = 0; half < ROUNDS; ++half) {
+        const int rbl = MR < 4 ? (wave & (RBR - 1)) : wave;                 // row block within the round
+        const int k0 = MR < 4 ? NK * (wave / RBR) : 0;                      // first pixel group of this wave
+        const int rb = half * RBR + rbl;                 // the row block this wave finishes in this round
+        unsigned off_o[NK];
+        f32x4 c_old[NK];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int row = rb * 32 + pl + 8 * k;
+        for (int k = 0; k < NK; ++k) {
+            const int row = rb * 32 + pl + 8 * (k0 + k);
             int img = 0, rem = row;
             if (!ni1) { img = div_rpi.div(row); rem = row - img * p.RPI; }
             const int yy = div_tw.div(rem);
@@ -660,17 +665,17 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
         }
         __syncthreads();                    // the operand tile / the previous round's gates are no longer read
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < RBR; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xch[((m * 4 + wave) * 16 + r) * 64 + lane] = acc[half * 4 + m][0][r] + bias;
+            for (int r = 0; r < 16; ++r) xch[((m * 4 + wave) * 16 + r) * 64 + lane] = acc[half * RBR + m][0][r] + bias;
         __syncthreads();
         // GEMM row R = pl + 8 k of the block sits in accumulator row r = (R & 3) + 4 (R >> 3) of lane half (R >> 2) & 1
-        const float *xw = xch + ((wave * 4) * 16 + (pl & 3)) * 64 + 32 * ((pl >> 2) & 1) + 4 * cq;
+        const float *xw = xch + ((rbl * 4) * 16 + (pl & 3)) * 64 + 32 * ((pl >> 2) & 1) + 4 * cq;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NK; ++k) {
             f32x4 gate[4], cn, hn;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gate[g] = *reinterpret_cast<const f32x4 *>(xw + (g * 16 + 4 * k) * 64);
+            for (int g = 0; g < 4; ++g) gate[g] = *reinterpret_cast<const f32x4 *>(xw + (g * 16 + 4 * (k0 + k)) * 64);
             const bool live = off_o[k] != 0xFFFFFFFFu;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -683,29 +688,22 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, hn), r_out, off_o[k], 0, 0);
         }
     }
-    // exact integer reduction, as conv_epilogue (MR = 4: wave w = GEMM rows [32 w, 32 w + 32); the 256-row tile always
-    // holds ONE image - plan_geometry - so only the per-tile total is needed there)
+    // exact integer reduction (the 256-row tile always holds ONE image - plan_geometry - so only the per-tile total is
+    // needed there; otherwise wave w finished (part of) row block w, or w & 1 in the 64-row tile)
     const long long wsum = wave_sum(hstat.sum()), wsq = wave_sum(hstat.sumsq());
     if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
     __syncthreads();
-    if (p.NI == 1) {
-        if (tid == 0 && bimg0 < p.B) {
+    if (tid == 0) {
+        for (int img = 0; img < p.NI; ++img) {
+            if (bimg0 + img >= p.B) continue;
             long long su = 0, sq = 0;
-            for (int w = 0; w < 4; ++w) { su += red[2 * w]; sq += red[2 * w + 1]; }
-            long long *dst = p.stats + ((long long)bimg0 * p.stats_nparts + tile_id * p.ncg + cg) * 2;
-            dst[0] = su; dst[1] = sq;
-        }
-    } else {
-        const int waves_per_img = p.RPI / 32;
-        if (lane == 0 && (wave % waves_per_img) == 0) {
-            const int img = wave / waves_per_img;
-            const int b = bimg0 + img;
-            if (img < p.NI && b < p.B) {
-                long long su = 0, sq = 0;
-                for (int w = 0; w < waves_per_img; ++w) { su += red[2 * (wave + w)]; sq += red[2 * (wave + w) + 1]; }
-                long long *dst = p.stats + ((long long)b * p.stats_nparts + cg) * 2;
-                dst[0] = su; dst[1] = sq;
+            for (int w = 0; w < 4; ++w) {
+                const int wrb = MR < 4 ? (w & (MR - 1)) : w;
+                if (p.NI == 1 || (wrb * 32) / p.RPI == img) { su += red[2 * w]; sq += red[2 * w + 1]; }
             }
+            long long *dst = p.stats + ((long long)(bimg0 + img) * p.stats_nparts +
+                                        (p.NI == 1 ? tile_id * p.ncg + cg : cg)) * 2;
+            dst[0] = su; dst[1] = sq;
         }
     }
 }
@@ -731,10 +729,12 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     const int bx = __builtin_amdgcn_readfirstlane(bx_), by = __builtin_amdgcn_readfirstlane(by_),
               bz = __builtin_amdgcn_readfirstlane(bz_);
     constexpr bool SPLIT = RB == 1 || RB == 2;
-    constexpr bool GSPLIT = RB == 0;    // gate-split conv-LSTM tile: wave w = gate w of ALL 4 * MREP row blocks (128 / 256 rows)
-    static_assert(RB == 4 || (G == 4 && EPI == EPI_LSTM && ((SPLIT && MREP == 1) || GSPLIT)),
+    // gate-split conv-LSTM tiles: wave w = gate w of ALL row blocks of the workgroup - RB 0: 4 * MREP row blocks (128 /
+    // 256 rows), RB -2: two row blocks (64 rows, the plan of narrow phases)
+    constexpr bool GSPLIT = RB <= 0;
+    static_assert(RB == 4 || (G == 4 && EPI == EPI_LSTM && ((SPLIT && MREP == 1) || RB == 0 || (RB == -2 && MREP == 1))),
                   "the row-split and gate-split tiles are conv-LSTM tiles");
-    constexpr int MR = GSPLIT ? 4 * MREP : MREP;    // MFMA row blocks (accumulator tiles along the rows) per wave
+    constexpr int MR = RB == 0 ? 4 * MREP : (RB < 0 ? -RB : MREP);  // MFMA row blocks (accumulator tiles along the rows) per wave
     constexpr int WROWS = MR * 32;      // GEMM rows per wave
     constexpr int GA = GSPLIT ? 1 : (SPLIT ? RB : G);   // gates (accumulator tiles along the columns) per wave
     // Where the weight operand B comes from:
@@ -1154,12 +1154,13 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
             // every other plan: the same bits.
             // (MREP 2: eight row blocks per wave, worked through in two groups of four per k8 step - a "substep" is one
             // group's 16 MFMAs; the operands of substep s + 1 are fetched before the MFMAs of substep s are issued)
-            constexpr int NG = MR / 4, NS = 4 * NG;         // row-block groups, substeps per tap
+            constexpr int GSZ = MR < 4 ? MR : 4;            // row blocks per group (the 64-row tile has one group of two)
+            constexpr int NG = MR / GSZ, NS = 4 * NG;       // row-block groups, substeps per tap
             const f32x4 *ar[MR];
-            f32x4 aP4[4], aQ4[4];
-            auto gs_fetch = [&](f32x4 (&A_)[4], const int kx, const int sub) {
+            f32x4 aP4[GSZ], aQ4[GSZ];
+            auto gs_fetch = [&](f32x4 (&A_)[GSZ], const int kx, const int sub) {
 #pragma unroll
-                for (int m_ = 0; m_ < 4; ++m_) A_[m_] = ar[(sub % NG) * 4 + m_][kx * 9 + (sub / NG) * 2];
+                for (int m_ = 0; m_ < GSZ; ++m_) A_[m_] = ar[(sub % NG) * GSZ + m_][kx * 9 + (sub / NG) * 2];
             };
             auto gs_loadb = [&](f32x4 (&D_)[4], const int gt) {
                 // (unconditional: behind the item's last tap the last slice is simply fetched again - a branch around
@@ -1175,8 +1176,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
                 constexpr int KX = decltype(kxc)::value;
                 static_for<NS>([&](auto sc) {
                     constexpr int S = decltype(sc)::value;
-                    f32x4 (&a_cur)[4] = (S & 1) ? aQ4 : aP4;
-                    f32x4 (&a_nxt)[4] = (S & 1) ? aP4 : aQ4;
+                    f32x4 (&a_cur)[GSZ] = (S & 1) ? aQ4 : aP4;
+                    f32x4 (&a_nxt)[GSZ] = (S & 1) ? aP4 : aQ4;
                     if constexpr (S + 1 < NS) gs_fetch(a_nxt, KX, S + 1);
                     else if constexpr (KX < 4) gs_fetch(a_nxt, KX + 1, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -1188,9 +1189,9 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
 #pragma unroll
                     for (int j_ = 0; j_ < 4; ++j_) {
 #pragma unroll
-                        for (int m_ = 0; m_ < 4; ++m_)
-                            acc[(S % NG) * 4 + m_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                a_cur[m_][j_], bq[j_], acc[(S % NG) * 4 + m_][0], 0, 0, 0);
+                        for (int m_ = 0; m_ < GSZ; ++m_)
+                            acc[(S % NG) * GSZ + m_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                a_cur[m_][j_], bq[j_], acc[(S % NG) * GSZ + m_][0], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -1469,6 +1470,12 @@ template <int RB>
 VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_lstm_split_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     conv_tile<4, EPI_LSTM, 1, ConvParams, RB>(p, blockIdx.x, blockIdx.y, 0, smem);
+}
+
+// the gate-split 64-row tile
+VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_lstm_gsplit64_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_tile<4, EPI_LSTM, 1, ConvParams, -2>(p, blockIdx.x, blockIdx.y, 0, smem);
 }
 
 // the gate-split tiles: 128 (MREP 1) / 256 (MREP 2) rows per workgroup

@@ -229,11 +229,16 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
 #ifdef VF_DEBUG_KNOBS
     if (const char *e = getenv("VF_GSPLIT256")) gs256 = atoi(e) != 0;
 #endif
-    l.gsplit = l.mode == PACK_LSTM && (l.mrep == 1 || (gs256 && l.mrep == 2 && l.NI == 1)) && l.prec == 0 && KC == 32 &&
-               l.KH == 5 && l.KW == 5;
+    bool gs64 = true;
+#ifdef VF_DEBUG_KNOBS
+    if (const char *e = getenv("VF_GSPLIT64")) gs64 = atoi(e) != 0;
+#endif
+    l.gsplit = l.mode == PACK_LSTM && (l.mrep == 1 || (gs64 && l.mrep == 0) || (gs256 && l.mrep == 2 && l.NI == 1)) &&
+               l.prec == 0 && KC == 32 && l.KH == 5 && l.KW == 5;
     if (l.gsplit) {
-        // no weight buffers in LDS, but the epilogue's gate exchange (64 KiB over the dead operand tile) + its scratch
-        const size_t b_lds = l.mrep == 1 ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
+        // no weight buffers in LDS, but the epilogue's gate exchange (64 KiB over the dead operand tile; 32 KiB for the
+        // 64-row tile) + its scratch
+        const size_t b_lds = l.mrep <= 1 ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
         l.lds_bytes = std::max(l.lds_bytes - b_lds, (size_t)vf::kGsXchFloats * 4 + 64);
     }
     if (l.prec == 1) {
@@ -587,6 +592,7 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_CONVT_RAW_STATS, 1>, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_PARTIAL, 2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_bf16x6_kernel<1>, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_gsplit64_kernel, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_gsplit_kernel<1>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_gsplit_kernel<2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_split_kernel<2>, n))) return rc;
@@ -612,6 +618,8 @@ static int launch_lstm_split(const ConvLayer &l, const ConvParams &p, hipStream_
     const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
     if (l.gsplit && l.mrep == 2)
         hipLaunchKernelGGL(conv_lstm_gsplit_kernel<2>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
+    else if (l.gsplit && l.mrep == 0)
+        hipLaunchKernelGGL(conv_lstm_gsplit64_kernel, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     else if (l.gsplit)
         hipLaunchKernelGGL(conv_lstm_gsplit_kernel<1>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     else if (l.mrep == 0)
@@ -1237,7 +1245,7 @@ struct ScheduleSink {
         P.gx = l.NI == 1 ? p.B * P.tiles_per_img : (p.B + l.NI - 1) / l.NI;
         P.gy = l.ncg;
         P.whole = type == PH_FC_PARTIAL;
-        P.mrep = l.gsplit ? (l.mrep == 2 ? 4 : 3) : l.mrep;
+        P.mrep = l.gsplit ? (l.mrep == 2 ? 4 : (l.mrep == 0 ? 5 : 3)) : l.mrep;
         P.prec = p.tile_variant;
         max_lds = std::max(max_lds, l.lds_bytes);
         const double rows = (double)p.B * l.Hout * l.Wout;
