@@ -81,7 +81,8 @@ for w in range(WGS):
             close(v, 'sched')
         elif not lstm and state is not None and state.startswith('light:'):
             base = ':'.join(state.split(':')[:2])
-            sub = {TR_STAGE: 'stage', TR_KLOOP: 'K', TR_EPI: 'epi', TR_LATE: 'late', TR_LATE_END: 'stage'}.get(int(c))
+            sub = {TR_STAGE: 'stage', TR_KLOOP: 'K', TR_EPI: 'epi', TR_LATE: 'late', TR_LATE_END: 'stage',
+                   24: 'epi:halo', 25: 'epi:mates', 26: 'epi:compose'}.get(int(c))
             if sub:
                 close(v, base + ':' + sub)
         elif lstm:
@@ -117,7 +118,7 @@ for w, iv in wg_iv.items():
     for t0, t1, s, _ in iv:
         if s.startswith('light:'):
             parts = s.split(':')
-            light[(parts[1], parts[2] if len(parts) > 2 else 'pro')] += (t1 - t0) * TICK_US
+            light[(parts[1], ':'.join(parts[2:]) if len(parts) > 2 else 'pro')] += (t1 - t0) * TICK_US
             if len(parts) == 2:
                 lightn[parts[1]] += 1
 print('   light items: type, items per slot, ms per slot (us per item) by part')
@@ -125,7 +126,7 @@ for ty in sorted(set(k[0] for k in light)):
     n = max(lightn[ty], 1)
     tot_ty = sum(v for k, v in light.items() if k[0] == ty)
     print('   %-11s %6.1f items  %5.2f ms (%6.1f us):  ' % (ty, n / nw, tot_ty / nw / 1e3, tot_ty / n) +
-          '  '.join('%s %.1f' % (part, light[(ty, part)] / n) for part in ('pro', 'stage', 'K', 'late', 'epi') if (ty, part) in light))
+          '  '.join('%s %.1f' % (part, light[(ty, part)] / n) for part in ('pro', 'stage', 'K', 'late', 'epi', 'epi:halo', 'epi:mates', 'epi:compose') if (ty, part) in light))
 
 # ---- pair the workgroups of a CU
 by_cu = defaultdict(list)

@@ -29,7 +29,7 @@ constexpr int kFusedCtlGoal = 8;        // == kCtlGoal of vf_persistent.h (check
 // LDS floats the fused epilogue needs for a tile of TH x TW input pixels (host + device)
 __host__ __device__ inline size_t fused_top_lds_floats(int TH, int TW, int ND) {
     const size_t halo = (size_t)(2 * TH + 4) * (2 * TW + 4);
-    return (size_t)256 * kCompEncPad + halo * (3 + ND) + (size_t)kTaps * 10 + 16 + 64;
+    return (size_t)256 * kCompEncPad + halo * comp_px_stride(ND) + (size_t)kTaps * kCompKernPad + 16 + 64;
 }
 
 template <int ND, bool FIRST, class PT, class CT>
@@ -76,16 +76,17 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
     }
     __syncthreads();                        // red is dead from here on: the LDS below may cover it
     [[maybe_unused]] const unsigned long long tf1 = VF_TS_NOW();
+    VF_TRACE_EVT(TR_TOP_STATS);
 
     // ---- LDS layout of the compositing part
     const int RH = 2 * p.TH, RW = 2 * p.TW;             // output region of this tile
     const int HW_ = RW + 4, HH_ = RH + 4;               // its halo tile
     const int oy0 = 2 * ty0, ox0 = 2 * tx0;
     float *s_enc = smem;                                 // [256][kCompEncPad]
-    float *s_frame = s_enc + 256 * kCompEncPad;          // [HH_ * HW_][3]
-    float *s_dist = s_frame + HH_ * HW_ * 3;             // [HH_ * HW_][ND]
-    float *s_kern = s_dist + HH_ * HW_ * ND;             // [kTaps * K]
-    float *s_ln = s_kern + kTaps * K;                    // [2]
+    constexpr int PS = comp_px_stride(ND);
+    float *s_px = s_enc + 256 * kCompEncPad;             // [HH_ * HW_][PS]: frame, distributions (composite_pixel)
+    float *s_kern = s_px + HH_ * HW_ * PS;               // [kTaps][kCompKernPad]
+    float *s_ln = s_kern + kTaps * kCompKernPad;         // [2]
     float *s_dscale = s_ln + 2;                          // [ND]
     int *s_flag = reinterpret_cast<int *>(s_dscale + ND + 1);
     const int nblocks = sum_blocks(c.H, c.W);
@@ -102,7 +103,7 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
         }
         if (lane == 0) s_dscale[d] = sc;
     }
-    for (int i = tid; i < kTaps * K; i += 256) s_kern[i] = c.kern[(long long)b * kTaps * K + i];
+    for (int i = tid; i < kTaps * K; i += 256) s_kern[(i / K) * kCompKernPad + i % K] = c.kern[(long long)b * kTaps * K + i];
     __syncthreads();
     {
         const float *pf = c.prev_frame + (long long)b * c.prev_frame_bstride;
@@ -114,13 +115,14 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
             const bool in = y >= 0 && y < c.H && x >= 0 && x < c.W;
             const long long o = (long long)y * c.W + x;
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) s_frame[i * 3 + ch] = in ? pf[o * 3 + ch] : 0.f;
+            for (int ch = 0; ch < 3; ++ch) s_px[i * PS + ch] = in ? pf[o * 3 + ch] : 0.f;
 #pragma unroll
-            for (int d = 0; d < ND; ++d) s_dist[i * ND + d] = in ? pd[o * ND + d] * s_dscale[d] : 0.f;
+            for (int d = 0; d < ND; ++d) s_px[i * PS + 3 + d] = in ? pd[o * ND + d] * s_dscale[d] : 0.f;
         }
     }
 
     [[maybe_unused]] const unsigned long long tf2 = VF_TS_NOW();
+    VF_TRACE_EVT(TR_TOP_HALO);
     // ---- 4. wait for the sample's other tiles, then the LayerNorm of the whole image
     if (wave == 0) {
         unsigned spins = 0;
@@ -158,6 +160,7 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
     }
     const float mean = s_ln[0], rstd = s_ln[1];
     [[maybe_unused]] const unsigned long long tf3 = VF_TS_NOW();
+    VF_TRACE_EVT(TR_TOP_MATES);
 
     // ---- 5. four blocks (4 rows x 16 columns, one per wave) at a time through LDS
     const int nbx = RW / kSumBlockW, nby = RH / kSumBlockH, nblk = nbx * nby;
@@ -186,7 +189,7 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
 #pragma unroll
         for (int i = 0; i < 2 * ND; ++i) cost[i] = 0.0;
         if (valid)
-            composite_pixel<ND, K, FIRST>(c, b, y, x, &s_enc[tid * kCompEncPad], mean, rstd, s_frame, s_dist, s_kern, HW_,
+            composite_pixel<ND, K, FIRST>(c, b, y, x, &s_enc[tid * kCompEncPad], mean, rstd, s_px, s_kern, HW_,
                                           hy, hx, goal, cost);
 #pragma unroll
         for (int i = 0; i < 2 * ND; ++i) cost[i] = wave_sum(cost[i]);

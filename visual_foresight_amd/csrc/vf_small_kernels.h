@@ -140,9 +140,14 @@ struct CompositeParams {
 
 // LDS floats needed by composite_tile<ND, K>
 constexpr int kCompEncPad = 36;         // floats per pixel row of the staged feature tile (32 + 4: conflict-free b128 reads)
+// The haloed previous frame and distributions sit in LDS as ONE record per pixel - [r, g, b, d0 | d1, d2, d3, -] - and
+// the sample's CDNA kernels as one 12-float row per tap, so the 25 taps of a pixel cost 25 x (1 or 2) + 25 x 3
+// ds_read_b128 / b32 instead of 25 x (3 + ND) + 25 x 9 ds_read_b32: the compositing is LDS-instruction bound.
+__host__ __device__ constexpr int comp_px_stride(int nd) { return nd <= 1 ? 4 : 8; }
+constexpr int kCompKernPad = 12;        // floats per tap row of the CDNA kernels in LDS (K <= 10 used, 16-byte aligned rows)
 template <int ND, int K>
 __host__ __device__ constexpr int composite_small_floats() {
-    return (kCompTile + 4) * (kCompTile + 4) * (3 + ND) + kTaps * K + 2 + ND + 2 /*pad*/ + 2 * 4 * 2 * ND;
+    return (kCompTile + 4) * (kCompTile + 4) * comp_px_stride(ND) + kTaps * kCompKernPad + 2 + ND + 2 /*pad*/ + 2 * 4 * 2 * ND;
 }
 template <int ND, int K>
 __host__ __device__ constexpr int composite_lds_floats() {
@@ -156,28 +161,47 @@ __host__ __device__ constexpr int composite_lds_floats() {
 // same bits.
 template <int ND, int K, bool FIRST, class PT>
 __device__ __forceinline__ void composite_pixel(const PT &p, const int b, const int y, const int x, const float *feat,
-                                                const float mean, const float rstd, const float *s_frame,
-                                                const float *s_dist, const float *s_kern, const int halo_w,
+                                                const float mean, const float rstd, const float *s_px,
+                                                const float *s_kern, const int halo_w,
                                                 const int hy, const int hx, const int *goal, double (&cost)[2 * ND]) {
     constexpr int NM = K + 1;
-    // ---- LN9 + relu of this pixel's 32 features, then the two 1x1 heads
+    constexpr int PS = comp_px_stride(ND);
+    static_assert(K <= 10 && ND <= 4, "LDS record layouts");
+    // one halo pixel: frame[3], distributions[ND]
+    auto load_px = [&](const int sp, float (&fr)[3], float (&di)[ND]) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(s_px + sp * PS);
+        fr[0] = a[0]; fr[1] = a[1]; fr[2] = a[2]; di[0] = a[3];
+        if constexpr (ND > 1) {
+            const f32x4 c2 = *reinterpret_cast<const f32x4 *>(s_px + sp * PS + 4);
+#pragma unroll
+            for (int d = 1; d < ND; ++d) di[d] = c2[d - 1];
+        }
+    };
+    // ---- LN9 + relu of this pixel's 32 features, then the two 1x1 heads.  The 512 head / LayerNorm weights are the
+    // same for every lane: read through the CONSTANT address space they are scalar loads feeding the VALU as SGPR
+    // operands - as plain global pointers the compiler issued 132 vector loads (and as many waits) per pixel, which was
+    // half of the compositing time.
+    typedef const __attribute__((address_space(4))) float cfloat;
+    auto as_const = [](const float *q) { return (cfloat *)(unsigned long long)q; };
+    cfloat *gam_ = as_const(p.gamma), *bet_ = as_const(p.beta), *wrgb_ = as_const(p.w_rgb), *wmask_ = as_const(p.w_mask);
+    cfloat *brgb_ = as_const(p.b_rgb), *bmask_ = as_const(p.b_mask);
     const f32x4 *src = reinterpret_cast<const f32x4 *>(feat);
     float o_rgb[3], o_m[NM];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) o_rgb[j] = p.b_rgb[j];
+    for (int j = 0; j < 3; ++j) o_rgb[j] = brgb_[j];
 #pragma unroll
-    for (int j = 0; j < NM; ++j) o_m[j] = p.b_mask[j];
+    for (int j = 0; j < NM; ++j) o_m[j] = bmask_[j];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const f32x4 raw = src[q];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = q * 4 + e;
-            const float f = fmaxf(fmaf((raw[e] - mean) * rstd, p.gamma[c], p.beta[c]), 0.f);
+            const float f = fmaxf(fmaf((raw[e] - mean) * rstd, gam_[c], bet_[c]), 0.f);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) o_rgb[j] = fmaf(f, p.w_rgb[c * 3 + j], o_rgb[j]);
+            for (int j = 0; j < 3; ++j) o_rgb[j] = fmaf(f, wrgb_[c * 3 + j], o_rgb[j]);
 #pragma unroll
-            for (int j = 0; j < NM; ++j) o_m[j] = fmaf(f, p.w_mask[c * NM + j], o_m[j]);
+            for (int j = 0; j < NM; ++j) o_m[j] = fmaf(f, wmask_[c * NM + j], o_m[j]);
         }
     }
     float mx = o_m[0];
@@ -194,11 +218,14 @@ __device__ __forceinline__ void composite_pixel(const PT &p, const int b, const 
     // (arch 1: mask 2 weighs the first context frame, the warps use masks 3.. and kernels 0..K-3)
     float of[3], od[ND];
     const int ctr = (hy + 2) * halo_w + (hx + 2);
+    {
+        float fr[3], di[ND];
+        load_px(ctr, fr, di);
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-        of[c] = fmaf(o_m[0], s_frame[ctr * 3 + c], o_m[1] * sigmoidf_(o_rgb[c]));
+        for (int c = 0; c < 3; ++c) of[c] = fmaf(o_m[0], fr[c], o_m[1] * sigmoidf_(o_rgb[c]));
 #pragma unroll
-    for (int d = 0; d < ND; ++d) od[d] = o_m[0] * s_dist[ctr * ND + d];
+        for (int d = 0; d < ND; ++d) od[d] = o_m[0] * di[d];
+    }
     if constexpr (FIRST) {
         const long long o1 = (long long)y * p.W + x;
 #pragma unroll
@@ -216,14 +243,23 @@ __device__ __forceinline__ void composite_pixel(const PT &p, const int b, const 
 #pragma unroll
         for (int dx = 0; dx < kDnaKern; ++dx) {
             const int tap = dy * kDnaKern + dx;
+            float kr[kCompKernPad];
+#pragma unroll
+            for (int q = 0; q < (K - 1 + 3) / 4; ++q) {
+                const f32x4 kq = *reinterpret_cast<const f32x4 *>(s_kern + tap * kCompKernPad + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kr[4 * q + e] = kq[e];
+            }
             float ke = 0.f;
 #pragma unroll
-            for (int k = 0; k < K - 1; ++k) ke = fmaf(o_m[k + 2], s_kern[tap * K + k], ke);
+            for (int k = 0; k < K - 1; ++k) ke = fmaf(o_m[k + 2], kr[k], ke);
             const int sp = (hy + dy) * halo_w + (hx + dx);
+            float fr[3], di[ND];
+            load_px(sp, fr, di);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) of[c] = fmaf(ke, s_frame[sp * 3 + c], of[c]);
+            for (int c = 0; c < 3; ++c) of[c] = fmaf(ke, fr[c], of[c]);
 #pragma unroll
-            for (int d = 0; d < ND; ++d) od[d] = fmaf(ke, s_dist[sp * ND + d], od[d]);
+            for (int d = 0; d < ND; ++d) od[d] = fmaf(ke, di[d], od[d]);
         }
     }
     const long long o = (long long)y * p.W + x;
@@ -249,10 +285,10 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
                                                float *smem) {
     constexpr int TS = kCompTile, HS = TS + 4;
     constexpr int NM = K + 1;
-    float *s_frame = smem;                              // [HS*HS*3]
-    float *s_dist = s_frame + HS * HS * 3;              // [HS*HS*ND]
-    float *s_kern = s_dist + HS * HS * ND;              // [kTaps*K]
-    float *s_ln = s_kern + kTaps * K;                   // [2]
+    constexpr int PS = comp_px_stride(ND);
+    float *s_px = smem;                                 // [HS*HS][PS]: frame, distributions
+    float *s_kern = s_px + HS * HS * PS;                // [kTaps][kCompKernPad]
+    float *s_ln = s_kern + kTaps * kCompKernPad;        // [2]
     float *s_dscale = s_ln + 2;                         // [ND]
     float *s_enc = smem + ((composite_small_floats<ND, K>() + 3) & ~3);     // [TS*TS][kCompEncPad]
 
@@ -298,7 +334,7 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
             if (lane_ == 0) s_dscale[d] = sc;
         }
     }
-    for (int i = tid; i < kTaps * K; i += 256) s_kern[i] = p.kern[(long long)b * kTaps * K + i];
+    for (int i = tid; i < kTaps * K; i += 256) s_kern[(i / K) * kCompKernPad + i % K] = p.kern[(long long)b * kTaps * K + i];
     __syncthreads();
 
     const float *pf = p.prev_frame + (long long)b * p.prev_frame_bstride;
@@ -309,9 +345,9 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
         const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W;
         const long long o = (long long)y * p.W + x;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s_frame[i * 3 + c] = in ? pf[o * 3 + c] : 0.f;
+        for (int c = 0; c < 3; ++c) s_px[i * PS + c] = in ? pf[o * 3 + c] : 0.f;
 #pragma unroll
-        for (int d = 0; d < ND; ++d) s_dist[i * ND + d] = in ? pd[o * ND + d] * s_dscale[d] : 0.f;
+        for (int d = 0; d < ND; ++d) s_px[i * PS + 3 + d] = in ? pd[o * ND + d] * s_dscale[d] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -328,7 +364,7 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
     for (int i = 0; i < 2 * ND; ++i) cost[i] = 0.0;
 
     if (valid)
-        composite_pixel<ND, K, FIRST>(p, b, y, x, &s_enc[tid * kCompEncPad], s_ln[0], s_ln[1], s_frame, s_dist, s_kern, HS,
+        composite_pixel<ND, K, FIRST>(p, b, y, x, &s_enc[tid * kCompEncPad], s_ln[0], s_ln[1], s_px, s_kern, HS,
                                       ly, lx, goal, cost);
     // ---- cost sums of this wave's block (4 rows x 16 columns): lanes in a fixed butterfly, one entry per block
 #pragma unroll
