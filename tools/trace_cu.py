@@ -175,6 +175,8 @@ for (s1, s2), v in joint.items():
 for k, v in sorted(sym.items(), key=lambda kv: -kv[1]):
     print('   %-14s %5.1f %%' % ('%s + %s' % k, 100.0 * v / npair / span))
 X, Y = np.array(X), np.array(Y, dtype=np.float64)
+if len(Y) == 0:
+    sys.exit(0)         # (the split-bf16 tile logs no K-loop events)
 for mfc in sorted(set(Y.tolist())):
     sel = Y == mfc
     rr, *_ = np.linalg.lstsq(X[sel], Y[sel], rcond=None)
