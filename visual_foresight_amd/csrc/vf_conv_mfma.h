@@ -796,13 +796,16 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     // ---- this lane's A rows (GEMM rows wave*WROWS + m*32 + n)
     const int px_per_img = p.TH * p.TW;
     int abase[MR];
+    {
+        const TileDiv div_rpi(p.RPI), div_tw(p.TW);     // (multiply-high instead of four integer divisions per row block)
 #pragma unroll
-    for (int m = 0; m < MR; ++m) {
-        const int row = wrow0 + m * 32 + n;
-        const int img = row / p.RPI, rem = row % p.RPI;
-        const bool ok = img < p.NI && rem < px_per_img;
-        const int y = rem / p.TW, x = rem % p.TW;
-        abase[m] = (ok ? (img * tile_px + y * p.stride * LW + x * p.stride) * KCpad : 0) + kh * 4;
+        for (int m = 0; m < MR; ++m) {
+            const int row = wrow0 + m * 32 + n;
+            const int img = div_rpi.div(row), rem = row - img * p.RPI;
+            const bool ok = img < p.NI && rem < px_per_img;
+            const int y = div_tw.div(rem), x = rem - y * p.TW;
+            abase[m] = (ok ? (img * tile_px + y * p.stride * LW + x * p.stride) * KCpad : 0) + kh * 4;
+        }
     }
 
     f32x16 acc[MR][GA];
