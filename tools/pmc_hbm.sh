@@ -35,7 +35,8 @@ json.dump({'kernel': 'rollout_persistent_kernel<1>', 'workload': 'c2', 'precisio
            'WRITE_SIZE_KiB_per_launch': res['WRITE_SIZE'][1], 'hbm_bytes_per_launch': total,
            'algorithmic_bytes_per_launch': algorithmic, 'ratio_to_algorithmic': total / algorithmic,
            'correction': 'MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports half the bytes of a wide '
-                         'coalesced read, so the read side is doubled; WRITE_SIZE is uncalibrated and taken as is; '
-                         'Infinity-Cache hits are included in both'},
+                         'coalesced read, so the read side is doubled; both counters calibrated with '
+                         'tools/ubench/hbm_calib.hip on the rollout\'s access patterns (FETCH 0.500x, WRITE 1.000x, '
+                         'profiles/r03_hbm_calib.txt); Infinity-Cache hits are included in both'},
           open('$R/gpurun_out/hbm_traffic.json', 'w'), indent=1)
 PY

@@ -39,4 +39,15 @@ python tools/persist_stats.py 25 > $O/phase_stats_25.txt 2>&1
 python tools/persist_stats.py 125 64 cdna 15 > $O/phase_stats_125.txt 2>&1
 python tools/persist_stats.py 625 128 savp 15 > $O/phase_stats_c5_shard.txt 2>&1
 python bench.py --gpus 2 --no-alt --no-cpu-baseline --steps 4 --warmup 1 2>/dev/null | tail -1 > $O/bench_2ranks_gloo_dryrun.json; python tools/bench_line.py $O/bench_2ranks_gloo_dryrun.json 2ranks-gloo
-rm -rf $O/ktrace $O/ktrace16 gpurun_out/hbm_FETCH_SIZE gpurun_out/hbm_WRITE_SIZE gpurun_out/mfma_pmc
+# 6. what the two workgroups of a CU are doing (event-log build, tools/build_variants.sh), micro-benchmarks, counter
+#    calibration, instruction mix
+if [ -f build/ab/trace.so ]; then
+  VF_LIBRARY=build/ab/trace.so timeout 300 python tools/trace_cu.py 200 > $O/cu_trace_200.txt 2>&1
+  VF_TRACE_TIMELINE=1 VF_LIBRARY=build/ab/trace.so timeout 300 python tools/trace_cu.py 200 2>&1 | awk '/^timeline/{f=1} f' > $O/cu_trace_200_timeline.txt
+  VF_LIBRARY=build/ab/trace.so timeout 300 python tools/trace_cu.py 25 > $O/cu_trace_25.txt 2>&1
+fi
+[ -x tools/ubench/mfma_shadow ] && timeout 120 tools/ubench/mfma_shadow > $O/mfma_shadow_ubench.txt 2>&1
+[ -x tools/ubench/hbm_calib ] && timeout 300 bash tools/pmc_calib.sh > /dev/null 2>&1 && cp gpurun_out/hbm_calib.txt $O/hbm_calib.txt
+timeout 600 bash tools/pmc_sq.sh > /dev/null 2>&1; cp gpurun_out/sq_mix.txt $O/sq_mix.txt
+python tools/precision_check.py > $O/precision_check.txt 2>&1
+rm -rf $O/ktrace $O/ktrace16 gpurun_out/hbm_FETCH_SIZE gpurun_out/hbm_WRITE_SIZE gpurun_out/mfma_pmc gpurun_out/sq_mix1 gpurun_out/sq_mix2 gpurun_out/sq_mix3 gpurun_out/calib_FETCH_SIZE gpurun_out/calib_WRITE_SIZE
