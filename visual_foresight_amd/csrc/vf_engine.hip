@@ -153,6 +153,7 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
     int mrep;                       // MFMA row blocks per wave: the workgroup covers 128 * mrep rows;
                                     // 0 / -1 = the 64- / 32-row conv-LSTM tiles (waves split rows x gates)
     int prec = 0;                   // 1: split-bf16 tile (conv-LSTM only)
+    bool gs_v2 = false;              // ... in its final form (vf_conv_gsplit.h: one rolling weight register set)
     bool gsplit = false;            // 128-row fp32 conv-LSTM tile with 32-channel chunks: the gate-split tile (wave w =
                                     // gate w of all four row blocks, weights from L2 into registers, no barrier per tap)
     int NI, TH, TW, RPI, tilesY, tilesX;
@@ -197,6 +198,9 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
         l.TH = l.TW = 1; l.tilesY = l.tilesX = 1; l.RPI = 1; l.NI = rows;
     } else {
         l.TW = std::min(l.Wout, 32);
+        // the gate-split 128-row conv-LSTM tile (vf_conv_gsplit.h): 8 x 16 output pixels have a smaller halo than 4 x 32
+        // (240 instead of 288 staged pixels per chunk)
+        if (l.mode == PACK_LSTM && l.prec == 0 && l.mrep == 1 && l.KH == 5 && l.KW == 5) l.TW = std::min(l.Wout, 16);
 #ifdef VF_DEBUG_KNOBS
         if (const char *e = getenv("VF_TILE_W")) l.TW = std::min(l.Wout, std::max(8, atoi(e)));
 #endif
@@ -235,10 +239,17 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
 #endif
     l.gsplit = l.mode == PACK_LSTM && (l.mrep == 1 || (gs64 && l.mrep == 0) || (gs256 && l.mrep == 2 && l.NI == 1)) &&
                l.prec == 0 && KC == 32 && l.KH == 5 && l.KW == 5;
+    l.gs_v2 = false;
     if (l.gsplit) {
         // no weight buffers in LDS, but the epilogue's gate exchange (64 KiB over the dead operand tile; 32 KiB for the
         // 64-row tile) + its scratch
         const size_t b_lds = l.mrep <= 1 ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
+        const int LH = (l.TH - 1) * l.stride + l.KH, LW = (l.TW - 1) * l.stride + l.KW;
+        // the final form of the 128-row tile (vf_conv_gsplit.h) stages ten elements per thread at most
+        l.gs_v2 = l.mrep == 1 && l.stride == 1 && (size_t)l.NI * LH * LW <= 320;
+#ifdef VF_DEBUG_KNOBS
+        if (const char *e = getenv("VF_GSPLIT_V2")) l.gs_v2 = l.gs_v2 && atoi(e) != 0;
+#endif
         l.lds_bytes = std::max(l.lds_bytes - b_lds, (size_t)vf::kGsXchFloats * 4 + 64);
     }
     if (l.prec == 1) {
@@ -593,6 +604,7 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_PARTIAL, 2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_bf16x6_kernel<1>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_gsplit64_kernel, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_gsplit2_kernel<4>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_gsplit_kernel<1>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_gsplit_kernel<2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_split_kernel<2>, n))) return rc;
@@ -618,6 +630,8 @@ static int launch_lstm_split(const ConvLayer &l, const ConvParams &p, hipStream_
     const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
     if (l.gsplit && l.mrep == 2)
         hipLaunchKernelGGL(conv_lstm_gsplit_kernel<2>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
+    else if (l.gs_v2)
+        hipLaunchKernelGGL(conv_lstm_gsplit2_kernel<4>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     else if (l.gsplit && l.mrep == 0)
         hipLaunchKernelGGL(conv_lstm_gsplit64_kernel, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     else if (l.gsplit)
@@ -1245,7 +1259,7 @@ struct ScheduleSink {
         P.gx = l.NI == 1 ? p.B * P.tiles_per_img : (p.B + l.NI - 1) / l.NI;
         P.gy = l.ncg;
         P.whole = type == PH_FC_PARTIAL;
-        P.mrep = l.gsplit ? (l.mrep == 2 ? 4 : (l.mrep == 0 ? 5 : 3)) : l.mrep;
+        P.mrep = l.gsplit ? (l.mrep == 2 ? 4 : (l.mrep == 0 ? 5 : (l.gs_v2 ? 6 : 3))) : l.mrep;
         P.prec = p.tile_variant;
         max_lds = std::max(max_lds, l.lds_bytes);
         const double rows = (double)p.B * l.Hout * l.Wout;

@@ -20,6 +20,7 @@
 #include "vf_conv_mfma.h"
 #include "vf_small_kernels.h"
 #include "vf_conv_bf16x6.h"
+#include "vf_conv_gsplit.h"
 #include "vf_fused_top.h"
 
 namespace vf {
@@ -54,7 +55,8 @@ struct PhaseDesc {
     int NI, tiles_per_img;  // conv phases: how an item maps to samples
     int whole;              // 1: completion is counted once per item on counter 0
     int mrep;               // MFMA row blocks per wave of this conv phase (1 or 2; 0 / -1: the 64- / 32-row conv-LSTM
-                            // tiles; 3 / 4 / 5: the gate-split 128- / 256- / 64-row conv-LSTM tiles)
+                            // tiles; 3 / 4 / 5: the gate-split 128- / 256- / 64-row conv-LSTM tiles of vf_conv_mfma.h;
+                            // 6: the gate-split 128-row tile of vf_conv_gsplit.h)
     int prec;               // conv-LSTM tile: 0 exact fp32, 1 split-bf16
     int view;               // camera view this phase belongs to (selects the goal pixels of PH_COMPOSITE)
     int cnt_base;
@@ -143,6 +145,10 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void lstm_split_
 template <int MREP>
 static __device__ __noinline__ __attribute__((not_tail_called)) void lstm_gsplit_tile_call(const ConvParams *p, int bx, int by) {
     conv_tile<4, EPI_LSTM, MREP, const VF_CONST_AS ConvParams, 0>(const_params(p), bx, by, 0, tile_lds());
+}
+template <int MR>
+static __device__ __noinline__ __attribute__((not_tail_called)) void lstm_gsplit2_tile_call(const ConvParams *p, int bx, int by) {
+    conv_lstm_gsplit2_tile<MR>(const_params(p), bx, by, tile_lds());
 }
 static __device__ __noinline__ __attribute__((not_tail_called)) void lstm_gsplit64_tile_call(const ConvParams *p, int bx, int by) {
     conv_tile<4, EPI_LSTM, 1, const VF_CONST_AS ConvParams, -2>(const_params(p), bx, by, 0, tile_lds());
@@ -288,6 +294,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                     else if (P.mrep == 3) lstm_gsplit_tile_call<1>(&P.conv, bx, by);       // gate-split 128-row tile
                     else if (P.mrep == 4) lstm_gsplit_tile_call<2>(&P.conv, bx, by);       // gate-split 256-row tile
                     else if (P.mrep == 5) lstm_gsplit64_tile_call(&P.conv, bx, by);        // gate-split 64-row tile
+                    else if (P.mrep == 6) lstm_gsplit2_tile_call<4>(&P.conv, bx, by);    // gate-split 128-row tile, final form
                     else if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
                     else conv_tile_call<4, EPI_LSTM, 2>(&P.conv, bx, by, 0);
                     break;
