@@ -911,11 +911,18 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
 #define VF_TAPLIVE(TAP_) (kConvT ? ((((TAP_) >= p.KW) ? 15 : 3) & ((((TAP_) % p.KW) != 0) ? 15 : 5)) : 15)
     // ring slot SLOT_ <- B of step IT_ of chunk CI_ (a transposed conv fetches its dead parity blocks - zeros - too:
     // unconditional loads keep the ring in plain registers; only the MFMAs on them are skipped)
+    // (raw buffer loads: the lane's offset in one VGPR, the (chunk, step, gate) offset on the scalar unit - no 64-bit
+    // vector address arithmetic inside the K loops of the light layers either)
+    [[maybe_unused]] const unsigned gr_loff = (unsigned)(((kh * Ntot + (cg * G) * 32 + n) * 4) * 4);
+    [[maybe_unused]] const unsigned gr_wstep_b = (unsigned)wstep * 4u;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t gr_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.Wp), 0, 0x7FFFFFFF, 0x00020000);
 #define VF_GLOAD(SLOT_, CI_, IT_)                                                               \
     {                                                                                           \
-        const float *wp_ = wlane + ((long long)(CI_) * nit_g + (IT_)) * wstep;                  \
+        const unsigned so_ = (unsigned)((CI_) * nit_g + (IT_)) * gr_wstep_b;                    \
         _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_)                                        \
-            gring[SLOT_][g_] = *reinterpret_cast<const f32x4 *>(wp_ + 128 * g_);                \
+            gring[SLOT_][g_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128( \
+                gr_rsrc, gr_loff, so_ + 512u * g_, 0));                                          \
     }
     if constexpr (kGRing) {
         if (ch_begin < ch_end) {
