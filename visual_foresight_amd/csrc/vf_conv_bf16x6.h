@@ -117,6 +117,7 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx_
             ln_table(p, bimg0, lnTab, 1, 2);
         }
         __syncthreads();
+        if constexpr (!std::is_same<PT, ConvParams>::value) VF_TRACE_EVT(TR_STAGE);
         for (int it = tid; it < items; it += kConvThreads) {
             const int pix = it >> 1, oct = it & 1;
             const int img = pix / tile_px, r = pix - img * tile_px;
@@ -161,6 +162,10 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx_
         }
         if (ci == 0) { VF_WRITEB16(0) }
         __syncthreads();
+        if constexpr (!std::is_same<PT, ConvParams>::value) {
+            if (ci == 0) VF_TRACE_EVT(TR_MFMAS, (unsigned long long)(ntaps * 6 * G * MREP));
+            VF_TRACE_EVT(TR_KLOOP);
+        }
 
         for (int ky = 0; ky < p.KH; ++ky) {
             for (int kx = 0; kx < p.KW; ++kx) {
@@ -193,6 +198,7 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx_
     }
 #undef VF_LOADB16
 #undef VF_WRITEB16
+    if constexpr (!std::is_same<PT, ConvParams>::value) VF_TRACE_EVT(TR_EPI);
     conv_epilogue<G, EPI_LSTM, MREP>(p, acc, bx, by, 0, red);
 }
 
