@@ -45,6 +45,7 @@ __host__ __device__ inline size_t bf16x6_lds_bytes(int NI, int LH, int LW) {
 template <int MREP, class PT>
 __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx_, const int by_, float *smem) {
     const int bx = __builtin_amdgcn_readfirstlane(bx_), by = __builtin_amdgcn_readfirstlane(by_);   // (see conv_tile)
+    static_assert(MREP == 1, "128-row tiles (the K loop below fetches one row block per wave)");
     constexpr int G = 4;
     constexpr int WROWS = MREP * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -97,6 +98,10 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx_
     const u16x8 *wgate = reinterpret_cast<const u16x8 *>(p.Wp16) + ((long long)cg * G + wave) * 3 * 64 + lane;
     const long long wtap = (long long)p.ncg * G * 3 * 64;          // units per (chunk, tap)
     const int gtN = total_chunks * ntaps;
+    const unsigned w_loff = (unsigned)((((cg * G + wave) * 3) * 64 + lane) * 16);         // this lane's 16-B unit, plane 0
+    const unsigned w_tap_b = (unsigned)(p.ncg * G * 3 * 64 * 16);                          // bytes per (chunk, tap)
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.Wp16), 0, 0x7FFFFFFF, 0x00020000);
     u16x8 breg[3];
 #define VF_LOADB16(GT_)                                                                         \
     _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) breg[pl] = wgate[(long long)(GT_) * wtap + pl * 64];
@@ -167,31 +172,56 @@ __device__ __forceinline__ void conv_lstm_bf16x6_tile(const PT &p, const int bx_
             VF_TRACE_EVT(TR_KLOOP);
         }
 
+        // ---- K loop.  A tap is only 24 MFMAs of 32 cycles, so everything else in it is paid dearly (a wave's own VALU /
+        // VMEM instructions do not overlap with its MFMAs, tools/ubench/mfma_shadow.hip): the next tap's weight planes
+        // come through raw buffer loads (lane offset in one VGPR, tap offset in an SGPR), the operand fetches use one
+        // address register per plane set up once per kernel row plus immediates, the weight fetches one per tap, and the
+        // A planes of the NEXT tap are requested before this tap's barrier (they do not depend on it).  Same terms in the
+        // same order as rounds 1-2: the same bits.
         for (int ky = 0; ky < p.KH; ++ky) {
+            const u16x8 *arow[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) arow[pl] = aP + pl * plane_units + abase[0] + ky * LW * kBfRowUnits;
+            bf16x8 a[3][MREP], an[3][MREP], bw[3][G];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl][0] = __builtin_bit_cast(bf16x8, arow[pl][0]);
             for (int kx = 0; kx < p.KW; ++kx) {
                 const int gt = ci * ntaps + ky * p.KW + kx;
                 const int buf = gt & 1;
-                const int ao = (ky * LW + kx) * kBfRowUnits;
                 const bool more = gt + 1 < gtN;
-                if (more) { VF_LOADB16(gt + 1) }
-                bf16x8 a[3][MREP], bw[3][G];
+                if (more) {
+                    const unsigned so = (unsigned)(gt + 1) * w_tap_b;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-                    for (int m = 0; m < MREP; ++m)
-                        a[pl][m] = __builtin_bit_cast(bf16x8, aP[pl * plane_units + abase[m] + ao]);
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        bw[pl][g] = __builtin_bit_cast(bf16x8, bsm[((buf * G + g) * 3 + pl) * 64 + lane]);
+                    for (int pl = 0; pl < 3; ++pl)
+                        breg[pl] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_loff, so + (unsigned)pl * 1024u, 0));
                 }
+                const u16x8 *brow = bsm + buf * (G * 3 * 64) + lane;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) bw[pl][g] = __builtin_bit_cast(bf16x8, brow[(g * 3 + pl) * 64]);
+                __builtin_amdgcn_sched_barrier(0);
                 // smallest terms first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1
 #define VF_T(PA_, PB_)                                                                          \
                 _Pragma("unroll") for (int g = 0; g < G; ++g)                                   \
-                    _Pragma("unroll") for (int m = 0; m < MREP; ++m)                            \
-                        acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA_][m], bw[PB_][g], acc[m][g], 0, 0, 0);
-                VF_T(2, 0) VF_T(0, 2) VF_T(1, 1) VF_T(1, 0) VF_T(0, 1) VF_T(0, 0)
+                    acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA_][0], bw[PB_][g], acc[0][g], 0, 0, 0);
+                VF_T(2, 0) VF_T(0, 2) VF_T(1, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                if (kx + 1 < p.KW) {        // the next tap's operands: independent of the barrier below
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) an[pl][0] = __builtin_bit_cast(bf16x8, arow[pl][(kx + 1) * kBfRowUnits]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                VF_T(1, 0) VF_T(0, 1) VF_T(0, 0)
 #undef VF_T
-                if (more) { VF_WRITEB16(buf ^ 1) }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    u16x8 *bw_ = bsm + (buf ^ 1) * (G * 3 * 64) + wave * 3 * 64 + lane;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) bw_[pl * 64] = breg[pl];
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl][0] = an[pl][0];
                 __syncthreads();
             }
         }
