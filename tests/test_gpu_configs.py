@@ -62,7 +62,7 @@ def test_config3_two_view_registration_planning_call(trade_off):
     """BASELINE configs[2]: 2 views x 64x64, 600 samples x horizon 13, flow-registration cost, 3 CEM iterations,
     selection_frac .05 (K = 30), RegisterGtruthController on the HIP predictor (one launch rolls both views)."""
     from visual_foresight_amd.policy.cem_controllers import RegisterGtruthController
-    torch.set_num_threads(min(64, torch.get_num_threads()))
+    torch.set_num_threads(min(32, torch.get_num_threads()))     # the oracle is fastest at 32 threads (bench.py)
     H = W = 64
     ncam, M, T = 2, 600, 13
     ag = {'adim': 4, 'sdim': 5, 'image_height': H, 'image_width': W, 'ncam': ncam}
@@ -206,7 +206,7 @@ def test_config4_shard_elites_match_oracle():
     oracle-driven controller in every iteration."""
     from visual_foresight_amd.policy.cem_controllers import PixelCostController
     from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
-    torch.set_num_threads(min(64, torch.get_num_threads()))
+    torch.set_num_threads(min(32, torch.get_num_threads()))     # the oracle is fastest at 32 threads (bench.py)
     ag = {'adim': 4, 'sdim': 5, 'image_height': 64, 'image_width': 64}
     base = {'nactions': 15, 'repeat': 1, 'rejection_sampling': False, 'verbose': False, 'num_samples': 125}
     factory = lambda cfg: CdnaWeights.random(cfg, seed=0)
@@ -292,7 +292,7 @@ def test_config5_full_rank_share_625_sequences_elites_match_oracle():
     from oracle.savp_predictor import OracleSavp
     from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
     from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
-    torch.set_num_threads(min(64, torch.get_num_threads()))
+    torch.set_num_threads(min(32, torch.get_num_threads()))     # the oracle is fastest at 32 threads (bench.py)
     H = W = 128
     T, M, nl, zd, sub = 15, 125, 5, 8, 25
     hp = dict(designated_pixel_count=1, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,
@@ -344,7 +344,7 @@ def test_config4_all_1000_samples_iteration0_elites_match_oracle():
     nactions = T, repeat 1, rejection_sampling False)."""
     from visual_foresight_amd.policy.cem_controllers import PixelCostController
     from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
-    torch.set_num_threads(min(64, torch.get_num_threads()))
+    torch.set_num_threads(min(32, torch.get_num_threads()))     # the oracle is fastest at 32 threads (bench.py)
     M, T = 1000, 15
     ag = {'adim': 4, 'sdim': 5, 'image_height': 64, 'image_width': 64}
     pol = {'nactions': T, 'repeat': 1, 'rejection_sampling': False, 'verbose': False, 'num_samples': M,

@@ -133,30 +133,53 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
         cs.relu = sg.relu != 0;
         return cs;
     };
-    // request element u: returns its value (zeros for padding) and remembers whether it is inside the image
-    auto st_issue = [&](const ChunkSrc &cs, const int u, bool &ok, int &img) {
+    // Where element u of this thread comes from is the same for every chunk of the item: image pixel iy * Win + ix, or -1
+    // for padding / rows past the tile.  Computed once (ten registers), so that a chunk's request is three instructions
+    // per element - every instruction outside the K loops is paid at one issue slot per ~40 cycles while the other
+    // workgroup of the CU is in its K loop (vf_conv_mfma.h, machine model).
+    constexpr int kBatch = 5;           // 2 x 5 elements per thread and chunk at most (320 haloed pixels)
+    int poff[2 * kBatch];
+#pragma unroll
+    for (int u = 0; u < 2 * kBatch; ++u) {
         const int pix = pl + u * ppp;
-        img = 0;
-        int r = pix;
+        int img = 0, r = pix;
         if (!ni1) { img = tile_px == 1 ? pix : (int)__umulhi((unsigned)pix, magic_px); r = pix - img * tile_px; }
         const int ly = (int)__umulhi((unsigned)r, magic_lw), lx = r - ly * LW;
         const int iy = y0 + ly, ix = x0 + lx;
-        ok = pix < npix && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win && img < n_here;
-        unsigned off = (unsigned)(iy * p.Win + ix) * cs.cstride + cs.cbyte;
-        if (!ni1) off += (unsigned)img * cs.img_step;
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs.rsrc, ok ? off : 0xFFFFFFFFu, 0, 0));
+        const bool ok = pix < npix && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win && img < n_here;
+        poff[u] = ok ? iy * p.Win + ix : -1;
+    }
+    // request element u: returns its value (zeros for padding)
+    auto st_issue = [&](const ChunkSrc &cs, const int u) {
+        unsigned off = (unsigned)poff[u] * cs.cstride + cs.cbyte;
+        if (!ni1) {
+            const int pix = pl + u * ppp;
+            off += (unsigned)(tile_px == 1 ? pix : (int)__umulhi((unsigned)pix, magic_px)) * cs.img_step;
+        }
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs.rsrc, poff[u] >= 0 ? off : 0xFFFFFFFFu, 0, 0));
+    };
+    // LayerNorm gain / offset of this thread's channel quad and (one image per tile) the statistics: once per chunk
+    struct ChunkLn { f32x4 g, b; float mean, rstd; };
+    auto chunk_ln = [&](const ChunkSrc &cs) {
+        ChunkLn L;
+        L.g = *reinterpret_cast<const f32x4 *>(gbTab + cs.gi);
+        L.b = *reinterpret_cast<const f32x4 *>(gbTab + gbC + cs.gi);
+        L.mean = lnTab[2 * (cs.seg * p.NI)]; L.rstd = lnTab[2 * (cs.seg * p.NI) + 1];
+        return L;
     };
     // LayerNorm / relu of element u and its LDS store into operand tile `dst`
-    auto st_finish = [&](const ChunkSrc &cs, const int u, f32x4 v, const bool ok, const int img, float *dst) {
+    auto st_finish = [&](const ChunkSrc &cs, const ChunkLn &L, const int u, f32x4 v, float *dst) {
         const int pix = pl + u * ppp;
         if (pix >= npix) return;
-        if (ok) {
+        if (poff[u] >= 0) {
             if (cs.has_ln) {
-                const f32x4 gq = *reinterpret_cast<const f32x4 *>(gbTab + cs.gi);
-                const f32x4 bq = *reinterpret_cast<const f32x4 *>(gbTab + gbC + cs.gi);
-                const float mean = lnTab[2 * (cs.seg * p.NI + img)], rstd = lnTab[2 * (cs.seg * p.NI + img) + 1];
+                float mean = L.mean, rstd = L.rstd;
+                if (!ni1) {
+                    const int img = tile_px == 1 ? pix : (int)__umulhi((unsigned)pix, magic_px);
+                    mean = lnTab[2 * (cs.seg * p.NI + img)]; rstd = lnTab[2 * (cs.seg * p.NI + img) + 1];
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaf((v[j] - mean) * rstd, gq[j], bq[j]);
+                for (int j = 0; j < 4; ++j) v[j] = fmaf((v[j] - mean) * rstd, L.g[j], L.b[j]);
             }
             if (cs.relu) {
 #pragma unroll
@@ -165,19 +188,18 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
         }
         *reinterpret_cast<f32x4 *>(dst + pix * KCpad + 4 * q) = v;
     };
-    constexpr int kElems = 10;          // elements per thread and chunk at most (320 haloed pixels)
-    auto stage_whole = [&](const int ci, float *dst) {
-        const ChunkSrc cs = chunk_src(ci);
+    // A chunk is staged in two batches of five elements per thread.  The first batch of chunk c + 1 is REQUESTED before the
+    // K loop of chunk c (five loads and their addresses, which had to be issued anyway; nothing is added inside the loop)
+    // and sits in 20 registers under it, so that after the loop only the second batch still has a memory latency to
+    // wait for - behind the LayerNorm and the stores of the first.
+    f32x4 pv[kBatch];
+    auto issue_batch = [&](const ChunkSrc &cs, const int u0, f32x4 (&v)[kBatch]) {
 #pragma unroll
-        for (int u0 = 0; u0 < kElems; u0 += 5) {
-            f32x4 v[5];
-            bool oks[5];
-            int imgs[5];
+        for (int u = 0; u < kBatch; ++u) v[u] = st_issue(cs, u0 + u);
+    };
+    auto finish_batch = [&](const ChunkSrc &cs, const ChunkLn &L, const int u0, const f32x4 (&v)[kBatch], float *dst) {
 #pragma unroll
-            for (int u = 0; u < 5; ++u) v[u] = st_issue(cs, u0 + u, oks[u], imgs[u]);
-#pragma unroll
-            for (int u = 0; u < 5; ++u) st_finish(cs, u0 + u, v[u], oks[u], imgs[u], dst);
-        }
+        for (int u = 0; u < kBatch; ++u) st_finish(cs, L, u0 + u, v[u], dst);
     };
 
     // ---- K loop of one kernel row (vf_conv_mfma.h: the gate-split K loop), reading operand tile `a4`
@@ -223,6 +245,7 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
     if constexpr (kInLaunch) VF_TRACE_EVT(TR_MFMAS, (unsigned long long)(25 * K8 * 4 * MR));
     __builtin_amdgcn_s_setprio(0);
     const f32x4 *a4 = reinterpret_cast<const f32x4 *>(smem);
+    bool pf = false;                    // batch 0 of this chunk was requested under the previous K loop
     for (int ci = 0; ci < total_chunks; ++ci) {
         if (late && ci == p.seg[0].nchunk) {         // the recurrent chunks are done: now the layer input is needed
             const int b1 = p.NI == 1 ? bimg0 + 1 : min(bimg0 + p.NI, p.B);
@@ -233,9 +256,19 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
         }
         __syncthreads();                // previous chunk fully consumed (and lnTab / gbTab visible)
         if constexpr (kInLaunch) VF_TRACE_EVT(TR_STAGE);
-        stage_whole(ci, smem);
+        {
+            const ChunkSrc cs = chunk_src(ci);
+            if (!pf) issue_batch(cs, 0, pv);
+            f32x4 v1[kBatch];
+            issue_batch(cs, kBatch, v1);
+            const ChunkLn L = chunk_ln(cs);
+            finish_batch(cs, L, 0, pv, smem);
+            finish_batch(cs, L, kBatch, v1, smem);
+        }
         if constexpr (kInLaunch) VF_TRACE_EVT(TR_ST_WRITTEN);
         __syncthreads();
+        pf = ci + 1 < total_chunks && !(late && ci + 1 == p.seg[0].nchunk);
+        if (pf) issue_batch(chunk_src(ci + 1), 0, pv);
         if constexpr (kInLaunch) VF_TRACE_EVT(TR_KLOOP);
         for (int ky = 0; ky < 5; ++ky) {
 #pragma unroll
