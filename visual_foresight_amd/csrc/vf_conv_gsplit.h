@@ -7,8 +7,11 @@
 //     this tap's MFMAs on block q have been issued (~3000 cycles before its first use) - 16 VGPRs and the two parity
 //     copies of the unrolled kernel row are gone (248 VGPRs, no spills, half the code);
 //   * an 8 x 16-pixel tile shape (plan_geometry): 240 instead of 288 staged pixels per chunk;
-//   * a chunk is staged in two batches of five 16-byte elements per thread.
-// Measured against the first version (same box): C2 64.85 -> 64.31 ms, 1000 samples 368.0 -> 362.0 ms.
+//   * a chunk is staged in two batches of five 16-byte elements per thread; where an element comes from is worked out
+//     once per item (ten registers), the LayerNorm gain / offset / statistics of the thread's channel quad are read once
+//     per chunk, and the first batch of chunk c + 1 is requested before the K loop of chunk c.
+// Measured against the first version (same box): C2 64.85 -> 64.31 ms, 1000 samples 368.0 -> 362.0 ms; the staging diet of
+// the last bullet: 63.6 -> 63.3 ms.
 //
 // Also measured here and NOT adopted: two operand tiles in LDS with chunk c + 1 staged UNDER the K loop of chunk c (two
 // elements per thread requested at the start of every kernel row and LayerNorm-ed / stored at its end, the late input of
