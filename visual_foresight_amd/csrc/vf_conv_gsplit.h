@@ -228,9 +228,19 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
                 for (int m_ = 0; m_ < GSZ; ++m_)
                     acc[(S % NG) * GSZ + m_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                         a_cur[m_][j_], gsW[S / NG][j_], acc[(S % NG) * GSZ + m_][0], 0, 0, 0);
+                if constexpr (KX == 0 && S == 0) {
+                    // the last k8 block of THIS tap: not requested at the end of the previous kernel row (the compiler
+                    // drains the vector-memory counter at the head of the row loop - a load issued just before it would be
+                    // waited for with the matrix pipe idle) but here, behind the row's first MFMAs, 44 MFMAs ahead of its use
+                    if (j_ == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        gs_loadq(3, gt_next - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (S % NG == NG - 1) {
+            if constexpr (S % NG == NG - 1 && !(KX == 4 && S / NG == 3)) {
                 gs_loadq(S / NG, gt_next);
                 __builtin_amdgcn_sched_barrier(0);
             }
