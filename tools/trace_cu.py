@@ -141,6 +141,7 @@ def simplify(s):
 
 
 joint = defaultdict(float)
+starve = defaultdict(list)   # non-K phase class -> [(duration, time the partner spent in a K loop during it)]
 X, Y = [], []       # per K interval: (overlap with the partner's K, rest), MFMAs
 for a, b in pairs:
     for me, other in ((a, b), (b, a)):
@@ -165,6 +166,11 @@ for a, b in pairs:
             if s == 'K' and mf > 0:
                 X.append((ovK * TICK_US, (t1 - t0 - ovK) * TICK_US))
                 Y.append(mf)
+            elif s in ('epi', 'pro', 'stage') or s.startswith('light:'):
+                cls = s if not s.startswith('light:') else ':'.join(s.split(':')[:2])
+                if s.startswith('light:') and (s.endswith(':late') or s.endswith(':mates')):
+                    continue
+                starve[cls].append(((t1 - t0) * TICK_US, ovK * TICK_US))
 npair = len(pairs)
 print('joint state of a CU, %% of the traced span (K = issuing MFMAs of a conv-LSTM K loop, idle = waiting for a ticket / '
       'dependency / late input, other = prologue, staging, epilogue, light items):')
@@ -193,6 +199,18 @@ tK1 = (sym[('K', 'other')] + sym[('K', 'idle')]) / npair
 print('   pipe time accounted: both-K %.1f ms x %.3f + one-K %.1f ms x %.3f = %.1f ms of MFMA work per SIMD' % (
     tK2 / 1e3, 2 * r[0] * 64 / (GHZ * 1e3), tK1 / 1e3, r[1] * 64 / (GHZ * 1e3),
     (tK2 * 2 * r[0] + tK1 * r[1]) * 64 / (GHZ * 1e3) / 1e3))
+
+# ---- how much does a non-K phase advance while the other workgroup of the CU is in a K loop?  duration = a + b x (partner's
+# K time during the phase): b = 1 - the phase stands still next to a K loop and `a` is its real cost; b = 0 - it does not care
+print('non-K phases next to a K loop: duration = a + b x (partner K-loop time inside the phase), least squares')
+for cls in sorted(starve):
+    d = np.array(starve[cls])
+    if len(d) < 50:
+        continue
+    A = np.stack([np.ones(len(d)), d[:, 1]], axis=1)
+    (a_, b_), *_ = np.linalg.lstsq(A, d[:, 0], rcond=None)
+    print('   %-18s n %7d  mean %6.1f us (partner in K %4.1f us of it)  a %6.1f us  b %.2f' % (
+        cls, len(d), d[:, 0].mean(), d[:, 1].mean(), a_, b_))
 
 # ---- time-resolved: share of the workgroups in each state, in bins over the middle of the launch
 if os.environ.get('VF_TRACE_TIMELINE'):
