@@ -112,35 +112,77 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
     int *s_flag = reinterpret_cast<int *>(s_dscale + ND + 1);
     const int nblocks = sum_blocks(c.H, c.W);
 
-    // ---- 3. scale of the previous distributions, CDNA kernels, halo
-    for (int d = (wave + 3) & 3; d < ND; d += 4) {
-        float sc = 1.0f;
-        if (c.prev_sums) {
-            double su = 0.0;
-            const double *pp = c.prev_sums + ((long long)b * ND + d) * nblocks * 2;
-            for (int k = lane; k < nblocks; k += 64) su += pp[2 * k];
-            su = wave_sum(su);
-            sc = (float)(1.0 / su);
-        }
-        if (lane == 0) s_dscale[d] = sc;
-    }
-    for (int i = tid; i < kTaps * K; i += 256) s_kern[(i / K) * kCompKernPad + i % K] = c.kern[(long long)b * kTaps * K + i];
-    __syncthreads();
-    {
-        const float *pf = c.prev_frame + (long long)b * c.prev_frame_bstride;
-        const float *pd = c.prev_distrib + (long long)b * c.prev_distrib_bstride;
-        const TileDiv div_hw(HW_);
-        for (int i = tid; i < HH_ * HW_; i += 256) {
+    // ---- 3. scale of the previous distributions, CDNA kernels, halo.  Three independent groups of loads: all of them are
+    // requested before the first is used (the halo of up to 1024 pixels sits in registers across the reduction of the
+    // block sums and the barrier), so the item waits for ONE memory latency here instead of three or more
+    const float *pf = c.prev_frame + (long long)b * c.prev_frame_bstride;
+    const float *pd = c.prev_distrib + (long long)b * c.prev_distrib_bstride;
+    const TileDiv div_hw(HW_);
+    constexpr int kHaloU = 4;
+    float hv[kHaloU][3 + ND];
+    unsigned hin = 0;
+    auto halo_request = [&](const int i0) {
+        hin = 0;
+#pragma unroll
+        for (int u = 0; u < kHaloU; ++u) {
+            const int i = i0 + u * 256;
             const int ly = div_hw.div(i), lx = i - ly * HW_;
             const int y = oy0 + ly - 2, x = ox0 + lx - 2;
-            const bool in = y >= 0 && y < c.H && x >= 0 && x < c.W;
+            const bool in = i < HH_ * HW_ && y >= 0 && y < c.H && x >= 0 && x < c.W;
             const long long o = (long long)y * c.W + x;
+            hin |= in ? (1u << u) : 0u;
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) s_px[i * PS + ch] = in ? pf[o * 3 + ch] : 0.f;
+            for (int ch = 0; ch < 3; ++ch) hv[u][ch] = in ? pf[o * 3 + ch] : 0.f;
 #pragma unroll
-            for (int d = 0; d < ND; ++d) s_px[i * PS + 3 + d] = in ? pd[o * ND + d] * s_dscale[d] : 0.f;
+            for (int d = 0; d < ND; ++d) hv[u][3 + d] = in ? pd[o * ND + d] : 0.f;
+        }
+    };
+    auto halo_store = [&](const int i0) {
+#pragma unroll
+        for (int u = 0; u < kHaloU; ++u) {
+            const int i = i0 + u * 256;
+            if (i < HH_ * HW_) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) s_px[i * PS + ch] = hv[u][ch];
+#pragma unroll
+                for (int d = 0; d < ND; ++d) s_px[i * PS + 3 + d] = (hin >> u) & 1u ? hv[u][3 + d] * s_dscale[d] : 0.f;
+            }
+        }
+    };
+    double dsum[(ND + 3) / 4];
+#pragma unroll
+    for (int j = 0; j < (ND + 3) / 4; ++j) {
+        dsum[j] = 0.0;
+        const int d = ((wave + 3) & 3) + 4 * j;
+        if (d < ND && c.prev_sums) {
+            const double *pp = c.prev_sums + ((long long)b * ND + d) * nblocks * 2;
+            for (int k = lane; k < nblocks; k += 64) dsum[j] += pp[2 * k];
         }
     }
+    float kv[(kTaps * K + 255) / 256];
+#pragma unroll
+    for (int j = 0; j < (kTaps * K + 255) / 256; ++j) {
+        const int i = tid + 256 * j;
+        kv[j] = i < kTaps * K ? c.kern[(long long)b * kTaps * K + i] : 0.f;
+    }
+    halo_request(tid);
+#pragma unroll
+    for (int j = 0; j < (ND + 3) / 4; ++j) {
+        const int d = ((wave + 3) & 3) + 4 * j;
+        if (d < ND) {
+            float sc = 1.0f;
+            if (c.prev_sums) sc = (float)(1.0 / wave_sum(dsum[j]));
+            if (lane == 0) s_dscale[d] = sc;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < (kTaps * K + 255) / 256; ++j) {
+        const int i = tid + 256 * j;
+        if (i < kTaps * K) s_kern[(i / K) * kCompKernPad + i % K] = kv[j];
+    }
+    __syncthreads();
+    halo_store(tid);
+    for (int i0 = tid + kHaloU * 256; i0 < HH_ * HW_; i0 += kHaloU * 256) { halo_request(i0); halo_store(i0); }
 
     [[maybe_unused]] const unsigned long long tf2 = VF_TS_NOW();
     VF_TRACE_EVT(TR_TOP_HALO);
