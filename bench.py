@@ -49,6 +49,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E, ~8 TB/s
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: dense bf16 MFMA
 
 WORKLOADS = {
@@ -428,6 +429,9 @@ class Bench(object):
             roof['traffic'] = prof['hbm_bytes_per_launch']
             roof['traffic_source'] = 'profiles/r03_hbm_traffic.json (rocprofv3 PMC passes of this library, offline)'
             roof['traffic_vs_algorithmic'] = prof.get('ratio_to_algorithmic')
+            if roof.get('avg_launch_us'):       # HBM-side rate of the launch against the 8 TB/s peak (north_star: GB/s vs peak)
+                roof['hbm_gbps'] = prof['hbm_bytes_per_launch'] / (roof['avg_launch_us'] * 1e-6) / 1e9
+                roof['hbm_frac_of_peak'] = roof['hbm_gbps'] / PEAK_HBM_GBPS
 
     def metric_label(self):
         """BASELINE.json's metric string for the configuration it is quoted on (c2 at its own size); any other

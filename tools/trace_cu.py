@@ -76,6 +76,8 @@ for w in range(WGS):
             close(v, 'wait')
         elif c >= TR_RUN:
             lstm = (c - TR_RUN) == PH_LSTM
+            if state == 'wait':
+                state = 'wait:' + PH_NAMES[c - TR_RUN]      # the wait in front of an item belongs to that item's type
             close(v, 'pro' if lstm else 'light:' + PH_NAMES[c - TR_RUN])
         elif c == TR_DONE:
             close(v, 'sched')
@@ -110,7 +112,7 @@ print('traced span %.2f ms' % (span / 1e3))
 tot = defaultdict(float)
 for w, iv in wg_iv.items():
     for t0, t1, s, _ in iv:
-        tot[s.split(':')[0] if s.startswith('light') else s] += (t1 - t0) * TICK_US
+        tot[s.split(':')[0] if s.startswith(('light', 'wait')) else s] += (t1 - t0) * TICK_US
 nw = len(wg_iv)
 print('per workgroup slot (mean over %d), ms: ' % nw + '  '.join('%s %.2f' % (k, v / nw / 1e3) for k, v in sorted(tot.items())))
 light, lightn = defaultdict(float), defaultdict(int)
@@ -137,10 +139,11 @@ print('%d CUs host exactly two workgroups (%d CUs seen)' % (len(pairs), len(by_c
 
 
 def simplify(s):
-    return 'K' if s == 'K' else ('idle' if s in ('wait', 'late', 'sched', 'stage:barrier') else 'other')
+    return 'K' if s == 'K' else ('idle' if s in ('wait', 'late', 'sched', 'stage:barrier') or s.startswith('wait:') else 'other')
 
 
 joint = defaultdict(float)
+unc = defaultdict(lambda: [0.0, 0.0])     # waiting state -> [time, time with no K loop on the CU's other workgroup]
 starve = defaultdict(list)   # non-K phase class -> [(duration, time the partner spent in a K loop during it)]
 X, Y = [], []       # per K interval: (overlap with the partner's K, rest), MFMAs
 for a, b in pairs:
@@ -166,6 +169,10 @@ for a, b in pairs:
             if s == 'K' and mf > 0:
                 X.append((ovK * TICK_US, (t1 - t0 - ovK) * TICK_US))
                 Y.append(mf)
+            elif s.startswith('wait') or s == 'late' or s.endswith(':late') or s.endswith(':mates'):
+                key = s if s.startswith('wait') else ('late (conv-LSTM)' if s == 'late' else s.replace('light:', ''))
+                unc[key][0] += (t1 - t0) * TICK_US
+                unc[key][1] += (t1 - t0 - ovK) * TICK_US
             elif s in ('epi', 'pro', 'stage') or s.startswith('light:'):
                 cls = s if not s.startswith('light:') else ':'.join(s.split(':')[:2])
                 if s.startswith('light:') and (s.endswith(':late') or s.endswith(':mates')):
@@ -212,6 +219,11 @@ for cls in sorted(starve):
     print('   %-18s n %7d  mean %6.1f us (partner in K %4.1f us of it)  a %6.1f us  b %.2f' % (
         cls, len(d), d[:, 0].mean(), d[:, 1].mean(), a_, b_))
 
+# ---- waits: which ones fall next to a K loop (free: the matrix pipe is busy anyway) and which do not
+print('waiting, ms per slot [of it with NO K loop next to it]:')
+for k, (t_all, t_unc) in sorted(unc.items(), key=lambda kv: -kv[1][1]):
+    print('   %-24s %6.2f  [%5.2f]' % (k, t_all / (2 * npair) / 1e3, t_unc / (2 * npair) / 1e3))
+
 # ---- time-resolved: share of the workgroups in each state, in bins over the middle of the launch
 if os.environ.get('VF_TRACE_TIMELINE'):
     nb = 400
@@ -222,7 +234,7 @@ if os.environ.get('VF_TRACE_TIMELINE'):
         for t0, t1, s, _ in iv:
             if t1 <= lo_t or t0 >= hi_t:
                 continue
-            key = 'K' if s == 'K' else ('idle' if s in ('wait', 'late', 'sched') or s.endswith(':late') else
+            key = 'K' if s == 'K' else ('idle' if s in ('wait', 'late', 'sched') or s.startswith('wait:') or s.endswith(':late') else
                                         (s.split(':')[1] if s.startswith('light') else 'lstm-other'))
             a, b = max(t0, lo_t), min(t1, hi_t)
             i0, i1 = int((a - lo_t) / (hi_t - lo_t) * nb), min(nb - 1, int((b - lo_t) / (hi_t - lo_t) * nb))
