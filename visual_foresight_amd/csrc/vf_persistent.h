@@ -209,6 +209,9 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
     for (;;) {
         [[maybe_unused]] const unsigned long long ts_top = VF_TS_NOW();
         __syncthreads();                    // previous item fully retired (LDS reusable)
+        // (Keep LDS stores out of the END of this loop body: hipcc 7.2 does not put an `s_waitcnt lgkmcnt(0)` in front of
+        // this loop-head barrier for a store pending on the back edge - a draw moved there let the other waves read the
+        // previous ticket, profiles/r03_tile_plan_sweep.txt; it was no faster with the wait added by hand either.)
         VF_TRACE_EVT(TR_TICKET);
         if (tid == 0) {
             int t = -1, qq = q_own;
