@@ -244,7 +244,15 @@ class Bench(object):
         local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         # one rank per GPU over RCCL; VF_BENCH_BACKEND=gloo lets several ranks share one GPU for dry runs
         self.backend = os.environ.get('VF_BENCH_BACKEND', 'nccl')
-        dev_index = local_rank % max(torch.cuda.device_count(), 1)
+        n_dev = max(torch.cuda.device_count(), 1)
+        if self.world > n_dev and 'VF_BENCH_BACKEND' not in os.environ:
+            # more ranks than GPUs (a launcher started N ranks on a smaller box): RCCL refuses two ranks on one device,
+            # so the ranks share GPUs over gloo - a dry run of the sharding and the collective, and the line says so
+            self.backend = 'gloo'
+            if self.rank == 0:
+                print('note: %d ranks on %d GPU(s): gloo dry run, not a scaling measurement' % (self.world, n_dev),
+                      file=sys.stderr)
+        dev_index = local_rank % n_dev
         if self.world > 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
