@@ -42,6 +42,13 @@ import subprocess
 import sys
 import time
 
+HOST_THREAD_CAPS = ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS', 'NUMEXPR_NUM_THREADS')
+if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    # N ranks on one host: the sampler's 52x52 refits must not start N x (all cores) BLAS / OpenMP workers.  Set before
+    # numpy / torch load their runtimes, whoever launched the ranks (spawn_ranks below or torch.distributed.run).
+    for _k in HOST_THREAD_CAPS:
+        os.environ.setdefault(_k, '1')
+
 import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -78,21 +85,46 @@ def parse():
 
 
 # ----------------------------------------------------------------------------- self-launch
-def spawn_ranks(args):
-    """Start one child per rank (this process has not initialised any GPU and never will)."""
-    import socket
-    import torch
-    have = torch.cuda.device_count()            # counting devices does not initialise the runtime
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
+def count_gpus_in_child(timeout=600):
+    """Number of GPUs this host exposes, asked of a throw-away child process: the launcher itself never imports
+    torch nor makes any HIP call, so it provably cannot have initialised a GPU before it starts the ranks (and the
+    ranks are fresh children - nothing is ever re-exec'ed)."""
+    code = 'import torch; print("VF_GPU_COUNT", torch.cuda.device_count())'
+    try:
+        out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             text=True, timeout=timeout).stdout
+    except (OSError, subprocess.TimeoutExpired):
+        return 0
+    for line in out.splitlines():
+        if line.startswith('VF_GPU_COUNT'):
+            return int(line.split()[1])
+    return 0
+
+
+def rank_env(args, have, port):
+    """Environment of the self-launched ranks."""
     env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in HOST_THREAD_CAPS:          # N ranks share the host cores: one math thread each (not left to threadpoolctl)
+        env[k] = '1'
     if have < args.gpus:
         # fewer GPUs than ranks (a 1-GPU box): the ranks share them and talk over gloo - a dry run of the
         # sharding and the collective, not a scaling measurement; the line says so
         env['VF_BENCH_BACKEND'] = 'gloo'
+    return env
+
+
+def spawn_ranks(args):
+    """Start one child per rank (this process has not initialised any GPU and never will: no torch import, the
+    device count comes from a throw-away child)."""
+    import socket
+    assert 'torch' not in sys.modules, 'the launcher must stay GPU-free'
+    have = count_gpus_in_child()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = rank_env(args, have, port)
     procs = []
     for r in range(args.gpus):
         renv = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -360,6 +392,8 @@ class Bench(object):
                 plan(1 + i)
             score_time[0] = 0.0
             pred.set_profiling(True)
+            if self.world > 1:
+                pred.set_collective_timing(True)
             self.sync()
             t0 = time.perf_counter()
             marks = [t0]
@@ -370,6 +404,7 @@ class Bench(object):
             elapsed = time.perf_counter() - t0
             kernel_ms, launches, flops, busy_ms = pred.get_profile()
             pred.set_profiling(False)
+            collective = self.collective_report(pred) if self.world > 1 else None
         if self.world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == 'nccl' else 'cpu')
             self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
@@ -379,13 +414,42 @@ class Bench(object):
         if self.world > 1:
             from visual_foresight_amd.video_prediction.sharding import shard_bounds
             lo, hi = shard_bounds(self.M, self.rank, self.world)
-        return dict(ctrl=ctrl, pred=pred, elapsed=elapsed,
+        return dict(ctrl=ctrl, pred=pred, elapsed=elapsed, collective=collective,
                     call_ms=[float(np.percentile(per_call, q)) for q in (50, 10, 90)], kernel_ms=kernel_ms,
                     launches=launches, flops=flops, busy_ms=busy_ms,
                     host_ms=1e3 * (elapsed - score_time[0]) / a.steps,
                     rollouts=(hi - lo) * max(self.draws, 1) * self.ncam * self.iters * a.steps,
                     elites=[int(i) for i in ctrl._best_indices],
                     best=float(np.min(out['plan_stat']['scores_itr%d' % (self.iters - 1)])))
+
+    def collective_report(self, pred):
+        """What the process group actually was - backend, world size, every rank's device - and what the one
+        all-gather of score rows per CEM iteration cost (HIP events around the collective on every rank; mean over the
+        timed calls, then mean / max over ranks).  Evidence in a SCALE record that RCCL saw N ranks on N GPUs."""
+        torch, dist = self.torch, self.dist
+        st = pred.collective_stats()
+        pred.set_collective_timing(False)
+        props = torch.cuda.get_device_properties(self.dev)
+        mine = {'rank': self.rank, 'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'device': self.dev_index,
+                'name': props.name, 'uuid': str(getattr(props, 'uuid', '')), 'pid': os.getpid(),
+                'allgather_calls': st['calls'], 'allgather_mean_ms': st['mean_ms'], 'allgather_max_ms': st['max_ms'],
+                'bytes_per_rank': st['bytes_per_rank']}
+        ranks = [None] * self.world
+        dist.all_gather_object(ranks, mine)
+        means = [r['allgather_mean_ms'] for r in ranks if r['allgather_mean_ms'] is not None]
+        return {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                'devices': [r['device'] for r in ranks],
+                'distinct_gpus': len({(r['uuid'] or r['device']) for r in ranks}),
+                'allgather_ms_per_cem_iter': {'mean_over_ranks': float(np.mean(means)) if means else None,
+                                              'max_over_ranks': float(np.max(means)) if means else None,
+                                              'worst_single_call': max([r['allgather_max_ms'] or 0.0 for r in ranks]),
+                                              'calls_per_rank': ranks[0]['allgather_calls'],
+                                              'how': 'HIP events on the stream the collective is ordered on, around '
+                                                     'every all-gather of the timed region (includes waiting for '
+                                                     'the slowest rank to arrive)'},
+                'bytes_per_rank_per_allgather': ranks[0]['bytes_per_rank'],
+                'host_threads_per_rank': {k: os.environ.get(k) for k in HOST_THREAD_CAPS},
+                'ranks': ranks}
 
     def survey_rate(self, m):
         """SURVEY.md 8(d) accounting: every sample charged with all seq_len - 1 cell evaluations at the layer
@@ -482,6 +546,7 @@ class Bench(object):
                                    (self.world, ' (gloo dry run: ranks share a GPU, not a scaling measurement)'
                                     if shared_gpus else ' over RCCL' if self.world > 1 else '')},
             'roofline': self.roofline(m, primary),
+            'collective': m['collective'],
             'host_ms_per_step_outside_predictor': m['host_ms'],
             'best_score_last_plan': m['best'],
         }

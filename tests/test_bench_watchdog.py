@@ -31,3 +31,21 @@ def test_metric_label_names_the_workload():
     b.args = types.SimpleNamespace(workload='c5', samples=125, scaling='strong')
     b.M, b.T, b.H, b.W, b.ncam, b.draws = 125, 15, 128, 128, 1, 5
     assert 'workload c5' in b.metric_label() and '125-sample' in b.metric_label() and '5 latent draws' in b.metric_label()
+
+
+def test_launcher_env_caps_host_threads_and_never_needs_torch():
+    """The 8-GPU pre-flight: the self-launcher counts GPUs in a throw-away child (its own process stays GPU-free) and
+    gives every rank one host math thread."""
+    import types
+    args = types.SimpleNamespace(gpus=8)
+    env = bench.rank_env(args, have=8, port=12345)
+    assert env['WORLD_SIZE'] == '8' and env['MASTER_ADDR'] == '127.0.0.1' and env['MASTER_PORT'] == '12345'
+    assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    for k in bench.HOST_THREAD_CAPS:
+        assert env[k] == '1'
+    assert 'VF_BENCH_BACKEND' not in env                       # 8 GPUs for 8 ranks: RCCL
+    assert bench.rank_env(args, have=1, port=1)['VF_BENCH_BACKEND'] == 'gloo'
+    assert bench.count_gpus_in_child() == 0 or bench.count_gpus_in_child() >= 1    # runs, returns an int
+    import inspect
+    src = inspect.getsource(bench.spawn_ranks)
+    assert 'import torch' not in src and 'torch.cuda' not in src

@@ -1,4 +1,4 @@
-"""Multi-rank planning on CPU (gloo, world_size 2): sharded scoring + all-gather gives every rank
+"""Multi-rank planning on CPU (gloo, world_size 2 and 8): sharded scoring + all-gather gives every rank
 the single-process score vector and therefore bit-identical elites and actions."""
 import os
 import pickle
@@ -44,13 +44,15 @@ def test_shard_bounds_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-@pytest.mark.parametrize('num_samples,propagation', [(24, False), (23, True)])
-def test_two_ranks_match_single_process(tmp_path, num_samples, propagation):
+@pytest.mark.parametrize('world,num_samples,propagation', [(2, 24, False), (2, 23, True), (8, 203, True)])
+def test_ranks_match_single_process(tmp_path, world, num_samples, propagation):
+    """World 2 (even and ragged) and the 8-rank shape of the node with a ragged candidate count (203 = 3 x 26 + 5 x 25:
+    the padded all-gather and the propagation fetch from whichever rank owns the winner)."""
     single = _launch(1, tmp_path, num_samples, propagation)[0]
-    ranks = _launch(2, tmp_path, num_samples, propagation)
+    ranks = _launch(world, tmp_path, num_samples, propagation)
     # each rank rolled only its own shard
     for r, res in enumerate(ranks):
-        assert set(res['evaluated']) == {shard_bounds(num_samples, r, 2)}
+        assert set(res['evaluated']) == {shard_bounds(num_samples, r, world)}
     assert set(single['evaluated']) == {(0, num_samples)}
     for res in ranks:
         for a, b in zip(res['log'], single['log']):

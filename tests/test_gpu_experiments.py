@@ -1,0 +1,278 @@
+"""The reference's literal experiment files through the harness on the device, against the oracle-driven run.
+
+``Sim`` -> ``SyntheticAgent`` -> ``PixelCostController`` -> ``HipVPredEvaluation`` in a closed loop (reference
+``visual_mpc/sim/simulator.py:13-51,46-93`` + ``visual_mpc/agent/general_agent.py:174-228``), once with the HIP
+predictor and once with the CPU oracle behind the SAME controller (host cost path), on the ``policy`` dicts of
+
+  * ``experiments/robonet/pixel_cost/hparams.py:31-42``   48x64, 600 samples > ``vpred_batch_size``,
+    ``predictor_propagation``, ``replan_interval 13``, ``selection_frac .05``;
+  * ``experiments/robonet/franka/franka.py:40-58``        ``CorrelatedNoiseSampler``, 5 iterations, ``start_planning 5``,
+    random start actions, ``verbose_every_iter``;
+  * ``experiments/sim/cartgripper_2d_grasping/pixel_cost/hparams.py:31-39``   ``action_order`` x / z / grasp, adim 3.
+
+The dicts are the reference's, key for key; what differs is stated in ``_adapt``: ``type`` / ``predictor_class`` are
+this repo's classes, ``model_path`` is dropped (no checkpoint exists in this project: seeded random weights on both
+sides), and the sample count is one the CPU oracle can afford (60, chunked at ``vpred_batch_size`` 20 so that the
+"more samples than one chunk, winner no longer resident" path of the 600-sample config still runs).  The agent's
+episode length is set so that every trajectory makes three planning calls (the agent dict is not part of the policy).
+
+Done = every step's action identical (to 1e-6 with the correlated sampler, whose refit is score-weighted and so
+inherits the fp32-level score differences), every CEM iteration's elite indices identical (with a margin assert at the
+K / K+1 boundary), ``plan_stat`` scores rtol 1e-5, propagated distributions 2e-5 x plane max, identical
+``policy_out.pkl`` keys.  Plus ``only_take_first_view`` on a 2-view engine (reference
+``pixel_cost_controller.py:150-151``) against ``oracle.pixel_cost.eval_pixel_cost(..., only_take_first_view=True)``.
+"""
+import contextlib
+import io
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+from oracle import pixel_cost                                           # noqa: E402
+from tests.helpers.oracle_predictor import make_oracle_predictor_class  # noqa: E402
+from visual_foresight_amd.policy.cem_controllers import PixelCostController                 # noqa: E402
+from visual_foresight_amd.policy.cem_controllers.samplers import CorrelatedNoiseSampler     # noqa: E402
+from visual_foresight_amd.sim import Sim, SyntheticAgent, SyntheticPushEnv                  # noqa: E402
+from visual_foresight_amd.video_prediction.cdna_arch import CdnaWeights                     # noqa: E402
+from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation          # noqa: E402
+
+# --- the reference's policy dicts, verbatim (minus 'type', which names the reference's own class)
+ROBONET_PIXEL_COST = {          # experiments/robonet/pixel_cost/hparams.py:31-42
+    'replan_interval': 13,
+    'num_samples': 600,
+    'selection_frac': 0.05,
+    'predictor_propagation': True,
+    'initial_std_lift': 0.2,
+    'initial_std_rot': np.pi / 10,
+    'rejection_sampling': False,
+    'nactions': 13,
+    'repeat': 1,
+}
+FRANKA = {                      # experiments/robonet/franka/franka.py:40-58
+    'verbose_every_iter': True,
+    'zeros_for_start_frames': False,
+    'replan_interval': 10,
+    'start_planning': 5,
+    'iterations': 5,
+    'selection_frac': 1. / 10,
+    'nactions': 10,
+    'model_path': '/home/panda1/models/ag_franka/VPredTrainable_0_462f7842_2019-10-05_00-03-46poiv7dyy/checkpoint_75000/',
+    'sampler': CorrelatedNoiseSampler,
+}
+CARTGRIPPER = {                 # experiments/sim/cartgripper_2d_grasping/pixel_cost/hparams.py:31-39
+    'action_order': ['x', 'z', 'grasp'],
+    'initial_std_lift': 0.5,
+    'rejection_sampling': False,
+    'replan_interval': 10,
+    'num_samples': 800,
+}
+
+#                name                 policy dict     adim sdim  episode length (-> planning calls at)   samples
+EXPERIMENTS = [('robonet_pixel_cost', ROBONET_PIXEL_COST, 4, 5, 28, 60),        # t = 1, 14, 27
+               ('franka', FRANKA, 4, 5, 26, 60),                                # t = 5, 15, 25
+               ('cartgripper', CARTGRIPPER, 3, 3, 22, 60)]                      # t = 1, 11, 21
+HEIGHT, WIDTH = 48, 64          # 'image_height': 48, 'image_width': 64 in all three agent dicts
+
+
+def _adapt(policy, predictor_class, samples):
+    """The only departures from the reference's dict."""
+    p = dict(policy)
+    p.pop('model_path', None)               # no checkpoint in this project: seeded random weights on both sides
+    p['type'] = PixelCostController
+    p['predictor_class'] = predictor_class
+    p['num_samples'] = samples              # what the CPU oracle can afford ...
+    p['vpred_batch_size'] = 20              # ... still more than one chunk, like 600 samples against the default 200
+    return p
+
+
+class _Recorder(object):
+    """Keeps what every CEM iteration of every planning call was asked and what it answered."""
+
+    def __init__(self, policy):
+        self.policy, self.calls = policy, []
+        self._inner = policy.evaluate_rollouts
+        policy.evaluate_rollouts = self
+
+    def __call__(self, actions, cem_itr):
+        pol = self.policy
+        ctx_distrib = np.array(pol._make_input_distrib(cem_itr))
+        scores = self._inner(actions, cem_itr)
+        entry = {'t': pol._t, 'itr': cem_itr, 'actions': np.array(actions), 'scores': np.array(scores),
+                 'ctx_distrib': ctx_distrib, 'chosen': None}
+        if pol._hp.predictor_propagation and cem_itr == pol._hp.iterations - 1:
+            entry['chosen'] = np.array(pol._chosen_distrib)
+        self.calls.append(entry)
+        return scores
+
+
+def _run(name, policy, adim, sdim, steps, samples, predictor_class, out_dir):
+    agent = {'type': SyntheticAgent, 'env': (SyntheticPushEnv, {'seed': 3}), 'data_save_dir': str(out_dir),
+             'T': steps, 'image_height': HEIGHT, 'image_width': WIDTH, 'adim': adim, 'sdim': sdim}
+    config = {'agent': agent, 'policy': _adapt(policy, predictor_class, samples), 'start_index': 0, 'end_index': 0,
+              'save_data': True, 'save_raw_images': True, 'ngroup': 1000}
+    np.random.seed(7)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim = Sim(config)
+        rec = _Recorder(sim.policy)
+        results = sim.run()
+    traj = os.path.join(str(out_dir), 'train', 'traj_group0', 'traj0')
+    policy_out = pickle.load(open(os.path.join(traj, 'policy_out.pkl'), 'rb'))
+    obs = pickle.load(open(os.path.join(traj, 'obs_dict.pkl'), 'rb'))
+    return sim, rec, results, policy_out, obs
+
+
+@pytest.mark.parametrize('name,policy,adim,sdim,steps,samples', EXPERIMENTS, ids=[e[0] for e in EXPERIMENTS])
+def test_reference_experiment_closed_loop_matches_oracle(tmp_path, name, policy, adim, sdim, steps, samples):
+    torch.set_num_threads(min(32, torch.get_num_threads()))        # the oracle is fastest at 32 threads (bench.py)
+    factory = lambda cfg: CdnaWeights.random(cfg, seed=0)           # == HipVPredEvaluation.restore() without a path
+    hip_sim, hip, hip_res, hip_out, hip_obs = _run(name, policy, adim, sdim, steps, samples, HipVPredEvaluation,
+                                                   tmp_path / 'hip')
+    ora_sim, ora, ora_res, ora_out, ora_obs = _run(name, policy, adim, sdim, steps, samples,
+                                                   make_oracle_predictor_class(factory), tmp_path / 'oracle')
+    hp = hip_sim.policy._hp
+    # the literal dict arrived: spot checks of what makes each experiment what it is
+    for k, v in policy.items():
+        if k in ('num_samples', 'model_path'):
+            continue
+        got = hp.get(k)
+        assert (got is v) if k == 'sampler' else (got == v), (k, got, v)
+    assert isinstance(hip_sim.policy.predictor, HipVPredEvaluation) and hip_sim.policy.predictor.device_status() == 0
+    assert hip_sim.policy.predictor.run_batch_size == 20 and samples > 20
+    K = hip_sim.policy._elite_count()
+    iters = hp.iterations
+    # GaussianCEMSampler refits on the elite ACTIONS only: identical elites -> bit-identical next candidates, actions
+    # and trajectory.  CorrelatedNoiseSampler weights the elites by exp(-kappa * score) (reference
+    # samplers/correlated_noise.py:60-66), so its next candidates inherit the fp32-level score difference between any
+    # two correct predictors (1e-7 relative) - equal to 1e-6 is what "the same plan" can mean there.
+    exact = hp.sampler is not CorrelatedNoiseSampler
+    same = np.testing.assert_array_equal if exact else \
+        (lambda x, y, err_msg='': np.testing.assert_allclose(x, y, rtol=0, atol=1e-6, err_msg=err_msg))
+
+    # --- every CEM iteration of every planning call
+    assert len(hip.calls) == len(ora.calls) == 3 * iters, 'three planning calls per trajectory'
+    assert sorted({c['t'] for c in hip.calls}) == sorted({c['t'] for c in ora.calls})
+    worst_rel, worst_gap_ratio = 0.0, np.inf
+    for a, b in zip(hip.calls, ora.calls):
+        where = '%s t=%d itr=%d' % (name, a['t'], a['itr'])
+        assert (a['t'], a['itr']) == (b['t'], b['itr'])
+        same(a['actions'], b['actions'], err_msg=where + ': candidate sets differ')
+        np.testing.assert_allclose(a['scores'], b['scores'], rtol=1e-5, err_msg=where)
+        err = np.abs(a['scores'] - b['scores']).max()
+        gap = np.diff(np.sort(b['scores']))[K - 1]                 # margin at the K / K+1 boundary
+        assert gap > 4 * err, where + ': fixture seeds give an ambiguous elite boundary'
+        np.testing.assert_array_equal(np.sort(a['scores'].argsort()[:K]), np.sort(b['scores'].argsort()[:K]),
+                                      err_msg=where + ': elite sets differ')
+        np.testing.assert_array_equal(a['scores'].argsort()[:K], b['scores'].argsort()[:K],
+                                      err_msg=where + ': elite order differs')
+        # the context distributions that went IN (one-hot at first, the propagated plan afterwards)
+        scale = max(float(b['ctx_distrib'].max()), 1e-30)
+        np.testing.assert_allclose(a['ctx_distrib'], b['ctx_distrib'], atol=2e-5 * scale, rtol=0, err_msg=where)
+        if b['chosen'] is not None:
+            assert a['chosen'].shape == b['chosen'].shape == (hip_sim.policy.predictor.sequence_length - 2, 1,
+                                                              HEIGHT, WIDTH, 1)
+            plane_max = b['chosen'].max(axis=(2, 3), keepdims=True)
+            assert np.all(np.abs(a['chosen'] - b['chosen']) <= 2e-5 * plane_max), where + ': propagated distributions'
+        worst_rel = max(worst_rel, float(np.abs(a['scores'] / b['scores'] - 1).max()))
+        worst_gap_ratio = min(worst_gap_ratio, float(gap / max(err, 1e-300)))
+    if hp.predictor_propagation:
+        # the closed loop really closed: later planning calls started from a propagated (not one-hot) distribution
+        later = [c for c in hip.calls if c['t'] != hip.calls[0]['t']]
+        assert later and all(np.count_nonzero(c['ctx_distrib']) > 2 for c in later)
+        assert all(c['chosen'] is not None for c in hip.calls if c['itr'] == iters - 1)
+
+    # --- what the agent saw and what went to disk
+    assert len(hip_out) == len(ora_out) == steps
+    for t, (a, b) in enumerate(zip(hip_out, ora_out)):
+        assert a.keys() == b.keys() == {'actions', 'plan_stat'}
+        same(a['actions'], b['actions'], err_msg='%s: action at t=%d' % (name, t))
+        assert a['actions'].shape == (adim,)
+        assert a['plan_stat'].keys() == b['plan_stat'].keys()
+        for k in a['plan_stat']:
+            np.testing.assert_allclose(a['plan_stat'][k], b['plan_stat'][k], rtol=1e-5)
+    assert set(hip_out[-1]['plan_stat'].keys()) == {'scores_itr%d' % i for i in range(iters)}
+    same(hip_obs['state'], ora_obs['state'])                                   # same actions -> same trajectory
+    assert abs(hip_res[0]['final_goal_distance'] - ora_res[0]['final_goal_distance']) <= (0 if exact else 1e-4)
+    for sub in ('hip', 'oracle'):
+        traj = os.path.join(str(tmp_path), sub, 'train', 'traj_group0', 'traj0')
+        assert sorted(os.listdir(traj)) == ['agent_data.pkl', 'images0', 'obs_dict.pkl', 'policy_out.pkl']
+        assert len(os.listdir(os.path.join(traj, 'images0'))) == steps + 1
+    print('%s: worst score rel err %.2e, smallest K/K+1 gap = %.0f x the score error' % (name, worst_rel,
+                                                                                          worst_gap_ratio))
+
+
+def test_franka_start_actions_and_schedule(tmp_path):
+    """``start_planning 5`` + ``zeros_for_start_frames False``: weighted random actions before planning starts
+    (reference ``cem_base_controller.py:138-148``), then a plan every ``replan_interval`` steps - on the device
+    predictor, with the host-only schedule facts that need no oracle."""
+    name, policy, adim, sdim, steps, samples = EXPERIMENTS[1]
+    sim, rec, res, out, obs = _run(name, policy, adim, sdim, 16, 40, HipVPredEvaluation, tmp_path)
+    assert [c['t'] for c in rec.calls] == [5] * 5 + [15] * 5
+    for t in range(5):          # (plan_stat is ONE dict per trajectory, here as in the reference: not checked per step)
+        assert np.any(out[t]['actions'] != 0)
+    plan = rec.calls[4]['actions'][rec.calls[4]['scores'].argsort()[0]]
+    for t in range(5, 15):
+        np.testing.assert_array_equal(out[t]['actions'], plan[t - 5])
+
+
+@pytest.mark.parametrize('through_controller', [False, True])
+def test_only_take_first_view_two_view_engine(through_controller):
+    """``only_take_first_view`` (reference ``pixel_cost_controller.py:150-151``: ``scores_per_task[:, 0][:, None]``,
+    i.e. camera 0 / pixel 0 alone decides) on a 2-view x 2-pixel engine against the oracle's cost with the same flag."""
+    H = W = 32
+    T, M, nd, ncam = 3, 24, 2, 2
+    weights_of = lambda cfg, v=0: CdnaWeights.random(cfg, seed=10 + v, bias_scale=0.05, ln_jitter=0.1)
+    rs = np.random.RandomState(5)
+    desig = rs.randint(0, H, (ncam, nd, 2))
+    goal = rs.randint(0, H, (ncam, nd, 2))
+    frames = rs.randint(0, 256, (2, ncam, H, W, 3)).astype(np.uint8)
+    states = rs.normal(0, .1, (2, 5))
+    oracle_cls = make_oracle_predictor_class(weights_of)
+    if not through_controller:
+        hp = dict(designated_pixel_count=nd, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,
+                  sequence_length=T + 2, ncam=ncam)
+        pred = HipVPredEvaluation('', hp)
+        pred.restore([weights_of(pred.cfg, v) for v in range(ncam)])
+        ora = oracle_cls('', hp)
+        ora.restore()
+        ctx = {'context_frames': frames, 'context_actions': rs.normal(0, .05, (1, 4)), 'context_states': states,
+               'context_pixel_distributions': pixel_cost.one_hot_distrib(desig, 2, ncam, H, W, nd)}
+        actions = rs.normal(0, .1, (M, T, 4))
+        d = ora(ctx, {'actions': actions})['predicted_pixel_distributions']
+        for flag in (True, False):
+            want, want_pt = pixel_cost.eval_pixel_cost(d, goal, 10., only_take_first_view=flag)
+            got, got_pt = pred.score(ctx, {'actions': actions}, goal, finalweight=10., only_take_first_view=flag)
+            assert got_pt.shape == want_pt.shape == ((M, 1) if flag else (M, ncam * nd))
+            np.testing.assert_allclose(got_pt, want_pt, rtol=1e-5)
+            np.testing.assert_allclose(got, want, rtol=1e-5)
+        first, _ = pred.score(ctx, {'actions': actions}, goal, finalweight=10., only_take_first_view=True)
+        _, full_pt = pred.score(ctx, {'actions': actions}, goal, finalweight=10.)
+        np.testing.assert_array_equal(first, full_pt[:, 0])            # exactly camera 0 / pixel 0's column
+        assert pred.device_status() == 0
+        return
+    ag = {'adim': 4, 'sdim': 5, 'image_height': H, 'image_width': W, 'ncam': ncam}
+    base = {'num_samples': M, 'nactions': T, 'repeat': 1, 'rejection_sampling': False, 'verbose': False,
+            'designated_pixel_count': nd, 'only_take_first_view': True, 'iterations': 2}
+    outs = []
+    for cls in (HipVPredEvaluation, oracle_cls):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ctrl = PixelCostController(dict(ag), dict(base, predictor_class=cls), 0, 1)
+            if cls is HipVPredEvaluation:
+                ctrl.predictor.restore([weights_of(ctrl.predictor.cfg, v) for v in range(ncam)])
+            ctrl.reset()
+            np.random.seed(3)
+            ctrl.act(t=0, i_tr=0, desig_pix=desig, goal_pix=goal, images=frames[:1], state=states[:1])
+            out = ctrl.act(t=1, i_tr=0, desig_pix=desig, goal_pix=goal, images=frames, state=states)
+        outs.append((out, ctrl._best_indices.copy()))
+    (hip, hip_idx), (ora, ora_idx) = outs
+    for k in ('scores_itr0', 'scores_itr1'):
+        np.testing.assert_allclose(hip['plan_stat'][k], ora['plan_stat'][k], rtol=1e-5)
+        gap = np.diff(np.sort(ora['plan_stat'][k]))[9]
+        assert gap > 4 * np.abs(hip['plan_stat'][k] - ora['plan_stat'][k]).max()
+    np.testing.assert_array_equal(hip_idx, ora_idx)
+    np.testing.assert_array_equal(hip['actions'], ora['actions'])

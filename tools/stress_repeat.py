@@ -41,9 +41,19 @@ def run(arch, H, W, T, M, nd, prec, seed, reps, ncam=1):
     for it in range(reps):
         try:
             sc, pt = pred.score(ctx, {'actions': actions}, goal)
-            cur = (np.array(sc).tobytes(), np.array(pt).tobytes())
-        except Exception as e:      # NaN scores raise (hip_predictor._check_scores): counted as a differing repetition
-            cur = ('raised: ' + str(e)[:60],)
+        except Exception as e:      # NaN scores raise (hip_predictor._check_scores)
+            if ref is None:         # never accept a failure as the reference value
+                raise
+            print('  repetition %d raised: %s' % (it, str(e)[:100]), flush=True)
+            bad += 1
+            continue
+        sc, pt = np.array(sc), np.array(pt)
+        if not (np.isfinite(sc).all() and np.isfinite(pt).all()):
+            if ref is None:
+                raise RuntimeError('the first repetition produced non-finite scores')
+            bad += 1
+            continue
+        cur = (sc.tobytes(), pt.tobytes())
         if ref is None:
             ref = cur
         elif cur != ref:

@@ -2188,6 +2188,8 @@ int vf_allgather_scores_group(int32_t n, vf_handle *const *hs, void *const *comm
         if (!hs[i] || !comms[i] || !d_local[i] || !d_all[i]) return fail(VF_ERR_INVALID, "null entry " + std::to_string(i));
     int rc = bind_rccl();
     if (rc) return rc;
+    int caller_dev = -1;        // the loop below walks the lanes' devices: hand the calling thread's device back
+    if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
     if ((rc = g_rccl.group_start()) != 0) return fail(VF_ERR_HIP, "ncclGroupStart failed with ncclResult_t " + std::to_string(rc));
     int first_bad = 0;
     for (int i = 0; i < n && !first_bad; ++i) {
@@ -2196,6 +2198,7 @@ int vf_allgather_scores_group(int32_t n, vf_handle *const *hs, void *const *comm
                                       streams ? streams[i] : nullptr);
     }
     rc = g_rccl.group_end();        // always closes the group
+    if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
     if (first_bad) return fail(VF_ERR_HIP, "grouped ncclAllGather failed (" + std::to_string(first_bad) + ")");
     if (rc != 0) return fail(VF_ERR_HIP, "ncclGroupEnd failed with ncclResult_t " + std::to_string(rc));
     return VF_OK;

@@ -88,6 +88,12 @@ class HipVPredEvaluation(object):
         if world == 1 and self.n_gpus > n_dev and not oversubscribe:
             raise ValueError('n_gpus=%d but this host exposes %d GPU(s) (set the predictor hyper-parameter '
                              "'oversubscribe_gpus' to let the lanes share devices)" % (self.n_gpus, n_dev))
+        if world == 1 and not oversubscribe and (int(first_gpu) < 0 or int(first_gpu) + self.n_gpus > n_dev):
+            # devices first_gpu .. first_gpu + n_gpus - 1 are promised: never wrap onto GPUs below first_gpu,
+            # which another policy process may own (reference sim/run.py hands out disjoint gpu_id ranges)
+            raise ValueError('first_gpu=%d + n_gpus=%d exceeds the %d GPU(s) of this host (set the predictor '
+                             "hyper-parameter 'oversubscribe_gpus' to wrap around)"
+                             % (int(first_gpu), self.n_gpus, n_dev))
         # under torchrun LOCAL_RANK picks this rank's GPU; the lanes of the in-process mode follow first_gpu
         local_rank = int(os.environ.get('LOCAL_RANK', 0)) if world > 1 else 0
         self.device_index = (int(first_gpu) + local_rank) % n_dev
@@ -157,19 +163,22 @@ class HipVPredEvaluation(object):
     def set_persistent(self, enable):
         """Run each rollout as one persistent launch (bit-identical results; see vf_persistent.h)."""
         for lane in self._all_lanes():
-            _lib.check(lane._libh.vf_set_persistent(lane._handle, int(bool(enable))))
+            with self._torch.cuda.device(lane.device):
+                _lib.check(lane._libh.vf_set_persistent(lane._handle, int(bool(enable))))
             lane.persistent = bool(enable)
 
     def set_xcd_queues(self, enable):
         """One ticket queue per XCD (default) or plain phase order; placement only, bit-identical results."""
         for lane in self._all_lanes():
-            _lib.check(lane._libh.vf_set_xcd_queues(lane._handle, int(bool(enable))))
+            with self._torch.cuda.device(lane.device):
+                _lib.check(lane._libh.vf_set_xcd_queues(lane._handle, int(bool(enable))))
             lane.xcd_queues = bool(enable)
 
     def set_fuse_top(self, enable):
         """Top transposed conv + compositing as one item per tile (vf_set_fuse_top); bit-identical results."""
         for lane in self._all_lanes():
-            _lib.check(lane._libh.vf_set_fuse_top(lane._handle, int(bool(enable))))
+            with self._torch.cuda.device(lane.device):
+                _lib.check(lane._libh.vf_set_fuse_top(lane._handle, int(bool(enable))))
             lane.fuse_top = bool(enable)
 
     def device_status(self):
@@ -177,7 +186,8 @@ class HipVPredEvaluation(object):
         worst = 0
         for lane in self._all_lanes():
             st = ctypes.c_int32()
-            _lib.check(lane._libh.vf_device_status(lane._handle, ctypes.byref(st)))
+            with self._torch.cuda.device(lane.device):
+                _lib.check(lane._libh.vf_device_status(lane._handle, ctypes.byref(st)))
             worst = max(worst, st.value)
         return worst
 
@@ -193,7 +203,8 @@ class HipVPredEvaluation(object):
     def set_dedup(self, enable):
         """Switch context de-duplication (bit-identical results either way; for A/B timing)."""
         for lane in self._all_lanes():
-            _lib.check(lane._libh.vf_set_dedup(lane._handle, int(bool(enable))))
+            with self._torch.cuda.device(lane.device):
+                _lib.check(lane._libh.vf_set_dedup(lane._handle, int(bool(enable))))
 
     # ------------------------------------------------------------------ weights
     def restore(self, weights=None):
@@ -217,8 +228,9 @@ class HipVPredEvaluation(object):
         want = self._libh.vf_weight_count(ctypes.byref(self._c_cfg)) * self.n_cam
         if blob.size != want:
             raise _lib.VfError('weight blob has %d floats, library expects %d' % (blob.size, want))
-        _lib.check(self._libh.vf_load_weights(self._handle, blob.ctypes.data_as(ctypes.c_void_p),
-                                              blob.size))
+        with self._torch.cuda.device(self.device):      # the library selects the engine's device: put the caller's back
+            _lib.check(self._libh.vf_load_weights(self._handle, blob.ctypes.data_as(ctypes.c_void_p),
+                                                  blob.size))
         for lane in (self._lanes or [])[1:]:        # the weights are replicated on every lane's device
             lane.restore(list(weights))
         return self
@@ -402,19 +414,45 @@ class HipVPredEvaluation(object):
                 local.append(buf)
                 full.append(torch.empty((n * width, cols), dtype=torch.float64, device=lane.device))
         arr = lambda items: (P * n)(*items)
-        _lib.check(self._libh.vf_allgather_scores_group(
-            n, arr([l._handle for l in self._lanes]), arr(self._comms), arr([P(t.data_ptr()) for t in local]),
-            width * cols, arr([P(t.data_ptr()) for t in full]), arr([l._stream() for l in self._lanes])))
+        with torch.cuda.device(self.device):    # (the library also puts the calling thread's device back itself)
+            _lib.check(self._libh.vf_allgather_scores_group(
+                n, arr([l._handle for l in self._lanes]), arr(self._comms), arr([P(t.data_ptr()) for t in local]),
+                width * cols, arr([P(t.data_ptr()) for t in full]), arr([l._stream() for l in self._lanes])))
         with torch.cuda.device(self.device):
             out = full[0].cpu().numpy().reshape(n, width, cols)
         for lane in self._lanes[1:]:        # every lane's collective has completed before its buffers are released
             torch.cuda.synchronize(lane.device)
         return np.concatenate([out[i, :sizes[i]] for i in range(n)], axis=0)
 
+    def set_collective_timing(self, enable):
+        """Bracket every score all-gather with HIP events on the stream the collective is ordered on (the current
+        stream of this rank's device: c10d makes it wait for the RCCL stream before the call returns) so a bench line
+        can show what the one collective of a CEM iteration costs.  ``collective_stats()`` reads them."""
+        self._coll_events = [] if enable else None
+
+    def collective_stats(self):
+        """-> {'calls', 'mean_ms', 'max_ms', 'bytes_per_rank'} of the all-gathers since ``set_collective_timing(True)``."""
+        ev = getattr(self, '_coll_events', None) or []
+        if not ev:
+            return {'calls': 0, 'mean_ms': None, 'max_ms': None, 'bytes_per_rank': None}
+        self._torch.cuda.synchronize(self.device)
+        ms = [a.elapsed_time(b) for a, b, _ in ev]
+        return {'calls': len(ms), 'mean_ms': float(np.mean(ms)), 'max_ms': float(np.max(ms)),
+                'bytes_per_rank': int(ev[-1][2])}
+
     def _all_gather(self, scores, per_task, M, world):
         """One collective: every rank's [score | per-task scores] rows -> all M rows on every rank."""
-        packed = self._torch.cat([scores[:, None], per_task], dim=1).contiguous()
-        out = all_gather_rows(packed, M)
+        torch = self._torch
+        packed = torch.cat([scores[:, None], per_task], dim=1).contiguous()
+        timing = getattr(self, '_coll_events', None)
+        if timing is not None and len(timing) < 4096:
+            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record(torch.cuda.current_stream(self.device))
+            out = all_gather_rows(packed, M)
+            stop.record(torch.cuda.current_stream(self.device))
+            timing.append((start, stop, packed.numel() * packed.element_size()))
+        else:
+            out = all_gather_rows(packed, M)
         return out[:, 0].contiguous(), out[:, 1:].contiguous()
 
     def fetch_pixel_distributions(self, sample_index):
@@ -575,6 +613,10 @@ class HipVPredEvaluation(object):
                 lo, hi = shard_bounds(M, i, n)
                 if hi > lo:
                     parts.append(lane._materialise(context, seqs[lo * nd:hi * nd], hi - lo, lo))
+                else:           # nothing of THIS call is resident on the lane (a stale range must not match a fetch)
+                    lane._last_lo, lane._last_M = lo, 0
+            if not parts:       # M == 0: empty arrays of the right shapes
+                return self._materialise(context, seqs, 0, 0)
             return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
         return self._materialise(context, seqs, actions.shape[0], 0)
 
@@ -606,6 +648,9 @@ class HipVPredEvaluation(object):
                 frames[c0:c1] = f[::nd].cpu().numpy()
                 distrib[c0:c1] = d[::nd].cpu().numpy()
                 states[c0:c1] = s[::nd].cpu().numpy()
-            self._check_scores(scores[:n].cpu().numpy())
+            if M > 0:
+                self._check_scores(scores[:n].cpu().numpy())
+            else:
+                self._last_lo, self._last_M = index_base, 0
         return {'predicted_frames': frames, 'predicted_pixel_distributions': distrib,
                 'predicted_states': states}
