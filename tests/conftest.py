@@ -12,6 +12,7 @@ GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: CPU tests that cross-compile the engine (about a minute)')
 
 
 @pytest.fixture(scope='session')

@@ -77,6 +77,10 @@ CARTGRIPPER = {                 # experiments/sim/cartgripper_2d_grasping/pixel_
 EXPERIMENTS = [('robonet_pixel_cost', ROBONET_PIXEL_COST, 4, 5, 28, 60),        # t = 1, 14, 27
                ('franka', FRANKA, 4, 5, 26, 60),                                # t = 5, 15, 25
                ('cartgripper', CARTGRIPPER, 3, 3, 22, 60)]                      # t = 1, 11, 21
+# NumPy seed of each run.  With 60 candidates two neighbouring scores at the K / K+1 boundary can fall within the fp32
+# distance between two correct predictors by chance (franka with seed 7: a 3e-6 gap at t = 25); the seeds below give
+# every iteration of every call a boundary gap >= 100x that distance, so "identical elites" is a fair demand.
+SEEDS = {'robonet_pixel_cost': 7, 'franka': 11, 'cartgripper': 7}
 HEIGHT, WIDTH = 48, 64          # 'image_height': 48, 'image_width': 64 in all three agent dicts
 
 
@@ -116,7 +120,7 @@ def _run(name, policy, adim, sdim, steps, samples, predictor_class, out_dir):
              'T': steps, 'image_height': HEIGHT, 'image_width': WIDTH, 'adim': adim, 'sdim': sdim}
     config = {'agent': agent, 'policy': _adapt(policy, predictor_class, samples), 'start_index': 0, 'end_index': 0,
               'save_data': True, 'save_raw_images': True, 'ngroup': 1000}
-    np.random.seed(7)
+    np.random.seed(SEEDS[name])
     with contextlib.redirect_stdout(io.StringIO()):
         sim = Sim(config)
         rec = _Recorder(sim.policy)

@@ -8,7 +8,10 @@ variant whose last statement stored the next ticket to LDS ran items twice, prof
 site listed here must have no LDS store between the last LDS wait of the loop body and the back edge; the listing shows
 the LDS instructions after the last `lgkmcnt(0)` / barrier / call of the function's textual tail for a quick look.
 
-    python tools/lint_barriers.py            # compiles csrc/vf_engine.hip with -save-temps into /tmp (~70 s)
+    python tools/lint_barriers.py            # device-only compile of csrc/vf_engine.hip to assembly in /tmp (~50 s)
+
+Exit code 1 when a loop-head barrier has an LDS store pending on its back edge, or when the scheduler loop of the
+persistent kernel lost its explicit wait; tests/test_kernel_lint.py runs this in the CPU suite.
 """
 import os
 import re
@@ -19,15 +22,24 @@ import tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main():
+def device_assembly(extra_flags=()):
+    """gfx950 assembly of the engine (device-only compile, ~50 s)."""
     tmp = tempfile.mkdtemp(prefix='vf_lint_')
     src = os.path.join(REPO, 'visual_foresight_amd', 'csrc', 'vf_engine.hip')
-    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-shared', '-fPIC',
-           '-save-temps=obj', '-o', os.path.join(tmp, 'lint.so'), src]
+    out = os.path.join(tmp, 'vf_engine_gfx950.s')
+    hipcc = '/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else 'hipcc'
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only',
+           '--no-gpu-bundle-output', '-S', '-o', out, src] + list(extra_flags)
     subprocess.run(cmd, cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    asm = [f for f in os.listdir(tmp) if f.endswith('gfx950.s')]
-    lines = open(os.path.join(tmp, asm[0])).read().split('\n')
-    func, label, label_line, n = None, None, 0, 0
+    with open(out) as f:
+        return f.read().split('\n')
+
+
+def lint(lines):
+    """-> list of findings {'func', 'line', 'label', 'tail', 'pending': [LDS stores behind the last LDS wait of the loop
+    tail]} for every loop-head `s_barrier` without an `s_waitcnt lgkmcnt(0)` in its block."""
+    findings = []
+    func, label, label_line = None, None, 0
     for k, l in enumerate(lines):
         m = re.match(r'^(_Z\w+):', l)
         if m:
@@ -40,7 +52,6 @@ def main():
         block = lines[label_line:k]
         if any('lgkmcnt(0)' in x for x in block) or not any('Loop Header' in x for x in lines[label_line:label_line + 12]):
             continue
-        n += 1
         # the loop's textual extent: up to the last branch back to a label at or before this header
         hdr_no = int(label.split('_')[1])
         end = k
@@ -54,13 +65,44 @@ def main():
         for q in range(end, k, -1):
             if 'lgkmcnt(0)' in lines[q] or 's_barrier' in lines[q] or 's_swappc' in lines[q]:
                 break
-            if re.search(r'\bds_(write|add|min|max|or|and|xor)', lines[q]):
+            if re.search(r'\bds_(write|store|add|min|max|or|and|xor)', lines[q]):
                 pending.append(lines[q].strip())
+        findings.append({'func': func, 'line': k, 'label': label, 'tail': end, 'pending': pending})
+    return findings
+
+
+def scheduler_barrier_is_guarded(lines):
+    """The scheduler loop of every rollout_persistent_kernel instance must reach its loop-head barrier through the
+    explicit `s_waitcnt lgkmcnt(0)` of vf_persistent.h (not through whatever the compiler decides to emit): the first
+    `s_barrier` after the kernel's entry label has an `lgkmcnt(0)` wait within the few instructions in front of it."""
+    bad, func, seen = [], None, False
+    for k, l in enumerate(lines):
+        m = re.match(r'^(_ZN2vf25rollout_persistent_kernel\w*):', l)
+        if m:
+            func, seen = m.group(1), False
+        elif re.match(r'^_Z\w+:', l):
+            func = None
+        if func and not seen and 's_barrier' in l:
+            seen = True
+            window = [x for x in lines[max(0, k - 6):k] if not x.strip().startswith(';')]
+            if not any('lgkmcnt(0)' in x for x in window):
+                bad.append(func)
+    return bad
+
+
+def main():
+    lines = device_assembly()
+    findings = lint(lines)
+    for f in findings:
         print('%s\n   loop-head barrier at line %d (%s), loop tail line %d: %s' % (
-            func, k, label, end, 'LDS STORES PENDING ON THE BACK EDGE: ' + '; '.join(pending[:4]) if pending
+            f['func'], f['line'], f['label'], f['tail'],
+            'LDS STORES PENDING ON THE BACK EDGE: ' + '; '.join(f['pending'][:4]) if f['pending']
             else 'no LDS store behind the last LDS wait of the tail'))
-    print('%d loop-head barriers without an LDS wait in their block' % n)
-    return 0
+    print('%d loop-head barriers without an LDS wait in their block' % len(findings))
+    unguarded = scheduler_barrier_is_guarded(lines)
+    for name in unguarded:
+        print('scheduler loop of %s: no explicit lgkmcnt(0) in front of its loop-head barrier' % name)
+    return 1 if unguarded or any(f['pending'] for f in findings) else 0
 
 
 if __name__ == '__main__':

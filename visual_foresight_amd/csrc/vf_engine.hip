@@ -249,8 +249,13 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
         l.gs_v2 = l.mrep == 1 && l.stride == 1 && (size_t)l.NI * LH * LW <= 320;
 #ifdef VF_DEBUG_KNOBS
         if (const char *e = getenv("VF_GSPLIT_V2")) l.gs_v2 = l.gs_v2 && atoi(e) != 0;
+#else
+        // production builds carry ONE 128-row gate-split tile (vf_conv_gsplit.h); a geometry it cannot stage (none of
+        // the shipped networks has one) falls back to the weights-through-LDS tile instead of the first-generation
+        // gate-split tile, which only exists in -DVF_DEBUG_KNOBS builds
+        if (l.mrep == 1 && !l.gs_v2) l.gsplit = false;
 #endif
-        l.lds_bytes = std::max(l.lds_bytes - b_lds, (size_t)vf::kGsXchFloats * 4 + 64);
+        if (l.gsplit) l.lds_bytes = std::max(l.lds_bytes - b_lds, (size_t)vf::kGsXchFloats * 4 + 64);
     }
     if (l.prec == 1) {
         const int LH = (l.TH - 1) * l.stride + l.KH, LW = (l.TW - 1) * l.stride + l.KW;
@@ -596,7 +601,12 @@ static int configure_kernels(vf_handle *h) {
     const size_t n = h->max_lds;
     int rc;
     if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_LSTM, 1>, n))) return rc;
+#ifdef VF_DEBUG_KNOBS
     if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_LSTM, 2>, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_gsplit_kernel<1>, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_gsplit_kernel<2>, n))) return rc;
+    if ((rc = allow_lds(&conv_lstm_split_kernel<2>, n))) return rc;
+#endif
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_BIAS_RELU, 1>, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_RAW_STATS, 1>, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_CONVT_RELU, 1>, n))) return rc;
@@ -605,9 +615,6 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_lstm_bf16x6_kernel<1>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_gsplit64_kernel, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_gsplit2_kernel<4>, n))) return rc;
-    if ((rc = allow_lds(&conv_lstm_gsplit_kernel<1>, n))) return rc;
-    if ((rc = allow_lds(&conv_lstm_gsplit_kernel<2>, n))) return rc;
-    if ((rc = allow_lds(&conv_lstm_split_kernel<2>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_split_kernel<1>, n))) return rc;
     const size_t np = n + kCtlWords * sizeof(int);
     if ((rc = allow_lds(&rollout_persistent_kernel<1>, np))) return rc;
@@ -628,16 +635,23 @@ static int launch_conv_m(const ConvLayer &l, const ConvParams &p, hipStream_t st
 
 static int launch_lstm_split(const ConvLayer &l, const ConvParams &p, hipStream_t st) {
     const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
-    if (l.gsplit && l.mrep == 2)
-        hipLaunchKernelGGL(conv_lstm_gsplit_kernel<2>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
-    else if (l.gs_v2)
+    // (tiles no production plan selects - the first-generation gate-split tiles and the 64-row tile with its weights
+    // through LDS - are compiled into -DVF_DEBUG_KNOBS builds only; plan_geometry / vf_create never plan them otherwise)
+    if (l.gs_v2)
         hipLaunchKernelGGL(conv_lstm_gsplit2_kernel<4>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     else if (l.gsplit && l.mrep == 0)
         hipLaunchKernelGGL(conv_lstm_gsplit64_kernel, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
+#ifdef VF_DEBUG_KNOBS
+    else if (l.gsplit && l.mrep == 2)
+        hipLaunchKernelGGL(conv_lstm_gsplit_kernel<2>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     else if (l.gsplit)
         hipLaunchKernelGGL(conv_lstm_gsplit_kernel<1>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     else if (l.mrep == 0)
         hipLaunchKernelGGL(conv_lstm_split_kernel<2>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
+#else
+    else if (l.gsplit || l.mrep == 0)
+        return fail(VF_ERR_INVALID, "conv-LSTM tile plan not compiled into this build (needs -DVF_DEBUG_KNOBS)");
+#endif
     else
         hipLaunchKernelGGL(conv_lstm_split_kernel<1>, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
     VF_HIP_CHECK(hipGetLastError());
@@ -659,7 +673,12 @@ static int launch_conv_t(const ConvLayer &l, const ConvParams &p, hipStream_t st
     if constexpr (EPI == EPI_LSTM) {
         if (l.prec == 1) return launch_lstm_bf16x6<1>(l, p, st);        // 128-row tiles only
         if (l.mrep <= 0 || l.gsplit) return launch_lstm_split(l, p, st);
-        return l.mrep == 1 ? launch_conv_m<G, EPI, 1>(l, p, st) : launch_conv_m<G, EPI, 2>(l, p, st);
+#ifdef VF_DEBUG_KNOBS
+        if (l.mrep == 2) return launch_conv_m<G, EPI, 2>(l, p, st);
+#else
+        if (l.mrep == 2) return fail(VF_ERR_INVALID, "256-row conv-LSTM plan not compiled into this build");
+#endif
+        return launch_conv_m<G, EPI, 1>(l, p, st);
     } else if constexpr (EPI == EPI_PARTIAL) {
         return launch_conv_m<G, EPI, 2>(l, p, st);
     } else {
@@ -823,11 +842,18 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         init_layer(h->lstm_big[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[1],
                    sm.segC[0], sm.Cout, true, false, 2, 0);
         // same chunking = same K order per output (bit-identical results) and the same packed weights
+#ifdef VF_DEBUG_KNOBS
         h->big_ok[k] = h->lstm_big[k].KC == sm.KC;
+#else
+        h->big_ok[k] = false;       // the 256-row tile lost to the 128-row gate-split tile at every batch size (round 3): debug builds only
+#endif
         if (h->big_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_big[k].stats_nparts);
         init_layer(h->lstm_half[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[1],
                    sm.segC[0], sm.Cout, true, false, 0, 0);
         h->half_ok[k] = h->lstm_half[k].KC == sm.KC && sm.KC == 32;
+#ifndef VF_DEBUG_KNOBS
+        h->half_ok[k] = h->half_ok[k] && h->lstm_half[k].gsplit;     // the only 64-row tile of a production build
+#endif
         if (h->half_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_half[k].stats_nparts);
         init_layer(h->lstm_quarter[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2,
                    sm.segC[1], sm.segC[0], sm.Cout, true, false, -1, 0);
@@ -1627,6 +1653,13 @@ static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &
     int ticket = 0;
     for (PhaseDesc &P : out.phases) { P.first_ticket = ticket; ticket += P.n_items; }
     out.items = ticket;
+#ifndef VF_DEBUG_KNOBS
+    // the persistent kernel of a production build carries the tiles 6 / 5 / -1 / 1 only (vf_persistent.h)
+    for (const PhaseDesc &P : out.phases)
+        if (P.type == PH_LSTM && P.prec == 0 && !(P.mrep == 6 || P.mrep == 5 || P.mrep == -1 || P.mrep == 1))
+            return fail(VF_ERR_INVALID, "conv-LSTM tile plan " + std::to_string(P.mrep) +
+                                            " is not compiled into this build (needs -DVF_DEBUG_KNOBS)");
+#endif
     // Deal every phase's items to the XCD queues (vf_persistent.h): item = (unit * q_inner + inner) * q_gy + cg
     // goes to queue (unit % (nq / q_gy)) * q_gy + cg.  unit = sample (or sample group) of the item, inner = its
     // tile within the sample, cg = output-channel group.  Launches too small to occupy every XCD keep one queue.

@@ -208,10 +208,14 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
 
     for (;;) {
         [[maybe_unused]] const unsigned long long ts_top = VF_TS_NOW();
+        // hipcc 7.2 does not put an `s_waitcnt lgkmcnt(0)` in front of a loop-head barrier for an LDS store that is
+        // still pending on the back edge (a draw moved to the end of this body once let the other waves read the
+        // previous ticket, profiles/r03_tile_plan_sweep.txt).  The wait is therefore explicit - measured free - so
+        // that the scheduler does not depend on where the compiler places its waits; tools/lint_barriers.py
+        // (tests/test_kernel_lint.py, CPU suite) checks that it is still there and that no other loop-head barrier of
+        // the code object is reached with an LDS store in flight.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();                    // previous item fully retired (LDS reusable)
-        // (Keep LDS stores out of the END of this loop body: hipcc 7.2 does not put an `s_waitcnt lgkmcnt(0)` in front of
-        // this loop-head barrier for a store pending on the back edge - a draw moved there let the other waves read the
-        // previous ticket, profiles/r03_tile_plan_sweep.txt; it was no faster with the wait added by hand either.)
         VF_TRACE_EVT(TR_TICKET);
         if (tid == 0) {
             int t = -1, qq = q_own;
@@ -291,15 +295,22 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
             const int by = local % P.gy, bx = local / P.gy;
             switch (P.type) {
                 case PH_LSTM:
+                    // Production plans (lstm_plan / plan_geometry in vf_engine.hip) select four fp32 tiles: the 128- and
+                    // 64-row gate-split tiles, the 32-row tile, and - only for a geometry the gate-split tile cannot stage
+                    // - the 128-row tile with its weights through LDS.  The tiles that lost in rounds 2-3 (first-generation
+                    // gate-split 128 / 256 rows, 256 rows from L2, 64 rows through LDS) are A/B material of
+                    // -DVF_DEBUG_KNOBS builds: compiled in here they cost the launch 33 spilled VGPRs and 924 B of scratch.
                     if (P.prec == 1) lstm_bf16x6_tile_call<1>(&P.conv, bx, by);         // 128-row tiles only
-                    else if (P.mrep == 0) lstm_split_tile_call<2>(&P.conv, bx, by);
-                    else if (P.mrep < 0) lstm_split_tile_call<1>(&P.conv, bx, by);
-                    else if (P.mrep == 3) lstm_gsplit_tile_call<1>(&P.conv, bx, by);       // gate-split 128-row tile
-                    else if (P.mrep == 4) lstm_gsplit_tile_call<2>(&P.conv, bx, by);       // gate-split 256-row tile
-                    else if (P.mrep == 5) lstm_gsplit64_tile_call(&P.conv, bx, by);        // gate-split 64-row tile
                     else if (P.mrep == 6) lstm_gsplit2_tile_call<4>(&P.conv, bx, by);    // gate-split 128-row tile, final form
-                    else if (P.mrep == 1) conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
-                    else conv_tile_call<4, EPI_LSTM, 2>(&P.conv, bx, by, 0);
+                    else if (P.mrep == 5) lstm_gsplit64_tile_call(&P.conv, bx, by);        // gate-split 64-row tile
+                    else if (P.mrep < 0) lstm_split_tile_call<1>(&P.conv, bx, by);
+#ifdef VF_DEBUG_KNOBS
+                    else if (P.mrep == 0) lstm_split_tile_call<2>(&P.conv, bx, by);
+                    else if (P.mrep == 3) lstm_gsplit_tile_call<1>(&P.conv, bx, by);       // gate-split 128-row tile, first form
+                    else if (P.mrep == 4) lstm_gsplit_tile_call<2>(&P.conv, bx, by);       // gate-split 256-row tile
+                    else if (P.mrep == 2) conv_tile_call<4, EPI_LSTM, 2>(&P.conv, bx, by, 0);
+#endif
+                    else conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
                     break;
                 case PH_CONV_RELU: conv_tile_call<1, EPI_BIAS_RELU, 1>(&P.conv, bx, by, 0); break;
                 case PH_CONV_RAW: conv_tile_call<1, EPI_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
