@@ -1498,6 +1498,12 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
             q.out = O.h_state[k][nxt]; q.cstate = O.c_state[k]; q.stats = O.st_h[k];
             q.stats_nparts = h->st_rows[k];
             q.cstate_in = I.c_state[k]; q.cin_bstride = bs(in_sh, per);
+#ifdef VF_DEBUG_KNOBS
+            // TIMING ONLY (wrong results): the recurrent half of every conv-LSTM item vanishes - an upper bound on what
+            // taking it off the per-sample dependency chain could give a small shard (round 4, EXPERIMENTS.md)
+            static const bool no_rec = getenv("VF_TIMING_NO_RECURRENT") && atoi(getenv("VF_TIMING_NO_RECURRENT"));
+            if (no_rec) { q.seg[0].nchunk = 0; q.chunks_per_split = q.seg[1].nchunk; }
+#endif
             return q;
         };
         VF_EMIT_SH(u_l1, lstm_shared(0, s), sink.lstm(lstm_plan(0, lstm_shared(0, s) ? 1 : B), lstm_params(0, enc0_n), u_prev[0], u_enc0))
