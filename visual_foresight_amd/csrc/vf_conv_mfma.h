@@ -62,7 +62,7 @@ constexpr int kTraceWgs = 512;
 __device__ unsigned long long g_trace[(size_t)kTraceWgs * kTraceMax];
 __device__ unsigned g_trace_n[kTraceWgs];
 enum TraceCode { TR_TICKET = 1, TR_DONE = 3, TR_STAGE = 10, TR_KLOOP = 11, TR_LATE = 12, TR_LATE_END = 13, TR_EPI = 14,
-                 TR_MFMAS = 15 /* value: MFMAs per wave per chunk */, TR_ST_LOADED = 16, TR_ST_WRITTEN = 17, TR_TOP_STATS = 24, TR_TOP_HALO = 25, TR_TOP_MATES = 26, TR_HWID = 20 /* value: xcc << 16 | hw_id */,
+                 TR_MFMAS = 15 /* value: MFMAs per wave per chunk */, TR_ST_LOADED = 16, TR_ST_WRITTEN = 17, TR_TOP_STATS = 24, TR_TOP_HALO = 25, TR_TOP_MATES = 26, TR_HWID = 20 /* value: xcc << 16 | hw_id */, TR_PHASE = 21 /* value: index of the phase the item belongs to */,
                  TR_RUN = 32 /* + phase type */ };
 __device__ __forceinline__ void vf_trace(const unsigned code, const unsigned long long val = ~0ull) {
     if (threadIdx.x == 0 && blockIdx.x < kTraceWgs) {

@@ -287,6 +287,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
         if (s_ctl[1] == 0) break;           // a producer never arrived: abandon the rollout
         const unsigned long long t_run = sched.stats ? wall_clock64() : 0ull;
         VF_TRACE_EVT(TR_RUN + (unsigned)P.type);
+        VF_TRACE_EVT(TR_PHASE, (unsigned long long)ph_run);
 
         // ---- run the item
         {
