@@ -491,15 +491,20 @@ class Bench(object):
         """HBM bytes per launch cannot be counted from inside the process: they come from the committed
         rocprofv3 PMC passes of this same command (tools/pmc_hbm.sh) and are only quoted when that profile
         was taken from this very library (source hash) on this workload."""
-        path = os.path.join(REPO, 'profiles', 'r03_hbm_traffic.json')
-        if not os.path.exists(path):
+        import glob
+        prof = name = None
+        for path in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_hbm_traffic.json')), reverse=True):
+            with open(path) as f:
+                cand = json.load(f)
+            if cand.get('lib_sources_sha16') == library_hash():     # the newest round's profile of THIS library
+                prof, name = cand, os.path.basename(path)
+                break
+        if prof is None:
             return
-        with open(path) as f:
-            prof = json.load(f)
-        if (prof.get('lib_sources_sha16') == library_hash() and prof.get('workload') == self.args.workload
+        if (prof.get('workload') == self.args.workload
                 and prof.get('precision') == precision and self.world == 1 and not self.args.samples):
             roof['traffic'] = prof['hbm_bytes_per_launch']
-            roof['traffic_source'] = 'profiles/r03_hbm_traffic.json (rocprofv3 PMC passes of this library, offline)'
+            roof['traffic_source'] = 'profiles/%s (rocprofv3 PMC passes of this library, offline)' % name
             roof['traffic_vs_algorithmic'] = prof.get('ratio_to_algorithmic')
             if roof.get('avg_launch_us'):       # HBM-side rate of the launch against the 8 TB/s peak (north_star: GB/s vs peak)
                 roof['hbm_gbps'] = prof['hbm_bytes_per_launch'] / (roof['avg_launch_us'] * 1e-6) / 1e9

@@ -3,7 +3,7 @@
 # summaries into profiles/ afterwards).  usage: tools/run_profiles.sh <tag>
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-tag=${1:-r03}
+tag=${1:-r04}
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 cd $R
@@ -45,6 +45,8 @@ if [ -f build/ab/trace.so ]; then
   VF_LIBRARY=build/ab/trace.so timeout 300 python tools/trace_cu.py 200 > $O/cu_trace_200.txt 2>&1
   VF_TRACE_TIMELINE=1 VF_LIBRARY=build/ab/trace.so timeout 300 python tools/trace_cu.py 200 2>&1 | awk '/^timeline/{f=1} f' > $O/cu_trace_200_timeline.txt
   VF_LIBRARY=build/ab/trace.so timeout 300 python tools/trace_cu.py 25 > $O/cu_trace_25.txt 2>&1
+  VF_LIBRARY=build/ab/trace.so timeout 300 python tools/trace_chain.py 25 6 1 > $O/chain_25.txt 2>&1
+  VF_LIBRARY=build/ab/trace.so timeout 300 python tools/trace_chain.py 200 6 1 > $O/chain_200.txt 2>&1
 fi
 [ -x tools/ubench/mfma_shadow ] && timeout 120 tools/ubench/mfma_shadow > $O/mfma_shadow_ubench.txt 2>&1
 [ -x tools/ubench/hbm_calib ] && timeout 300 bash tools/pmc_calib.sh > /dev/null 2>&1 && cp gpurun_out/hbm_calib.txt $O/hbm_calib.txt
