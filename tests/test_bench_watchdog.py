@@ -49,3 +49,31 @@ def test_launcher_env_caps_host_threads_and_never_needs_torch():
     import inspect
     src = inspect.getsource(bench.spawn_ranks)
     assert 'import torch' not in src and 'torch.cuda' not in src
+
+
+def test_traffic_is_quoted_only_from_a_profile_of_this_library():
+    """`roofline.traffic` comes from the newest committed PMC profile whose source hash equals the running library's
+    (the counters cannot be read in-process); any other profile, workload or precision leaves it null."""
+    import glob
+    import json
+    import os
+    import types
+    b = bench.Bench.__new__(bench.Bench)
+    b.args = types.SimpleNamespace(workload='c2', samples=0)
+    b.world = 1
+    matching = [p for p in sorted(glob.glob(os.path.join(bench.REPO, 'profiles', 'r*_hbm_traffic.json')), reverse=True)
+                if json.load(open(p)).get('lib_sources_sha16') == bench.library_hash()]
+    roof = {'traffic': None, 'avg_launch_us': 63000.0}
+    b.attach_traffic(roof, 'fp32')
+    if matching:
+        prof = json.load(open(matching[0]))
+        assert roof['traffic'] == prof['hbm_bytes_per_launch'] and os.path.basename(matching[0]) in roof['traffic_source']
+        assert 0 < roof['hbm_frac_of_peak'] < 1
+    else:
+        assert roof['traffic'] is None
+    for kw, prec in (({'workload': 'c4', 'samples': 0}, 'fp32'), ({'workload': 'c2', 'samples': 25}, 'fp32'),
+                     ({'workload': 'c2', 'samples': 0}, 'bf16x6')):
+        b.args = types.SimpleNamespace(**kw)
+        other = {'traffic': None, 'avg_launch_us': 1.0}
+        b.attach_traffic(other, prec)
+        assert other['traffic'] is None
