@@ -8,7 +8,9 @@ predictor and once with the CPU oracle behind the SAME controller (host cost pat
     ``predictor_propagation``, ``replan_interval 13``, ``selection_frac .05``;
   * ``experiments/robonet/franka/franka.py:40-58``        ``CorrelatedNoiseSampler``, 5 iterations, ``start_planning 5``,
     random start actions, ``verbose_every_iter``;
-  * ``experiments/sim/cartgripper_2d_grasping/pixel_cost/hparams.py:31-39``   ``action_order`` x / z / grasp, adim 3.
+  * ``experiments/sim/cartgripper_2d_grasping/pixel_cost/hparams.py:31-39``   ``action_order`` x / z / grasp, adim 3;
+  * ``experiments/robonet/baxter_fine_tune/baxter_fine_tune.py:31-44``        correlated sampler WITH propagation,
+    ``start_planning 2``, ``selection_frac 2/3`` (K = 40 of 60).
 
 The dicts are the reference's, key for key; what differs is stated in ``_adapt``: ``type`` / ``predictor_class`` are
 this repo's classes, ``model_path`` is dropped (no checkpoint exists in this project: seeded random weights on both
@@ -73,14 +75,31 @@ CARTGRIPPER = {                 # experiments/sim/cartgripper_2d_grasping/pixel_
     'num_samples': 800,
 }
 
+BAXTER_FINE_TUNE = {            # experiments/robonet/baxter_fine_tune/baxter_fine_tune.py:31-44
+    'verbose_every_iter': True,
+    'replan_interval': 13,
+    'num_samples': 600,
+    'start_planning': 2,
+    'selection_frac': 2. / 3,
+    'predictor_propagation': True,
+    'nactions': 13,
+    'model_path': '~/models/train_baxterout_baxter_finetune/household/checkpoint_70000/',
+    'sampler': CorrelatedNoiseSampler,
+}
+# (experiments/robonet/view_generalization/all_views.py cannot run in the reference either: its 5-dim `initial_std` meets
+#  the 4 entries of `context_action_weight` in cem_base_controller.py:143-144 and NumPy refuses the product - this repo's
+#  controller raises the same ValueError - and its `model_params_path` / `model_restore_path` are not hyper-parameters of
+#  this snapshot's controller.)
+
 #                name                 policy dict     adim sdim  episode length (-> planning calls at)   samples
 EXPERIMENTS = [('robonet_pixel_cost', ROBONET_PIXEL_COST, 4, 5, 28, 60),        # t = 1, 14, 27
                ('franka', FRANKA, 4, 5, 26, 60),                                # t = 5, 15, 25
-               ('cartgripper', CARTGRIPPER, 3, 3, 22, 60)]                      # t = 1, 11, 21
+               ('cartgripper', CARTGRIPPER, 3, 3, 22, 60),                      # t = 1, 11, 21
+               ('baxter_fine_tune', BAXTER_FINE_TUNE, 4, 5, 29, 60)]            # t = 2, 15, 28; K = 40 of 60
 # NumPy seed of each run.  With 60 candidates two neighbouring scores at the K / K+1 boundary can fall within the fp32
 # distance between two correct predictors by chance (franka with seed 7: a 3e-6 gap at t = 25); the seeds below give
 # every iteration of every call a boundary gap >= 100x that distance, so "identical elites" is a fair demand.
-SEEDS = {'robonet_pixel_cost': 7, 'franka': 11, 'cartgripper': 7}
+SEEDS = {'robonet_pixel_cost': 7, 'franka': 11, 'cartgripper': 7, 'baxter_fine_tune': 3}
 HEIGHT, WIDTH = 48, 64          # 'image_height': 48, 'image_width': 64 in all three agent dicts
 
 

@@ -290,3 +290,26 @@ def test_pred_util_context_and_chunking_match_reference(golden_dir):
     np.testing.assert_array_equal(np.concatenate(gi, 0), g['roll/gen_images'])
     np.testing.assert_array_equal(np.concatenate(gd, 0), g['roll/gen_distrib'])
     assert all(x is None for x in gs) == meta['gen_state_all_none']
+
+
+def test_all_views_config_fails_like_the_reference():
+    """``experiments/robonet/view_generalization/all_views.py:25-40``: a 5-dim ``initial_std`` (the correlated sampler takes
+    its action dimension from it) against the 4 entries of ``context_action_weight`` - the product in the reference's
+    ``cem_base_controller.py:143-144`` cannot broadcast, so the first ``act()`` of that experiment raises there; same here
+    (the file's ``model_params_path`` / ``model_restore_path`` are unknown hyper-parameters on top of that)."""
+    from visual_foresight_amd.policy.cem_controllers.samplers import CorrelatedNoiseSampler
+    fake = make_fake_predictor_class(13, 16, 16)
+    pol = {'replan_interval': 13, 'verbose_every_iter': True, 'zeros_for_start_frames': False, 'num_samples': 600,
+           'selection_frac': 2. / 3, 'predictor_propagation': True, 'nactions': 13, 'sampler': CorrelatedNoiseSampler,
+           'context_action_weight': [2, 2, 0.05, 2], 'initial_std': [0.05, 0.05, 0.2, np.pi / 10, 1],
+           'predictor_class': fake}
+    ag = dict(AG, adim=5, image_height=16, image_width=16)
+    with quiet():
+        ctrl = PixelCostController(ag, pol, 0, 1)
+        ctrl.reset()
+        with pytest.raises(ValueError, match='broadcast'):
+            ctrl.act(t=0, i_tr=0, desig_pix=[[8, 8]], goal_pix=[[3, 12]],
+                     images=np.zeros((1, 1, 16, 16, 3), np.uint8), state=np.zeros((1, 5)))
+    with pytest.raises(Exception):
+        with quiet():
+            PixelCostController(dict(ag), dict(pol, model_params_path='x.json'), 0, 1)
