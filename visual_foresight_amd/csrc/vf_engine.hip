@@ -1688,10 +1688,18 @@ static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &
             }
         }
         const int units = P.n_items / (P.q_gy * P.q_inner), per = nq / P.q_gy;
+        // The units that do not fill a whole round of the queue groups are dealt tile by tile (PhaseDesc::q_full) -
+        // except where a sample's tiles must meet in one queue (fused top: its tiles wait for each other; compositing).
+        const bool split_tail = nq > 1 && P.q_inner > 1 && P.type <= PH_CONVT_RAW;
+        const int full_units = split_tail ? (units / per) * per : units;
+        const int n_tail = (units - full_units) * P.q_inner;       // (unit, tile) pairs dealt one by one
+        P.q_full = split_tail ? (full_units / per) * P.q_inner : 0x7FFFFFFF;
         for (int q = 0; q < kQueues; ++q) {
             const int qb = q / P.q_gy;
             P.first_q[q] = out.total_q[q < nq ? q : 0];
-            P.n_q[q] = (q < nq && qb < units) ? ((units - qb + per - 1) / per) * P.q_inner : 0;
+            if (q >= nq) P.n_q[q] = 0;
+            else if (split_tail) P.n_q[q] = P.q_full + (qb < n_tail ? (n_tail - qb + per - 1) / per : 0);
+            else P.n_q[q] = qb < units ? ((units - qb + per - 1) / per) * P.q_inner : 0;
             if (q < nq) out.total_q[q] += P.n_q[q];
         }
     }
@@ -1793,14 +1801,26 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
                 if (P.first_q[q] != head[q]) return fail(VF_ERR_INVALID, "queue ranges are not contiguous");
                 for (int lq = 0; lq < P.n_q[q]; ++lq) {
                     const int per = bs.nq / P.q_gy, qb = q / P.q_gy, cg = q - qb * P.q_gy;
-                    const int grp = lq / P.q_inner, inner = lq - grp * P.q_inner;
-                    const int local = ((grp * per + qb) * P.q_inner + inner) * P.q_gy + cg;
+                    int unit, inner;
+                    if (lq < P.q_full) {
+                        const int grp = lq / P.q_inner;
+                        inner = lq - grp * P.q_inner; unit = grp * per + qb;
+                    } else {
+                        const int ii = (lq - P.q_full) * per + qb, u = ii / P.q_inner;
+                        inner = ii - u * P.q_inner; unit = (P.q_full / P.q_inner) * per + u;
+                    }
+                    const int local = (unit * P.q_inner + inner) * P.q_gy + cg;
                     if (local < 0 || local >= P.n_items || seen[(size_t)local])
                         return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": dealing is not a bijection");
                     seen[(size_t)local] = 1;
                 }
                 head[q] += P.n_q[q];
                 total += P.n_q[q];
+            }
+            if (bs.nq > 1 && P.q_inner > 1 && P.type <= PH_CONVT_RAW) {    // tile-by-tile tail: balanced to one item
+                int lo = P.n_q[0], hi = P.n_q[0];
+                for (int q = 0; q < bs.nq; ++q) { lo = std::min(lo, P.n_q[q]); hi = std::max(hi, P.n_q[q]); }
+                if (hi - lo > 1) return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": queues are not balanced");
             }
             for (int q = bs.nq; q < kQueues; ++q)
                 if (P.n_q[q]) return fail(VF_ERR_INVALID, "items in an unused queue");

@@ -50,6 +50,11 @@ struct PhaseDesc {
     int q_gy, q_inner;                  // dealing rule: item = (unit * q_inner + inner) * q_gy + cg  ->  queue
                                         // (unit % (nq / q_gy)) * q_gy + cg, so a channel group's weight slice and a
                                         // sample's tiles stay inside one XCD's L2
+    int q_full;                         // queue positions [0, q_full) of this phase follow that rule; the units that do
+                                        // not fill a whole round of the nq / q_gy queue groups (25 samples on 8 XCDs: one)
+                                        // are dealt tile by tile behind them, so the queues differ by one ITEM, not by
+                                        // one sample (a queue only gets help once it is exhausted: an XCD with one
+                                        // sample more than the others held a small shard back by 5 %)
     int gx, gy;             // conv phases: items = gx * gy * gz, channel group (gy) fastest
     int B;                  // samples this phase covers
     int NI, tiles_per_img;  // conv phases: how an item maps to samples
@@ -242,8 +247,18 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
         {
             const int lq = t - P.first_q[qq];
             const int per = nq / P.q_gy, qb = qq / P.q_gy, cg = qq - qb * P.q_gy;
-            const int grp = lq / P.q_inner, inner = lq - grp * P.q_inner;
-            local = ((grp * per + qb) * P.q_inner + inner) * P.q_gy + cg;
+            int unit, inner;
+            if (lq < P.q_full) {            // whole rounds of units: a sample's tiles stay in this queue
+                const int grp = lq / P.q_inner;
+                inner = lq - grp * P.q_inner;
+                unit = grp * per + qb;
+            } else {                        // the remaining units, dealt tile by tile over the queue groups
+                const int i = (lq - P.q_full) * per + qb;
+                const int u = i / P.q_inner;
+                inner = i - u * P.q_inner;
+                unit = (P.q_full / P.q_inner) * per + u;
+            }
+            local = (unit * P.q_inner + inner) * P.q_gy + cg;
         }
 
         int b0, b1;
