@@ -224,6 +224,25 @@ def test_n_gpus_in_process_lanes_match_one_engine():
         for k in want_out:
             np.testing.assert_array_equal(out[k], want_out[k])
         assert lanes.device_status() == 0
+        # fewer candidates than lanes: the lanes left empty forget what they held (round-3 advisor: a stale range must
+        # not answer a fetch with a sample of an EARLIER rollout), and an empty candidate set is not an error
+        few = lanes(ctx, {'actions': actions[:n - 1]})
+        for k in want_out:
+            np.testing.assert_array_equal(few[k], want_out[k][:n - 1])
+        assert [l._last_M for l in lanes._lanes][n - 1] == 0
+        np.testing.assert_array_equal(lanes.fetch_pixel_distributions(n - 2),
+                                      want_out['predicted_pixel_distributions'][n - 2])
+        with pytest.raises(IndexError):
+            lanes.fetch_pixel_distributions(n - 1)
+        none = lanes(ctx, {'actions': actions[:0]})
+        assert none['predicted_frames'].shape == (0, T, 1, H, W, 3)
+        assert torch.cuda.current_device() == 0             # every entry point leaves the caller's device current
+    # devices first_gpu .. first_gpu + n_gpus - 1 are a promise: no silent wrap onto GPUs below first_gpu
+    n_dev = torch.cuda.device_count()
+    with pytest.raises(ValueError):
+        HipVPredEvaluation('', hp, n_gpus=1, first_gpu=n_dev)
+    wrapped = HipVPredEvaluation('', dict(hp, oversubscribe_gpus=1), n_gpus=1, first_gpu=n_dev)    # opt-in: wraps
+    assert wrapped.device_index == 0
 
 
 def test_grouped_allgather_entry_points():
