@@ -30,6 +30,9 @@ def _stress():
     ('cdna', 64, 64, 4, 100, 2, 'fp32', 2),
     ('cdna', 64, 64, 4, 120, 2, 'bf16x6', 1),
     ('savp', 64, 64, 3, 150, 2, 'fp32', 1),
+    ('cdna', 64, 64, 4, 125, 2, 'fp32', 1),         # not a multiple of 8: the tile-by-tile tail of the XCD dealing
+    ('cdna', 64, 64, 6, 25, 1, 'fp32', 1),
+    ('cdna', 48, 64, 4, 61, 2, 'fp32', 2),
 ])
 def test_repeated_planning_calls_are_bit_identical(arch, H, W, T, M, nd, prec, ncam):
     assert _stress().run(arch, H, W, T, M, nd, prec, seed=11, reps=8, ncam=ncam) == 0
