@@ -204,11 +204,15 @@ int vf_device_status(vf_handle *h, int32_t *status);
  * are bit-identical with one queue (enable = 0), which is the plain phase order. */
 int vf_set_xcd_queues(vf_handle *h, int32_t enable);
 
-/* Fused decoder top of the persistent rollout (default on; no reference counterpart).  The last transposed convolution and the
+/* Fused items of the persistent rollout (default on; no reference counterpart).  (1) The last transposed convolution and the
  * compositing of the next frame become ONE item per tile: the tile stays in registers / LDS, its LayerNorm partial
  * is published, the item waits for the sample's other tiles and composes its pixels itself - the full-resolution
  * decoder tensor is never written to memory (visual_foresight_amd/csrc/vf_fused_top.h).  Same arithmetic on the same
- * values: results are bit-identical to the two-phase schedule and to the per-layer launches. */
+ * values: results are bit-identical to the two-phase schedule and to the per-layer launches.  (2) The two convolutions of
+ * the 8 x 8 bottleneck (3x3 / 2, then 1x1 with the tiled action / state entering as a per-sample bias) become one item per
+ * row tile: the first conv's tile holds whole images and all 64 channels, goes through LDS instead of memory and feeds the
+ * second GEMM in its stand-alone K order (conv_pair_epilogue, visual_foresight_amd/csrc/vf_conv_mfma.h) - one dependency
+ * hop per sample-step less, bit-identical as well.  enable = 0 switches both off (A/B measurements, tests). */
 int vf_set_fuse_top(vf_handle *h, int32_t enable);
 
 /* Context de-duplication (default on).  While a step's inputs are context, part of the network

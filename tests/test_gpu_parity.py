@@ -136,6 +136,35 @@ def test_tile_plans_are_invisible_in_the_results():
             np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize('H,W,T,M,nd', [(64, 64, 3, 37, 2), (48, 64, 3, 9, 1), (32, 32, 3, 21, 1), (64, 64, 2, 160, 1)])
+def test_fused_items_are_invisible_in_the_results(H, W, T, M, nd):
+    """The two fusions of the persistent schedule - decoder top + compositing, and the two convolutions of the 8 x 8
+    bottleneck as one item (vf_set_fuse_top; the second since round 4: several images per row tile, 16- and 32-channel
+    chunks of the first conv) - against the same schedule without them and against the oracle: same bits, cached-context
+    rollouts included."""
+    pred, weights = _predictor(H, W, T, nd, bs=M)
+    rs = np.random.RandomState(H + M)
+    ctx = _context(H, W, nd, rs)
+    actions = rs.normal(0, 0.1, (M, T, 4))
+    goal = rs.randint(0, min(H, W), (1, nd, 2))
+    outs = []
+    for fuse in (1, 0, 1):
+        pred.set_fuse_top(fuse)
+        for rep in range(2):
+            s, pt = pred.score(ctx, {'actions': actions}, goal)
+            assert pred.device_status() == 0
+        got = pred(ctx, {'actions': actions[:24]})
+        outs.append((s, pt, got['predicted_frames'], got['predicted_pixel_distributions'], got['predicted_states']))
+        pred._ctx_key = None                    # upload the context again: the next variant computes the shared units itself
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)
+    idx = [0, M // 2, M - 1]
+    f, d, st = _oracle(weights, ctx, actions[idx])
+    want, _ = pixel_cost.eval_pixel_cost(d, goal, 10.)
+    np.testing.assert_allclose(outs[0][0][idx], want, rtol=1e-5)
+
+
 def test_full_size_properties():
     """BASELINE config-2 size (200 x 13 x 64x64): size-independent properties."""
     H = W = 64

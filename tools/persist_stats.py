@@ -27,7 +27,7 @@ for _ in range(2):
 N = 500
 types, items, wr = (ctypes.c_int32 * N)(), (ctypes.c_int32 * N)(), (ctypes.c_uint64 * (2 * N))()
 n = lib.vf_debug_phase_stats(pred._handle, N, types, items, wr)
-names = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED']
+names = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED', 'CONV_PAIR']
 tick = 1e-8     # wall_clock64: 100 MHz
 agg = {}
 print('phase type items  wait_ms(sum over items)  run_ms(sum)  run_us/item')

@@ -24,7 +24,7 @@ step0 = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 WGS, MAXE, TICK_US = 512, 8192, 0.01
 TR_TICKET, TR_DONE, TR_PHASE, TR_RUN = 1, 3, 21, 32
-NAMES = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED']
+NAMES = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED', 'CONV_PAIR']
 
 pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2)).restore()
 rs = np.random.RandomState(0)

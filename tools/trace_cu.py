@@ -28,7 +28,7 @@ TICK_US = 0.01
 TR_TICKET, TR_DONE, TR_STAGE, TR_KLOOP, TR_LATE, TR_LATE_END, TR_EPI, TR_MFMAS, TR_HWID, TR_RUN = 1, 3, 10, 11, 12, 13, 14, 15, 20, 32
 TR_ST_LOADED, TR_ST_WRITTEN = 16, 17
 PH_LSTM = 0
-PH_NAMES = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED']
+PH_NAMES = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED', 'CONV_PAIR']
 
 pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2, precision=prec)).restore()
 rs = np.random.RandomState(0)

@@ -95,9 +95,12 @@ enum Epilogue {
     EPI_CONVT_RELU = 3,       // depth-to-space, relu(acc + bias)
     EPI_CONVT_RAW_STATS = 4,  // depth-to-space, acc + bias, + LayerNorm partial sums
     EPI_PARTIAL = 5,          // raw accumulators of one K split
-    EPI_CONVT_FUSED = 6       // top transposed conv whose tile is composed into the next frame right away
+    EPI_CONVT_FUSED = 6,      // top transposed conv whose tile is composed into the next frame right away
                               // (vf_fused_top.h); 6 + 2 * (designated pixels - 1) + (arch 1 first-frame layer)
+    EPI_CONV_PAIR = 20        // a conv whose whole-image tiles feed a 1x1 conv in the same item (conv_pair_epilogue: enc2 ->
+                              // enc3, the 8 x 8 bottleneck; G = 2: both 32-channel groups of the first conv in one workgroup)
 };
+__host__ __device__ constexpr bool is_top_fused(int epi) { return epi >= EPI_CONVT_FUSED && epi < EPI_CONV_PAIR; }
 __host__ __device__ constexpr int fused_epi(int nd, bool first) { return EPI_CONVT_FUSED + 2 * (nd - 1) + (first ? 1 : 0); }
 
 struct ConvSeg {
@@ -144,6 +147,9 @@ struct ConvParams {
     // EPI_CONVT_FUSED only (vf_fused_top.h): the compositing parameters of the same step (device address inside the
     // schedule), the per-sample "LayerNorm partials published" counters, the launch's failure word, view, pixels
     const void *fuse_comp;
+    // EPI_CONV_PAIR only: the parameters of the 1x1 conv that consumes this conv's tile inside the same item (device
+    // address inside the schedule)
+    const void *fuse_next;
     int *fuse_ready;
     const int *fuse_status;
     int fuse_view, fuse_nd;
@@ -708,6 +714,96 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
     }
 }
 
+// Epilogue of conv_tile<2, EPI_CONV_PAIR, 1>: conv -> relu -> 1x1 conv (+ per-sample bias) -> relu in ONE item.
+// The first conv's tiles hold whole images (the 8 x 8 bottleneck: enc2, 3x3 / 2) and its two 32-channel groups are
+// the two "gates" of this workgroup (same packed weights, same K order per output as the two items of the stand-alone
+// layer), so the tile in the accumulators is the COMPLETE input of the 1x1 conv that follows (enc3): it goes to LDS in
+// the layout that conv's staging would have produced - [32-channel chunk][GEMM row][KC + 4], the relu'd fp32 values
+// the stand-alone layer stores and reloads - and the second GEMM runs its K loop in the stand-alone order (chunk ->
+// k8 -> j) on the same operands: the same bits, one item, one dependency hop and one round trip through memory less
+// per sample-step.  The geometry of both layers is the same row grid (checked on the host: NI, RPI, tile = image).
+template <class PT>
+__device__ __forceinline__ void conv_pair_epilogue(const PT &p, f32x16 (&acc)[1][2], const int bx, float *smem) {
+    typedef const __attribute__((address_space(4))) ConvParams QT;
+    const unsigned long long qa = reinterpret_cast<unsigned long long>(p.fuse_next);
+    const unsigned qlo = __builtin_amdgcn_readfirstlane((unsigned)qa);
+    const unsigned qhi = __builtin_amdgcn_readfirstlane((unsigned)(qa >> 32));
+    QT &q = *(QT *)(((unsigned long long)qhi << 32) | qlo);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, kh = lane >> 5;
+    constexpr int KCP = 36;                 // 32-channel chunks of the second conv, padded like every operand tile
+    const int bimg0 = bx * p.NI;            // (whole images per tile: tilesY * tilesX == 1)
+    float *T = smem;                        // [2 chunks][128 rows][KCP] over the dead operand tile of the first conv
+
+    // the second conv's weights: 2 chunks x 4 k8 steps x 2 column groups, requested before anything else
+    const int Ntot = q.ncg * 32;            // (= 64: the stand-alone layer runs two channel-group items on these columns)
+    const float *wl = q.Wp + ((long long)kh * Ntot + n) * 4;
+    const long long wstep = (long long)2 * Ntot * 4;
+    f32x4 wb[2][4][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                wb[c][k8][g] = *reinterpret_cast<const f32x4 *>(wl + (long long)(c * 4 + k8) * wstep + g * 128);
+
+    // ---- 1. relu(acc + bias) -> T (exactly what conv_epilogue<1, EPI_BIAS_RELU> stores for the stand-alone layer)
+    __syncthreads();                        // every wave is done reading the operand tile
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float bias = p.bias[g * 32 + n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            T[(g * 128 + row) * KCP + n] = fmaxf(acc[0][g][r] + bias, 0.f);
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. the 1x1 conv: rows = the same GEMM rows, K = 64 input channels in two chunks, columns = 2 x 32
+    f32x16 acc2[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[g][r] = 0.f;
+    const f32x4 *T4 = reinterpret_cast<const f32x4 *>(T);
+    const int arow = wave * 32 + n;         // this lane's A row; channels 8 k8 + 4 kh .. + 3 of the chunk
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+            const f32x4 a = T4[((c * 128 + arow) * KCP + k8 * 8 + kh * 4) >> 2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    acc2[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wb[c][k8][g][j], acc2[g], 0, 0, 0);
+        }
+
+    // ---- 3. bias + per-sample bias + relu -> the second conv's output (conv_epilogue<1, EPI_BIAS_RELU> of that layer)
+    const int px_per_img = q.TH * q.TW;
+    const long long out_elems = (long long)q.Hout * q.Wout * q.Cout;
+    const TileDiv div_rpi(q.RPI), div_tw(q.TW);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int ch = g * 32 + n;
+        const float bias = q.bias[g * 32 + n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int img = div_rpi.div(row), rem = row - img * q.RPI;
+            const int y = div_tw.div(rem), x = rem - y * q.TW;
+            const int b = bimg0 + img;
+            if (!(img < q.NI && rem < px_per_img && b < q.B && y < q.Hout && x < q.Wout && ch < q.Cout)) continue;
+            float v = acc2[g][r] + bias;
+            if (q.sbias) v += q.sbias[(long long)b * q.sbias_ld + ch];
+            v = fmaxf(v, 0.f);
+            (q.out + (long long)b * out_elems)[(unsigned)((y * q.Wout + x) * q.Cout + ch)] = v;
+        }
+    }
+}
+
 // One workgroup tile.  (bx, by, bz) = (row tile, channel group, K split); smem = the workgroup's
 // dynamic LDS (conv_lds_bytes).  Called by the per-layer kernel below and, item by item, by the
 // persistent rollout kernel (vf_persistent.h).
@@ -786,7 +882,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     else if constexpr (EPI == EPI_BIAS_RELU) ts_key = p.KH == 1 ? 17 : (p.seg[0].C == 32 ? 18 : 19);
     else if constexpr (EPI == EPI_CONVT_RELU) ts_key = p.nseg == 1 ? 20 : 21;
     else if constexpr (EPI == EPI_PARTIAL) ts_key = 22;
-    else if constexpr (EPI >= EPI_CONVT_FUSED) ts_key = 23;
+    else if constexpr (is_top_fused(EPI)) ts_key = 23;
     else if constexpr (EPI == EPI_CONVT_RAW_STATS) ts_key = 24;
     // ---- LayerNorm statistics of the producing layers (this workgroup's samples only); an early-started conv-LSTM
     // item reads them only once the producer of its layer input is known to be done (chunk loop below)
@@ -903,7 +999,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     // 5 for the 5x5 layers with 8- / 16-channel chunks; D divides the steps of a chunk, so slots are static) that is
     // refilled D steps ahead - across chunk boundaries: the weights of the next chunk do not depend on its staging.
     constexpr bool kGRing = EPI != EPI_LSTM;
-    constexpr bool kConvT = (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS || EPI >= EPI_CONVT_FUSED);
+    constexpr bool kConvT = (EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS || is_top_fused(EPI));
     [[maybe_unused]] f32x4 gring[kGRing ? (G == 1 ? 5 : 4) : 1][G];
     [[maybe_unused]] const int nit_g = ntaps * K8;
     [[maybe_unused]] const int ring_d = (nit_g & 3) == 0 ? 4 : ((G == 1 && nit_g % 5 == 0) ? 5 : 0);
@@ -932,6 +1028,9 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
             } else if (G == 1 && ring_d == 5) {
 #pragma unroll
                 for (int d = 0; d < 5; ++d) VF_GLOAD(d, ch_begin, d)
+            } else if (G == 2) {            // (EPI_CONV_PAIR on 16-channel chunks: 18 steps per chunk, rings of 2)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) VF_GLOAD(d, ch_begin, d)
             }
         }
     }
@@ -1384,6 +1483,9 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
             if constexpr (G == 1) {
                 if (ring_d == 4) kloop(std::integral_constant<int, 4>{});
                 else kloop(std::integral_constant<int, 5>{});
+            } else if constexpr (G == 2) {
+                if (ring_d == 4) kloop(std::integral_constant<int, 4>{});
+                else kloop(std::integral_constant<int, 2>{});       // an even number of steps per chunk (host: pairable)
             } else {
                 kloop(std::integral_constant<int, 4>{});
             }
@@ -1456,8 +1558,9 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     // (xch = the double-buffered B area: 32 KiB at 32-channel chunks, disjoint from lnTab / red)
     if constexpr (GSPLIT) lstm_gsplit_epilogue<MR>(p, acc, bx, by, smem);
     else if constexpr (SPLIT) lstm_split_epilogue<RB>(p, acc, bx, by, red, reinterpret_cast<float *>(bsm));
-    else if constexpr (EPI >= EPI_CONVT_FUSED)
+    else if constexpr (is_top_fused(EPI))
         convt_fused_epilogue<(EPI - EPI_CONVT_FUSED) / 2 + 1, ((EPI - EPI_CONVT_FUSED) & 1) != 0>(p, acc, bx, red, smem);
+    else if constexpr (EPI == EPI_CONV_PAIR) conv_pair_epilogue(p, acc, bx, smem);
     else conv_epilogue<G, EPI, MREP>(p, acc, bx, by, bz, red);
 #ifdef VF_TILE_STATS
     {

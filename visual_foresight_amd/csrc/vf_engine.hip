@@ -482,6 +482,7 @@ struct vf_handle {
     int xcd_queues = kQueues;           // ticket queues of the persistent launch (vf_set_xcd_queues): kQueues or 1
     bool early_start = true;            // conv-LSTM items start on h(s-1) alone and wait for x(s) mid-item (ConvParams::late_cnt)
     bool fuse_top = true;               // vf_set_fuse_top: top transposed conv + compositing as one item (vf_fused_top.h)
+    bool fuse_pair = true;              // ... and enc2 + enc3 as one item (conv_pair_epilogue); follows vf_set_fuse_top
     int *d_status = nullptr;            // sticky failure word of the persistent kernel
     unsigned long long *d_stats = nullptr;  // per-phase wait/run ticks (vf_set_phase_stats)
     bool phase_stats = false;
@@ -1200,6 +1201,10 @@ struct LaunchSink {
     }
     int lstm(const ConvLayer &l, const ConvParams &p, int /*u_prev*/, int /*u_x*/) { return conv(PH_LSTM, l, p, {}); }
     int conv_late(int type, const ConvLayer &l, const ConvParams &p, int /*u_early*/, int /*u_late*/) { return conv(type, l, p, {}); }
+    static bool pair_capable() { return false; }    // one launch per layer: enc2 and enc3 stay two kernels
+    int conv_pair(const ConvLayer &, const ConvParams &, const ConvLayer &, const ConvParams &, std::initializer_list<int>) {
+        return VF_ERR_INVALID;
+    }
     int sa(const SaParams &p, std::initializer_list<int>) {
         hipLaunchKernelGGL(sa_kernel, dim3(p.B), dim3(64), 0, st, p);
         return VF_OK;
@@ -1299,6 +1304,31 @@ struct ScheduleSink {
         memset(&P, 0, sizeof(P));
         P.type = PH_SA; P.sa = p; P.B = p.B;
         return add(P, (p.B + kSaPerItem - 1) / kSaPerItem, p.B, deps);
+    }
+    // a conv whose tiles hold whole images + the 1x1 conv that consumes it, as one item per row tile (conv_pair_epilogue):
+    // the first conv's two channel groups become the two "gates" of the workgroup (ncg 1, G 2: the same packed weights)
+    static bool pair_capable() { return true; }
+    static bool pairable(const ConvLayer &a, const ConvLayer &b) {
+        return a.mode == PACK_PLAIN && b.mode == PACK_PLAIN && a.nseg == 1 && b.nseg == 1 && a.ncg == 2 && b.ncg == 2 &&
+               a.Cout == 64 && b.segC[0] == 64 && b.Cout <= 64 && b.KH == 1 && b.KW == 1 && b.stride == 1 && b.pad == 0 &&
+               b.KC == 32 && a.tilesY * a.tilesX == 1 && b.tilesY * b.tilesX == 1 && a.NI == b.NI && a.RPI == b.RPI &&
+               a.TH == b.TH && a.TW == b.TW && a.Hout == b.Hout && a.Wout == b.Wout && a.nsplit == 1 && b.nsplit == 1 &&
+               (a.KH * a.KW * (a.KC / 8)) % 2 == 0 &&     // the G = 2 K loop of conv_tile runs whole rings of 4 or 2 steps
+               a.lds_bytes >= (size_t)2 * 128 * 36 * 4;
+    }
+    int conv_pair(const ConvLayer &a, const ConvParams &pa, const ConvLayer &b, const ConvParams &pb,
+                  std::initializer_list<int> deps) {
+        PhaseDesc P;
+        memset(&P, 0, sizeof(P));
+        P.type = PH_CONV_PAIR; P.conv = pa; P.conv2 = pb; P.B = pa.B;
+        P.conv.ncg = 1;         // both channel groups in this item
+        P.NI = a.NI; P.tiles_per_img = 1;
+        P.gx = (pa.B + a.NI - 1) / a.NI; P.gy = 1;
+        P.mrep = 1;
+        max_lds = std::max(max_lds, a.lds_bytes);
+        const double rows = (double)pa.B * a.Hout * a.Wout;
+        flops += 2.0 * rows * a.KH * a.KW * a.segC[0] * a.Cout + 2.0 * rows * b.segC[0] * b.Cout;
+        return add(P, P.gx, pa.B, deps);
     }
     int fin(const FinParams &p, std::initializer_list<int> deps) {
         PhaseDesc P;
@@ -1518,14 +1548,22 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         VF_EMIT_SH(u_l4, lstm_shared(3, s), sink.lstm(lstm_plan(3, lstm_shared(3, s) ? 1 : B), lstm_params(3, h_normed(2)), u_prev[3], u_l3))
 
         const ConvLayer &enc2_l = light_plan(h->enc2, h->enc2_one, BE);
+        const ConvLayer &enc3_l = light_plan(h->enc3, h->enc3_one, BD);
         p = params(enc2_l, BE, h_normed(3), nullptr);
         p.out = E.enc2_o;
-        VF_EMIT_SH(u_enc2, enc_sh, sink.conv(PH_CONV_RELU, enc2_l, p, {u_l4}))
-
-        const ConvLayer &enc3_l = light_plan(h->enc3, h->enc3_one, BD);
-        p = params(enc3_l, BD, plain(E.enc2_o, bs(enc_sh, (long long)H8 * W8 * L[3])), nullptr);
-        p.out = D.enc3_o; p.sbias = D.sbias; p.sbias_ld = L[3];
-        VF_EMIT_SH(u_enc3, all_sh, sink.conv(PH_CONV_RELU, enc3_l, p, {u_enc2, u_sa}))
+        ConvParams p3 = params(enc3_l, BD, plain(E.enc2_o, bs(enc_sh, (long long)H8 * W8 * L[3])), nullptr);
+        p3.out = D.enc3_o; p3.sbias = D.sbias; p3.sbias_ld = L[3];
+        int u_enc3 = -1;
+        // enc2 + enc3 as ONE item per row tile where both run on the same samples (the persistent schedule, from the first
+        // step without shared encoder units on): one dependency hop and one memory round trip less on every sample's chain
+        if (Sink::pair_capable() && h->fuse_pair && enc_sh == all_sh && BE == BD && ScheduleSink::pairable(enc2_l, enc3_l)) {
+            VF_EMIT_SH(u_pair, enc_sh, sink.conv_pair(enc2_l, p, enc3_l, p3, {u_l4, u_sa}))
+            u_enc3 = u_pair;
+        } else {
+            VF_EMIT_SH(u_enc2, enc_sh, sink.conv(PH_CONV_RELU, enc2_l, p, {u_l4}))
+            VF_EMIT_SH(u_enc3_, all_sh, sink.conv(PH_CONV_RELU, enc3_l, p3, {u_enc2, u_sa}))
+            u_enc3 = u_enc3_;
+        }
 
         VF_EMIT_SH(u_l5, lstm_shared(4, s), sink.lstm(lstm_plan(4, lstm_shared(4, s) ? 1 : B),
                                 lstm_params(4, plain(D.enc3_o, bs(all_sh, (long long)H8 * W8 * L[3]))), u_prev[4], u_enc3))
@@ -1754,7 +1792,14 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
         if (P.cnt_base < 0 || P.cnt_base + ncnt > bs.counters) return fail(VF_ERR_INVALID, "counter out of range");
         // every pointer a tile dereferences must lie inside an allocation of this handle
         bool ok = true;
-        if (P.type <= PH_FC_PARTIAL || P.type == PH_TOP_FUSED) {
+        if (P.type == PH_CONV_PAIR) {      // the 1x1 conv behind the first one: weights, biases, output, per-sample bias
+            const ConvParams &c2 = P.conv2;
+            ok = ok && P.conv.ncg == 1 && c2.ncg == 2 && c2.KC == 32 && c2.nseg == 1 && c2.seg[0].nchunk == 2;
+            ok = ok && in_allocs(h, c2.Wp, (size_t)2 * 4 * 2 * 64 * 4 * 4) && in_allocs(h, c2.bias, 64 * 4);
+            ok = ok && in_allocs(h, c2.out, (size_t)P.B * c2.Hout * c2.Wout * c2.Cout * 4);
+            ok = ok && in_allocs(h, c2.sbias, c2.sbias ? (size_t)((P.B - 1) * c2.sbias_ld + c2.Cout) * 4 : 0);
+        }
+        if (P.type <= PH_FC_PARTIAL || P.type == PH_TOP_FUSED || P.type == PH_CONV_PAIR) {
             const ConvParams &c = P.conv;
             for (int s = 0; s < c.nseg; ++s) {
                 const long long span = (long long)(P.B - 1) * c.seg[s].bstride + (long long)c.Hin * c.Win * c.seg[s].C;
@@ -1836,6 +1881,7 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
 extern "C" int vf_set_fuse_top(vf_handle *h, int32_t enable) {      // (the device build defines it further down)
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->fuse_top = enable != 0;
+    h->fuse_pair = enable != 0;
     return VF_OK;
 }
 #else   // ------------------------------------------------------------------ device execution
@@ -1906,6 +1952,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
                 P.conv.late_mode = P.late.mode;
                 P.conv.late_status = h->d_status;
             }
+            if (P.type == PH_CONV_PAIR) P.conv.fuse_next = &sc_host.d_phases[i].conv2;
             if (P.type != PH_TOP_FUSED) continue;
             P.conv.fuse_comp = &sc_host.d_phases[i].comp;
             P.conv.fuse_ready = h->d_sync + kSyncHead + P.aux_base;
@@ -2034,6 +2081,10 @@ int vf_set_persistent(vf_handle *h, int32_t enable) {
 int vf_set_fuse_top(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->fuse_top = enable != 0;
+    h->fuse_pair = enable != 0;
+#ifdef VF_DEBUG_KNOBS
+    if (const char *e = getenv("VF_FUSE_PAIR")) h->fuse_pair = h->fuse_pair && atoi(e) != 0;
+#endif
     return VF_OK;
 }
 

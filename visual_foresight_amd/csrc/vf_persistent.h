@@ -28,7 +28,8 @@ namespace vf {
 enum PhaseType {
     PH_LSTM = 0, PH_CONV_RELU, PH_CONV_RAW, PH_CONVT_RELU, PH_CONVT_RAW, PH_FC_PARTIAL,
     PH_SA, PH_CDNA_FIN, PH_COMPOSITE,
-    PH_TOP_FUSED            // top transposed conv + compositing in one item (vf_fused_top.h)
+    PH_TOP_FUSED,           // top transposed conv + compositing in one item (vf_fused_top.h)
+    PH_CONV_PAIR            // enc2 + enc3 in one item (conv_pair_epilogue, vf_conv_mfma.h)
 };
 
 constexpr int kMaxDeps = 3;
@@ -71,6 +72,7 @@ struct PhaseDesc {
     int has_late;           // two-input conv phases: the producer of segment 1 is awaited INSIDE the item, after the chunks
     PhaseDep late;          // of segment 0 (ConvParams::late_cnt, "early start"); dep[] then only holds segment 0's producer
     ConvParams conv;
+    ConvParams conv2;       // PH_CONV_PAIR: the 1x1 conv behind `conv` (conv.fuse_next points here, on the device)
     SaParams sa;
     FinParams fin;
     CompositeParams comp;
@@ -335,6 +337,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                 case PH_FC_PARTIAL:
                     conv_tile_call<1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx);
                     break;
+                case PH_CONV_PAIR: conv_tile_call<2, EPI_CONV_PAIR, 1>(&P.conv, bx, 0, 0); break;
                 case PH_TOP_FUSED:
                     if (P.comp.first_frame) conv_tile_call<4, fused_epi(ND, true), 1>(&P.conv, bx, 0, 0);
                     else conv_tile_call<4, fused_epi(ND, false), 1>(&P.conv, bx, 0, 0);
