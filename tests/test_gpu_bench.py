@@ -74,3 +74,13 @@ def test_two_rank_line_and_collective_evidence(single, launcher):
     assert all(v == '1' for v in c['host_threads_per_rank'].values())
     # the same candidates, the same bits: sharding cannot change the plan that is found
     assert r['best_score_last_plan'] == single['best_score_last_plan']
+
+
+def test_build_then_smoke_in_one_process():
+    """The driver's hooks back to back in ONE fresh process: build() loads libvf_hip.so before anything has imported
+    torch - the order in which the two HIP runtimes of the image (PyTorch's bundled one, /opt/rocm's) used to end up
+    both loaded, the second one blind ("no ROCm-capable device"); `_lib.load_library` imports torch first now."""
+    out = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); g.smoke()'], cwd=REPO,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert 'smoke: frame err' in out.stdout

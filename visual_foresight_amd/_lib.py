@@ -81,6 +81,11 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise VfError('%s is missing - run `python -c "import __graft_entry__ as g; g.build()"` '
                       '(there is no CPU fallback for the predictor)' % LIB_PATH)
+    # PyTorch (the buffer carrier) ships its own copy of the HIP runtime.  It must be the FIRST one this process loads:
+    # when libvf_hip.so pulls in /opt/rocm's libamdhip64 before torch has loaded its bundled one, the process ends up
+    # with two runtimes and the second reports "no ROCm-capable device" (seen with build() followed by smoke() in one
+    # process).  Importing torch here makes the order independent of what the caller did first.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     P = ctypes.c_void_p
     lib.vf_abi_version.restype = ctypes.c_int
