@@ -1556,7 +1556,15 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         int u_enc3 = -1;
         // enc2 + enc3 as ONE item per row tile where both run on the same samples (the persistent schedule, from the first
         // step without shared encoder units on): one dependency hop and one memory round trip less on every sample's chain
-        if (Sink::pair_capable() && h->fuse_pair && enc_sh == all_sh && BE == BD && ScheduleSink::pairable(enc2_l, enc3_l)) {
+        // (small batches: the one-image plan of enc3 does not match enc2's row tiles - enc2 keeps its regular plan because
+        //  its weights are packed for that plan's 16-channel chunks - so the pair takes enc3's regular plan)
+        const bool pair_ok = Sink::pair_capable() && h->fuse_pair && enc_sh == all_sh && BE == BD;
+        if (pair_ok && !ScheduleSink::pairable(enc2_l, enc3_l) && ScheduleSink::pairable(enc2_l, h->enc3)) {
+            p3 = params(h->enc3, BD, plain(E.enc2_o, bs(enc_sh, (long long)H8 * W8 * L[3])), nullptr);
+            p3.out = D.enc3_o; p3.sbias = D.sbias; p3.sbias_ld = L[3];
+            VF_EMIT_SH(u_pair, enc_sh, sink.conv_pair(enc2_l, p, h->enc3, p3, {u_l4, u_sa}))
+            u_enc3 = u_pair;
+        } else if (pair_ok && ScheduleSink::pairable(enc2_l, enc3_l)) {
             VF_EMIT_SH(u_pair, enc_sh, sink.conv_pair(enc2_l, p, enc3_l, p3, {u_l4, u_sa}))
             u_enc3 = u_pair;
         } else {
