@@ -1,0 +1,66 @@
+"""Seeded sweep over shapes the fixed parity cases do not visit: every launch strategy must give the same bits.
+
+The persistent schedule (per-XCD queues with the tile-by-tile tail, fused decoder top, the bottleneck pair, early start,
+context de-duplication, batch-dependent tile plans) only reorganises per-sample arithmetic, so for ANY geometry and batch
+it must reproduce the plain one-launch-per-layer path bit for bit - frames, distributions, states and scores - and the
+planes must stay probability distributions.  Image sizes are multiples of 8 between 32 and 72 (non-square included, so
+the 8 x 8-stage layers see 4 x 4 .. 9 x 8 images and every tile geometry branch of plan_geometry), batches from 1 to 203
+(below / at / above the XCD count and not multiples of it), 1-3 steps, 1-2 context frames, 1-2 designated pixels, 1-2 views."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+from oracle import pixel_cost                                                                   # noqa: E402
+from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights             # noqa: E402
+from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation              # noqa: E402
+
+
+def _cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        H, W = (int(8 * rs.randint(4, 10)), int(8 * rs.randint(4, 10)))
+        out.append(dict(H=H, W=W, T=int(rs.randint(1, 4)), M=int(rs.choice([1, 2, 7, 8, 9, 17, 25, 33, 50, 64, 90, 125, 203])),
+                        nd=int(rs.randint(1, 3)), nc=int(rs.randint(1, 3)), ncam=int(rs.choice([1, 1, 2])), seed=100 + i))
+    return out
+
+
+CASES = _cases(36, 2024)
+
+
+@pytest.mark.parametrize('case', CASES, ids=['%dx%d_M%d_T%d_nd%d_nc%d_v%d' % (c['H'], c['W'], c['M'], c['T'], c['nd'], c['nc'],
+                                                                             c['ncam']) for c in CASES])
+def test_every_launch_strategy_gives_the_same_bits(case):
+    H, W, T, M, nd, nc, ncam = (case[k] for k in ('H', 'W', 'T', 'M', 'nd', 'nc', 'ncam'))
+    hp = dict(designated_pixel_count=nd, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,
+              sequence_length=T + nc, n_context=nc, ncam=ncam)
+    pred = HipVPredEvaluation('', hp)
+    cfg = CdnaConfig(height=H, width=W, ndesig=nd, sequence_length=T + nc, n_context=nc)
+    weights = [CdnaWeights.random(cfg, seed=case['seed'] + v, bias_scale=0.05, ln_jitter=0.1) for v in range(ncam)]
+    pred.restore(weights if ncam > 1 else weights[0])
+    rs = np.random.RandomState(case['seed'])
+    desig = rs.randint(0, min(H, W), (ncam, nd, 2))
+    ctx = {'context_frames': rs.randint(0, 256, (nc + 1, ncam, H, W, 3)).astype(np.uint8),
+           'context_actions': rs.normal(0, 0.05, (nc, 4)), 'context_states': rs.normal(0, 0.1, (nc + 1, 5)),
+           'context_pixel_distributions': pixel_cost.one_hot_distrib(desig, nc, ncam, H, W, nd)}
+    actions = rs.normal(0, 0.1, (M, T, 4))
+    goal = rs.randint(0, min(H, W), (ncam, nd, 2))
+    outs = []
+    #            dedup persistent xcd fuse
+    for knobs in ((1, 1, 1, 1), (1, 0, 1, 1), (1, 1, 0, 1), (1, 1, 1, 0), (0, 1, 1, 1)):
+        pred.set_dedup(knobs[0]); pred.set_persistent(knobs[1]); pred.set_xcd_queues(knobs[2]); pred.set_fuse_top(knobs[3])
+        pred._ctx_key = None
+        for rep in range(2):            # the second call runs the cached-context schedule
+            s, pt = pred.score(ctx, {'actions': actions}, goal)
+        assert pred.device_status() == 0, knobs
+        got = pred(ctx, {'actions': actions[:min(M, 12)]})
+        outs.append((s, pt, got['predicted_frames'], got['predicted_pixel_distributions'], got['predicted_states']))
+    for knobs, other in zip('per-layer xcd-off unfused no-dedup'.split(), outs[1:]):
+        for name, a, b in zip(('scores', 'per_task', 'frames', 'distrib', 'states'), outs[0], other):
+            np.testing.assert_array_equal(a, b, err_msg='%s differs from the default schedule: %s' % (knobs, name))
+    d = outs[0][3]
+    np.testing.assert_allclose(d.sum(axis=(3, 4)), 1.0, atol=1e-5)
+    assert np.isfinite(outs[0][0]).all() and (outs[0][2] >= 0).all() and (outs[0][2] <= 1).all()
