@@ -64,3 +64,48 @@ def test_every_launch_strategy_gives_the_same_bits(case):
     d = outs[0][3]
     np.testing.assert_allclose(d.sum(axis=(3, 4)), 1.0, atol=1e-5)
     assert np.isfinite(outs[0][0]).all() and (outs[0][2] >= 0).all() and (outs[0][2] <= 1).all()
+
+
+def _oracle_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    return [dict(H=int(8 * rs.randint(4, 10)), W=int(8 * rs.randint(4, 10)), T=int(rs.randint(1, 4)), M=int(rs.randint(1, 5)),
+                 nd=int(rs.randint(1, 4)), nc=int(rs.randint(1, 3)), adim=int(rs.choice([3, 4, 5])), sdim=int(rs.choice([3, 5])),
+                 seed=500 + i) for i in range(n)]
+
+
+ORACLE_CASES = _oracle_cases(10, 77)
+
+
+@pytest.mark.parametrize('case', ORACLE_CASES, ids=['%dx%d_M%d_T%d_nd%d_nc%d_a%d_s%d' % (
+    c['H'], c['W'], c['M'], c['T'], c['nd'], c['nc'], c['adim'], c['sdim']) for c in ORACLE_CASES])
+def test_seeded_shapes_match_the_oracle(case):
+    """The tolerances of test_gpu_parity.py (frames 1e-5, distributions 2e-5 x plane max, states 1e-6, scores 1e-5) on ten
+    more seeded geometries, action / state dimensions and context lengths."""
+    from oracle.cdna_predictor import OracleCdna
+    H, W, T, M, nd, nc, adim, sdim = (case[k] for k in ('H', 'W', 'T', 'M', 'nd', 'nc', 'adim', 'sdim'))
+    hp = dict(designated_pixel_count=nd, run_batch_size=M, adim=adim, sdim=sdim, image_height=H, image_width=W,
+              sequence_length=T + nc, n_context=nc)
+    pred = HipVPredEvaluation('', hp)
+    cfg = CdnaConfig(height=H, width=W, adim=adim, sdim=sdim, ndesig=nd, sequence_length=T + nc, n_context=nc)
+    weights = CdnaWeights.random(cfg, seed=case['seed'], bias_scale=0.05, ln_jitter=0.1)
+    pred.restore(weights)
+    rs = np.random.RandomState(case['seed'])
+    desig = rs.randint(0, min(H, W), (1, nd, 2))
+    ctx = {'context_frames': rs.randint(0, 256, (nc + 2, 1, H, W, 3)).astype(np.uint8),
+           'context_actions': rs.normal(0, 0.05, (nc + 1, adim)), 'context_states': rs.normal(0, 0.1, (nc + 2, sdim)),
+           'context_pixel_distributions': pixel_cost.one_hot_distrib(desig, nc, 1, H, W, nd)}
+    actions = rs.normal(0, 0.1, (M, T, adim))
+    goal = rs.randint(0, min(H, W), (1, nd, 2))
+    got = pred(ctx, {'actions': actions})
+    scores, per_task = pred.score(ctx, {'actions': actions}, goal, finalweight=10.)
+    oracle = OracleCdna(weights, torch.float32)
+    assert oracle.cfg.n_context == nc
+    f, d, s = oracle.rollout(ctx['context_frames'], ctx['context_actions'], ctx['context_pixel_distributions'],
+                             ctx['context_states'], actions)
+    assert np.abs(got['predicted_frames'] - f).max() <= 1e-5
+    plane_max = d.max(axis=(3, 4), keepdims=True)
+    assert np.all(np.abs(got['predicted_pixel_distributions'] - d) <= 2e-5 * plane_max)
+    assert np.abs(got['predicted_states'] - s).max() <= 1e-6
+    want, want_pt = pixel_cost.eval_pixel_cost(d, goal, 10.)
+    np.testing.assert_allclose(scores, want, rtol=1e-5)
+    np.testing.assert_allclose(per_task, want_pt, rtol=1e-5)
