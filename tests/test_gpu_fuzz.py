@@ -109,3 +109,48 @@ def test_seeded_shapes_match_the_oracle(case):
     want, want_pt = pixel_cost.eval_pixel_cost(d, goal, 10.)
     np.testing.assert_allclose(scores, want, rtol=1e-5)
     np.testing.assert_allclose(per_task, want_pt, rtol=1e-5)
+
+
+def _savp_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    return [dict(H=int(16 * rs.randint(2, 9)), W=int(16 * rs.randint(2, 9)), T=int(rs.randint(1, 4)),
+                 M=int(rs.choice([1, 3, 8, 13, 25, 40, 70])), nd=int(rs.randint(1, 3)), seed=900 + i) for i in range(n)]
+
+
+SAVP_CASES = _savp_cases(10, 5)
+
+
+@pytest.mark.parametrize('case', SAVP_CASES, ids=['savp_%dx%d_M%d_T%d_nd%d' % (c['H'], c['W'], c['M'], c['T'], c['nd'])
+                                                  for c in SAVP_CASES])
+def test_every_launch_strategy_gives_the_same_bits_savp(case):
+    """The same sweep for the SAVP-class generator (arch 1: four scales, first-frame compositing, multiples of 16)."""
+    from visual_foresight_amd.video_prediction.savp_arch import SavpConfig, CdnaWeights as SavpWeights
+    H, W, T, M, nd = (case[k] for k in ('H', 'W', 'T', 'M', 'nd'))
+    adim = 6
+    hp = dict(designated_pixel_count=nd, run_batch_size=M, adim=adim, sdim=5, image_height=H, image_width=W,
+              sequence_length=T + 2, arch='savp')
+    pred = HipVPredEvaluation('', hp)
+    cfg = SavpConfig(height=H, width=W, adim=adim, ndesig=nd, sequence_length=T + 2)
+    pred.restore(SavpWeights.random(cfg, seed=case['seed'], bias_scale=0.05, ln_jitter=0.1))
+    rs = np.random.RandomState(case['seed'])
+    desig = rs.randint(0, min(H, W), (1, nd, 2))
+    d0 = pixel_cost.one_hot_distrib(desig, 2, 1, H, W, nd)
+    d0[1] = 0.5 * d0[1] + 0.5 / (H * W)
+    ctx = {'context_frames': rs.randint(0, 256, (3, 1, H, W, 3)).astype(np.uint8),
+           'context_actions': rs.normal(0, 0.05, (2, adim)), 'context_states': rs.normal(0, 0.1, (3, 5)),
+           'context_pixel_distributions': d0}
+    actions = rs.normal(0, 0.1, (M, T, adim))
+    goal = rs.randint(0, min(H, W), (1, nd, 2))
+    outs = []
+    for knobs in ((1, 1, 1, 1), (1, 0, 1, 1), (1, 1, 0, 1), (1, 1, 1, 0), (0, 1, 1, 1)):
+        pred.set_dedup(knobs[0]); pred.set_persistent(knobs[1]); pred.set_xcd_queues(knobs[2]); pred.set_fuse_top(knobs[3])
+        pred._ctx_key = None
+        for rep in range(2):
+            s, pt = pred.score(ctx, {'actions': actions}, goal)
+        assert pred.device_status() == 0, knobs
+        got = pred(ctx, {'actions': actions[:min(M, 8)]})
+        outs.append((s, pt, got['predicted_frames'], got['predicted_pixel_distributions'], got['predicted_states']))
+    for knobs, other in zip('per-layer xcd-off unfused no-dedup'.split(), outs[1:]):
+        for name, a, b in zip(('scores', 'per_task', 'frames', 'distrib', 'states'), outs[0], other):
+            np.testing.assert_array_equal(a, b, err_msg='%s differs from the default schedule: %s' % (knobs, name))
+    np.testing.assert_allclose(outs[0][3].sum(axis=(3, 4)), 1.0, atol=1e-5)
