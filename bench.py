@@ -77,6 +77,9 @@ def parse():
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c2')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='strong')
     ap.add_argument('--samples', type=int, default=0, help='override the workload\'s candidate count')
+    ap.add_argument('--ndesig', type=int, default=0, choices=(0, 1, 2, 3, 4),
+                    help='override the workload\'s designated pixels per view (reference hparam designated_pixel_count, '
+                         'pixel_cost_controller.py:57)')
     ap.add_argument('--precision', choices=('fp32', 'bf16x6'), default=os.environ.get('VF_PRECISION', 'fp32'),
                     help='primary precision mode (the other one is reported as alt_precision)')
     ap.add_argument('--no-alt', action='store_true', help='skip the alt_precision measurement')
@@ -85,20 +88,26 @@ def parse():
 
 
 # ----------------------------------------------------------------------------- self-launch
+class GpuProbeError(RuntimeError):
+    pass
+
+
 def count_gpus_in_child(timeout=600):
     """Number of GPUs this host exposes, asked of a throw-away child process: the launcher itself never imports
     torch nor makes any HIP call, so it provably cannot have initialised a GPU before it starts the ranks (and the
-    ranks are fresh children - nothing is ever re-exec'ed)."""
+    ranks are fresh children - nothing is ever re-exec'ed).  A probe that FAILS (time-out, import error, no answer)
+    raises with the child's stderr: it must never be mistaken for "this host has 0 GPUs" - that would quietly turn an
+    RCCL scaling run on a real multi-GPU node into a shared-GPU gloo dry run."""
     code = 'import torch; print("VF_GPU_COUNT", torch.cuda.device_count())'
     try:
-        out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                             text=True, timeout=timeout).stdout
-    except (OSError, subprocess.TimeoutExpired):
-        return 0
-    for line in out.splitlines():
+        proc = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, timeout=timeout)
+    except (OSError, subprocess.TimeoutExpired) as e:
+        raise GpuProbeError('GPU-count probe did not finish: %r' % (e,))
+    for line in proc.stdout.splitlines():
         if line.startswith('VF_GPU_COUNT'):
             return int(line.split()[1])
-    return 0
+    raise GpuProbeError('GPU-count probe gave no answer (exit code %d): %s' % (proc.returncode, proc.stderr[-2000:]))
 
 
 def rank_env(args, have, port):
@@ -108,8 +117,8 @@ def rank_env(args, have, port):
     for k in HOST_THREAD_CAPS:          # N ranks share the host cores: one math thread each (not left to threadpoolctl)
         env[k] = '1'
     if have < args.gpus:
-        # fewer GPUs than ranks (a 1-GPU box): the ranks share them and talk over gloo - a dry run of the
-        # sharding and the collective, not a scaling measurement; the line says so
+        # the probe POSITIVELY reported fewer GPUs than ranks (a 1-GPU box): the ranks share them and talk over
+        # gloo - a dry run of the sharding and the collective, not a scaling measurement; the line says so
         env['VF_BENCH_BACKEND'] = 'gloo'
     return env
 
@@ -119,7 +128,11 @@ def spawn_ranks(args):
     device count comes from a throw-away child)."""
     import socket
     assert 'torch' not in sys.modules, 'the launcher must stay GPU-free'
-    have = count_gpus_in_child()
+    try:
+        have = count_gpus_in_child()
+    except GpuProbeError as e:      # never fall back to a gloo dry run on a failed probe: abort, loudly
+        print('bench: %s' % e, file=sys.stderr)
+        return 3
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
@@ -184,7 +197,7 @@ def cpu_baseline():
     cores = physical_cores()
     # oneDNN convolutions over a few hundred small images stop scaling long before a 128-core host is full (and
     # get SLOWER beyond a few dozen threads): the full sample runs at the thread count that is fastest, the
-    # all-physical-cores figure BASELINE.md asks for is measured beside it on a quarter of the candidates
+    # all-physical-cores figure BASELINE.md asks for is measured beside it on the same full sample
     used = min(cores, 32)
     torch.set_num_threads(used)
     factory = lambda cfg: CdnaWeights.random(cfg, seed=0)
@@ -217,9 +230,10 @@ def cpu_baseline():
     if cores > used:
         torch.set_num_threads(cores)
         plan(12, 2, 1)
-        t_all = plan(50, 13, 1)
-        all_cores = {'threads': cores, 'value': 50 * 13 / t_all, 'unit': 'predicted frames/s',
-                     'sample': 'one CEM iteration with 50 of the 200 samples on all %d physical cores, %.1f s' % (cores, t_all)}
+        t_all = plan(200, 13, 1)        # BASELINE.md section 3 literally: N = all physical cores, the whole config
+        all_cores = {'threads': cores, 'value': 200 * 13 / t_all, 'unit': 'predicted frames/s',
+                     'cem_iters_per_sec': 1.0 / t_all,
+                     'sample': 'C2: one full CEM iteration with all 200 samples on all %d physical cores, %.1f s' % (cores, t_all)}
         torch.set_num_threads(used)
     return {'value': 200 * 13 / t_c2, 'unit': 'predicted frames/s', 'cores': used, 'kind': 'port',
             'physical_cores_of_host': cores,
@@ -301,6 +315,8 @@ class Bench(object):
          self.workload_name) = WORKLOADS[args.workload]
         if args.samples:
             M = args.samples
+        if args.ndesig and args.workload != 'c3':       # (c3's pixels are (start, goal) registrations of one task)
+            self.ndesig = args.ndesig
         self.H = self.W = size
         self.M = M * (self.world if args.scaling == 'weak' else 1)
         self.per_rank = -(-self.M // self.world)
@@ -397,14 +413,22 @@ class Bench(object):
             self.sync()
             t0 = time.perf_counter()
             marks = [t0]
+            decided = []                        # what every timed call decided: hashed AFTER the timed region
             for i in range(a.steps):
                 out = plan(1 + a.warmup + i)    # synchronous: returns after the scores are back on the host
                 marks.append(time.perf_counter())
+                decided.append(({k: v for k, v in out['plan_stat'].items()}, ctrl._best_indices, out['actions']))
             self.sync()
             elapsed = time.perf_counter() - t0
             kernel_ms, launches, flops, busy_ms = pred.get_profile()
             pred.set_profiling(False)
-            collective = self.collective_report(pred) if self.world > 1 else None
+            avg_launch_us = 1e3 * kernel_ms / max(launches, 1)
+            collective = self.collective_report(pred, avg_launch_us) if self.world > 1 else None
+            # G-invariance, proven by the record itself: every rank hashes the score vectors of every CEM iteration,
+            # the elite indices and the executed action of every timed call; the hashes are compared across ranks, and
+            # `scores_sha` is the same string at N = 1 and at any N under strong scaling (same candidates, same bits)
+            from visual_foresight_amd.video_prediction.sharding import plan_digest, gather_plan_digests
+            same, shas = gather_plan_digests([plan_digest(ps, bi, act) for ps, bi, act in decided])
         if self.world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == 'nccl' else 'cpu')
             self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
@@ -420,9 +444,10 @@ class Bench(object):
                     host_ms=1e3 * (elapsed - score_time[0]) / a.steps,
                     rollouts=(hi - lo) * max(self.draws, 1) * self.ncam * self.iters * a.steps,
                     elites=[int(i) for i in ctrl._best_indices],
+                    elites_identical_across_ranks=bool(same), scores_sha=shas[0], scores_sha_per_rank=shas,
                     best=float(np.min(out['plan_stat']['scores_itr%d' % (self.iters - 1)])))
 
-    def collective_report(self, pred):
+    def collective_report(self, pred, avg_launch_us=None):
         """What the process group actually was - backend, world size, every rank's device - and what the one
         all-gather of score rows per CEM iteration cost (HIP events around the collective on every rank; mean over the
         timed calls, then mean / max over ranks).  Evidence in a SCALE record that RCCL saw N ranks on N GPUs."""
@@ -433,7 +458,8 @@ class Bench(object):
         mine = {'rank': self.rank, 'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'device': self.dev_index,
                 'name': props.name, 'uuid': str(getattr(props, 'uuid', '')), 'pid': os.getpid(),
                 'allgather_calls': st['calls'], 'allgather_mean_ms': st['mean_ms'], 'allgather_max_ms': st['max_ms'],
-                'bytes_per_rank': st['bytes_per_rank']}
+                'bytes_per_rank': st['bytes_per_rank'],
+                'avg_launch_us': avg_launch_us}      # this rank's rollout kernel: a straggler GPU shows here
         ranks = [None] * self.world
         dist.all_gather_object(ranks, mine)
         means = [r['allgather_mean_ms'] for r in ranks if r['allgather_mean_ms'] is not None]
@@ -449,6 +475,9 @@ class Bench(object):
                                                      'the slowest rank to arrive)'},
                 'bytes_per_rank_per_allgather': ranks[0]['bytes_per_rank'],
                 'host_threads_per_rank': {k: os.environ.get(k) for k in HOST_THREAD_CAPS},
+                'avg_launch_us_min_max_over_ranks': [min(r['avg_launch_us'] for r in ranks),
+                                                     max(r['avg_launch_us'] for r in ranks)]
+                if all(r.get('avg_launch_us') is not None for r in ranks) else None,
                 'ranks': ranks}
 
     def survey_rate(self, m):
@@ -502,7 +531,8 @@ class Bench(object):
         if prof is None:
             return
         if (prof.get('workload') == self.args.workload
-                and prof.get('precision') == precision and self.world == 1 and not self.args.samples):
+                and prof.get('precision') == precision and self.world == 1 and not self.args.samples
+                and self.ndesig == WORKLOADS[self.args.workload][4]):
             roof['traffic'] = prof['hbm_bytes_per_launch']
             roof['traffic_source'] = 'profiles/%s (rocprofv3 PMC passes of this library, offline)' % name
             roof['traffic_vs_algorithmic'] = prof.get('ratio_to_algorithmic')
@@ -514,10 +544,13 @@ class Bench(object):
         """BASELINE.json's metric string for the configuration it is quoted on (c2 at its own size); any other
         workload or --samples override names what it actually counts, so a c3/c5 or shard line cannot be read as
         the headline (frames of every view and latent draw are counted)."""
-        if self.args.workload == 'c2' and not self.args.samples and self.args.scaling == 'strong':
+        if (self.args.workload == 'c2' and not self.args.samples and self.args.scaling == 'strong'
+                and self.ndesig == WORKLOADS['c2'][4]):
             return 'predicted frames/sec (whole node), 200-sample x 13-step x 64x64 CEM'
         extra = ''.join([' x %d views' % self.ncam if self.ncam > 1 else '',
                          ' x %d latent draws' % self.draws if self.draws else ''])
+        if self.ndesig != WORKLOADS[self.args.workload][4]:
+            extra += ', %d designated pixels per view' % self.ndesig
         return 'predicted frames/sec (whole node), workload %s: %d-sample x %d-step x %dx%d%s CEM' % (
             self.args.workload, self.M, self.T, self.H, self.W, extra)
 
@@ -554,6 +587,12 @@ class Bench(object):
             'collective': m['collective'],
             'host_ms_per_step_outside_predictor': m['host_ms'],
             'best_score_last_plan': m['best'],
+            # sha256 over (scores of every CEM iteration, elite indices, executed action) of every timed call: equal on
+            # every rank of this run (`elites_identical_across_ranks`) and, under strong scaling, equal to the N = 1
+            # line's string - the sharded job planned bit for bit what one GPU plans
+            'elites_identical_across_ranks': m['elites_identical_across_ranks'],
+            'scores_sha': m['scores_sha'],
+            'scores_sha_per_rank': m['scores_sha_per_rank'] if self.world > 1 else None,
         }
         self.attach_traffic(result['roofline'], primary)
 

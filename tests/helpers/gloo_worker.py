@@ -36,8 +36,12 @@ def run(rank, world, port, out_dir, num_samples, propagation):
         log.append({'action': np.array(out['actions']),
                     'plan_stat': {k: np.array(v) for k, v in out['plan_stat'].items()},
                     'best': None if ctrl._best_indices is None else np.array(ctrl._best_indices)})
+    # what bench.py prints at N > 1: the per-call digests compared across the ranks of THIS job
+    from visual_foresight_amd.video_prediction.sharding import plan_digest, gather_plan_digests
+    same, shas = gather_plan_digests([plan_digest(e['plan_stat'], e['best'], e['action']) for e in log])
     with open(os.path.join(out_dir, 'rank%d_of%d.pkl' % (rank, world)), 'wb') as f:
-        pickle.dump({'log': log, 'evaluated': list(fake.evaluated)}, f)
+        pickle.dump({'log': log, 'evaluated': list(fake.evaluated), 'identical_across_ranks': same,
+                     'scores_sha_per_rank': shas}, f)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -51,6 +51,45 @@ def test_launcher_env_caps_host_threads_and_never_needs_torch():
     assert 'import torch' not in src and 'torch.cuda' not in src
 
 
+def test_a_failed_gpu_probe_aborts_instead_of_becoming_a_gloo_dry_run(monkeypatch):
+    """A probe that times out or dies is NOT "0 GPUs": the launcher must stop (non-zero exit code, the child's stderr
+    in the message) rather than silently run an 8-rank scaling job as a shared-GPU gloo dry run."""
+    import subprocess
+    import types
+
+    def broken(*a, **kw):
+        return subprocess.CompletedProcess(a, 1, stdout='', stderr='ImportError: libamdhip64.so')
+    monkeypatch.setattr(bench.subprocess, 'run', broken)
+    try:
+        bench.count_gpus_in_child()
+        raise AssertionError('a probe without an answer must raise')
+    except bench.GpuProbeError as e:
+        assert 'libamdhip64' in str(e)
+    started = []
+    monkeypatch.setattr(bench.subprocess, 'Popen', lambda *a, **kw: started.append(a))
+    assert bench.spawn_ranks(types.SimpleNamespace(gpus=8)) == 3 and not started
+
+    def timeout(*a, **kw):
+        raise subprocess.TimeoutExpired(a, 1)
+    monkeypatch.setattr(bench.subprocess, 'run', timeout)
+    assert bench.spawn_ranks(types.SimpleNamespace(gpus=8)) == 3 and not started
+
+
+def test_plan_digests_are_order_and_content_sensitive():
+    """The `scores_sha` of a bench line: equal plans hash equal, one changed score / elite / action bit does not."""
+    import numpy as np
+    from visual_foresight_amd.video_prediction.sharding import plan_digest, run_digest, gather_plan_digests
+    ps = {'scores_itr0': np.arange(5.0), 'scores_itr1': np.arange(5.0) * 2, 'scores_itr10': np.ones(5)}
+    d = plan_digest(ps, [1, 2], np.zeros(4))
+    assert d == plan_digest(dict(reversed(list(ps.items()))), np.array([1, 2]), np.zeros(4))
+    assert d != plan_digest(ps, [2, 1], np.zeros(4))
+    assert d != plan_digest(ps, [1, 2], np.array([0, 0, 0, 1e-300]))
+    ps2 = dict(ps, scores_itr1=np.nextafter(ps['scores_itr1'], 9.0))
+    assert d != plan_digest(ps2, [1, 2], np.zeros(4))
+    assert run_digest([d, d]) != run_digest([d]) and len(run_digest([d])) == 16
+    assert gather_plan_digests([d]) == (True, [run_digest([d])])
+
+
 def test_traffic_is_quoted_only_from_a_profile_of_this_library():
     """`roofline.traffic` comes from the newest committed PMC profile whose source hash equals the running library's
     (the counters cannot be read in-process); any other profile, workload or precision leaves it null."""

@@ -54,6 +54,11 @@ def test_ranks_match_single_process(tmp_path, world, num_samples, propagation):
     for r, res in enumerate(ranks):
         assert set(res['evaluated']) == {shard_bounds(num_samples, r, world)}
     assert set(single['evaluated']) == {(0, num_samples)}
+    # the self-proving fields of a scaling record (bench.py): every rank's digest of every planning call agrees, and
+    # equals the single-process digest
+    for res in ranks:
+        assert res['identical_across_ranks'] is True
+        assert res['scores_sha_per_rank'] == single['scores_sha_per_rank'] * world
     for res in ranks:
         for a, b in zip(res['log'], single['log']):
             np.testing.assert_array_equal(a['action'], b['action'])

@@ -50,6 +50,8 @@ def _check_common(r, n):
 def test_single_rank_line(single):
     _check_common(single, 1)
     assert single['collective'] is None
+    assert single['elites_identical_across_ranks'] is True and len(single['scores_sha']) == 16
+    assert single['scores_sha_per_rank'] is None
 
 
 @pytest.mark.parametrize('launcher', ['self', 'torchrun'])
@@ -74,6 +76,13 @@ def test_two_rank_line_and_collective_evidence(single, launcher):
     assert all(v == '1' for v in c['host_threads_per_rank'].values())
     # the same candidates, the same bits: sharding cannot change the plan that is found
     assert r['best_score_last_plan'] == single['best_score_last_plan']
+    # ... and the record proves it by itself: every rank hashed every timed call's scores / elites / action
+    assert r['elites_identical_across_ranks'] is True
+    assert r['scores_sha_per_rank'] == [r['scores_sha']] * 2
+    assert r['scores_sha'] == single['scores_sha'], 'the 2-rank job planned something else than one GPU'
+    assert all(x['avg_launch_us'] > 0 for x in c['ranks'])
+    lo, hi = c['avg_launch_us_min_max_over_ranks']
+    assert 0 < lo <= hi
 
 
 def test_build_then_smoke_in_one_process():

@@ -4,8 +4,8 @@
   the ``s_waitcnt lgkmcnt(0)`` for that case, and a race of this kind only shows up as a handful of differing cost
   sums on the GPU box (round 3, ``profiles/r03_tile_plan_sweep.txt``);
 * the scheduler loop of the persistent rollout kernel keeps its explicit wait;
-* the production kernel carries no dead tile variants: no VGPR spills and <= 128 B of scratch for the 1- and
-  2-pixel instances (``tools/kernel_resources.sh`` prints the same metadata).
+* the production kernel carries no dead tile variants: no VGPR spills and <= 128 B of scratch for every instance
+  (1 to 4 designated pixels; ``tools/kernel_resources.sh`` prints the same metadata).
 """
 import os
 import re
@@ -52,9 +52,9 @@ def test_production_kernel_has_no_spilled_vgprs(assembly):
         nd = int(m.group(2))
         get = lambda k: int(re.search(r'\.%s:\s+(\d+)' % k, blk).group(1))
         seen += 1
-        if nd <= 2:
-            assert get('vgpr_spill_count') == 0, (nd, get('vgpr_spill_count'))
-            assert get('private_segment_fixed_size') <= 128, (nd, get('private_segment_fixed_size'))
-        else:       # 3 / 4 designated pixels: the fused decoder top holds more per-pixel state
-            assert get('private_segment_fixed_size') <= 256, (nd, get('private_segment_fixed_size'))
+        # every advertised designated-pixel count (1..4): no spilled VGPR, only the few bytes of call bookkeeping
+        # (round 4: the 3- / 4-pixel instances spilled 35 VGPRs in the fused decoder top)
+        assert 1 <= nd <= 4
+        assert get('vgpr_spill_count') == 0, (nd, get('vgpr_spill_count'))
+        assert get('private_segment_fixed_size') <= 128, (nd, get('private_segment_fixed_size'))
     assert seen == 4

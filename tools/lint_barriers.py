@@ -71,22 +71,43 @@ def lint(lines):
     return findings
 
 
+SCHED_MARKER = 'vf_sched_loop_head'
+
+
 def scheduler_barrier_is_guarded(lines):
     """The scheduler loop of every rollout_persistent_kernel instance must reach its loop-head barrier through the
-    explicit `s_waitcnt lgkmcnt(0)` of vf_persistent.h (not through whatever the compiler decides to emit): the first
-    `s_barrier` after the kernel's entry label has an `lgkmcnt(0)` wait within the few instructions in front of it."""
-    bad, func, seen = [], None, False
+    explicit `s_waitcnt lgkmcnt(0)` of vf_persistent.h (not through whatever the compiler decides to emit).  The inline
+    asm carries the marker comment `vf_sched_loop_head`: every instance must contain it exactly once, on an
+    `s_waitcnt lgkmcnt(0)`, inside a loop-header block, and the next instruction that is not another wait must be the
+    `s_barrier` - so the check cannot land on a prologue barrier or on a block the compiler moved.  -> names of the
+    instances that fail."""
+    bad = []
+    func, start = None, 0
+    spans = []
     for k, l in enumerate(lines):
-        m = re.match(r'^(_ZN2vf25rollout_persistent_kernel\w*):', l)
+        m = re.match(r'^(_Z\w+):', l)
         if m:
-            func, seen = m.group(1), False
-        elif re.match(r'^_Z\w+:', l):
-            func = None
-        if func and not seen and 's_barrier' in l:
-            seen = True
-            window = [x for x in lines[max(0, k - 6):k] if not x.strip().startswith(';')]
-            if not any('lgkmcnt(0)' in x for x in window):
-                bad.append(func)
+            if func:
+                spans.append((func, start, k))
+            func, start = m.group(1), k
+    if func:
+        spans.append((func, start, len(lines)))
+    for name, a, b in spans:
+        if not name.startswith('_ZN2vf25rollout_persistent_kernel'):
+            continue
+        marks = [k for k in range(a, b) if SCHED_MARKER in lines[k]]
+        ok = len(marks) == 1 and 's_waitcnt' in lines[marks[0]] and 'lgkmcnt(0)' in lines[marks[0]]
+        if ok:
+            k = marks[0]
+            # the block the wait sits in must be a loop header
+            hdr = next((j for j in range(k, a, -1) if re.match(r'^\.LBB\d+_\d+:', lines[j])), None)
+            ok = hdr is not None and any('Loop Header' in x for x in lines[hdr:hdr + 12])
+            nxt = [x.strip() for x in lines[k + 1:k + 12]
+                   if x.strip() and not x.strip().startswith(';') and not x.strip().startswith('.')]
+            nxt = [x for x in nxt if not x.startswith('s_waitcnt') and not x.startswith('s_nop')]
+            ok = ok and bool(nxt) and nxt[0].startswith('s_barrier')
+        if not ok:
+            bad.append(name)
     return bad
 
 

@@ -467,7 +467,7 @@ struct vf_handle {
         int B = -1, items = 0, counters = 0, phases = 0;
         bool dedup = true;
         int xcd_queues = 0, nq = 1, total_q[kQueues] = {0};
-        bool fuse_top = false;
+        int options = -1;               // sched_options() the schedule was built with (every toggle build_schedule reads)
         double flops = 0.0;
         size_t lds = 0;
         std::vector<int> types, nitems;
@@ -483,6 +483,7 @@ struct vf_handle {
     bool early_start = true;            // conv-LSTM items start on h(s-1) alone and wait for x(s) mid-item (ConvParams::late_cnt)
     bool fuse_top = true;               // vf_set_fuse_top: top transposed conv + compositing as one item (vf_fused_top.h)
     bool fuse_pair = true;              // ... and enc2 + enc3 as one item (conv_pair_epilogue); follows vf_set_fuse_top
+    bool pair_allowed = true;           // (-DVF_DEBUG_KNOBS: VF_FUSE_PAIR=0, read once in vf_create)
     int *d_status = nullptr;            // sticky failure word of the persistent kernel
     unsigned long long *d_stats = nullptr;  // per-phase wait/run ticks (vf_set_phase_stats)
     bool phase_stats = false;
@@ -799,6 +800,12 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     if (const char *e = getenv("VF_LSTM_MREP"))
         for (int k = 0; k < 7 && e[k]; ++k)         // per layer: h = 64 rows, 1 = 128, 2 = 256, anything else automatic
             h->mrep_override[k] = e[k] == '2' ? 2 : (e[k] == '1' ? 1 : (e[k] == 'h' ? 3 : (e[k] == 'q' ? 4 : 0)));
+#endif
+#ifdef VF_DEBUG_KNOBS
+    // A/B knob of debug builds, read ONCE per handle (not inside a setter the caller may never invoke)
+    static const bool knob_no_pair = getenv("VF_FUSE_PAIR") && atoi(getenv("VF_FUSE_PAIR")) == 0;
+    h->pair_allowed = !knob_no_pair;
+    h->fuse_pair = h->fuse_pair && h->pair_allowed;
 #endif
     if (h->savp) {
         init_layer(h->enc00, "enc00", PACK_PLAIN, H, W, Hc, Wc, 5, 5, 2, 1, 3, 0, kEnc00Ch, true);
@@ -1918,6 +1925,12 @@ static int run_steps(vf_handle *h, int view, const BatchView &v, const BatchView
     return emit_rollout(h, view, v, sh, B, goal_pix + (size_t)view * h->ND * 2, sink, skip_shared);
 }
 
+// every toggle emit_rollout / build_schedule read besides (B, dedup, xcd_queues): part of the schedule cache's key, so an
+// option changed between two rollouts can never meet a schedule built for the old value
+static int sched_options(const vf_handle *h) {
+    return (h->fuse_top ? 1 : 0) | (h->fuse_pair ? 2 : 0) | (h->early_start ? 4 : 0);
+}
+
 // Are the shared buffers of configuration `cfg` (launch mode and split) still valid?
 static bool shared_cache_hit(vf_handle *h, int cfg) {
     return h->dedup && h->cache_shared && h->shared_valid && h->shared_cfg == cfg;
@@ -1942,7 +1955,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     const bool skip_shared = shared_cache_hit(h, cfg);
     vf_handle::SchedCache &sc_host = h->sched[skip_shared ? 1 : 0];
     if (sc_host.B != B || sc_host.dedup != h->dedup || sc_host.xcd_queues != h->xcd_queues ||
-        sc_host.fuse_top != h->fuse_top) {
+        sc_host.options != sched_options(h)) {
         BuiltSchedule bs;
         if ((rc = build_schedule(h, B, skip_shared, bs))) return rc;
         // Upload without synchronising the caller's stream: the copy is stream-ordered behind the
@@ -1975,7 +1988,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         h->stage_used[slot] = true;
         sc_host.B = B; sc_host.dedup = h->dedup;
         sc_host.xcd_queues = h->xcd_queues;
-        sc_host.fuse_top = h->fuse_top;
+        sc_host.options = sched_options(h);
         sc_host.items = bs.items; sc_host.counters = bs.counters;
         sc_host.nq = bs.nq;
         for (int q = 0; q < kQueues; ++q) sc_host.total_q[q] = bs.total_q[q];
@@ -2089,10 +2102,7 @@ int vf_set_persistent(vf_handle *h, int32_t enable) {
 int vf_set_fuse_top(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->fuse_top = enable != 0;
-    h->fuse_pair = enable != 0;
-#ifdef VF_DEBUG_KNOBS
-    if (const char *e = getenv("VF_FUSE_PAIR")) h->fuse_pair = h->fuse_pair && atoi(e) != 0;
-#endif
+    h->fuse_pair = enable != 0 && h->pair_allowed;
     return VF_OK;
 }
 

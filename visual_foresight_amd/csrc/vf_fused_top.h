@@ -229,9 +229,14 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
     const int nbx = RW / kSumBlockW, nby = RH / kSumBlockH, nblk = nbx * nby;
     for (int pass = 0; pass * 4 < nblk; ++pass) {
         if (pass) __syncthreads();           // the previous pass has read s_enc
+        // (the LDS slots of the 64 accumulators do not depend on the pass; hoisted out of this loop they would stay in
+        // registers across composite_pixel, which has none to spare for ND > 2 - laundering the row base keeps the
+        // handful of index instructions inside the pass)
+        int row0 = wave * 32 + 4 * kh;
+        if constexpr (ND > 2) asm volatile("" : "+v"(row0));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
             const int yy = div_tw.div(row), xx = row - yy * p.TW;
             if (row >= p.TH * p.TW) continue;
 #pragma unroll

@@ -221,7 +221,9 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
         // that the scheduler does not depend on where the compiler places its waits; tools/lint_barriers.py
         // (tests/test_kernel_lint.py, CPU suite) checks that it is still there and that no other loop-head barrier of
         // the code object is reached with an LDS store in flight.
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (the comment travels into the assembly listing: the lint finds THIS wait by its marker and checks that the
+        // barrier is the next instruction, instead of guessing which barrier of the kernel is the loop head)
+        asm volatile("s_waitcnt lgkmcnt(0) ; vf_sched_loop_head" ::: "memory");
         __syncthreads();                    // previous item fully retired (LDS reusable)
         VF_TRACE_EVT(TR_TICKET);
         if (tid == 0) {

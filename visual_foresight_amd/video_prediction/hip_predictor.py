@@ -96,6 +96,15 @@ class HipVPredEvaluation(object):
                              % (int(first_gpu), self.n_gpus, n_dev))
         # under torchrun LOCAL_RANK picks this rank's GPU; the lanes of the in-process mode follow first_gpu
         local_rank = int(os.environ.get('LOCAL_RANK', 0)) if world > 1 else 0
+        shared_dry_run = oversubscribe or os.environ.get('VF_BENCH_BACKEND') == 'gloo'
+        if world > 1 and not shared_dry_run and (int(first_gpu) < 0 or int(first_gpu) + local_rank >= n_dev):
+            import torch.distributed as dist
+            if dist.get_backend() != 'gloo':
+                # one process per GPU: rank r owns device first_gpu + LOCAL_RANK - never wrap onto a GPU below first_gpu
+                # (another job's), and never put two RCCL ranks on one device
+                raise ValueError('first_gpu=%d + LOCAL_RANK=%d is outside the %d GPU(s) of this host (ranks sharing a '
+                                 "GPU need the gloo backend or the hyper-parameter 'oversubscribe_gpus')"
+                                 % (int(first_gpu), local_rank, n_dev))
         self.device_index = (int(first_gpu) + local_rank) % n_dev
         self.device = torch.device('cuda', self.device_index)
         self._libh = _lib.load_library()

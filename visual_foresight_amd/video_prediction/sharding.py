@@ -47,3 +47,45 @@ def all_gather_rows(local, M):
     dist.all_gather(bufs, padded)
     out = torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0)
     return out.to(local.device) if via_host else out
+
+
+def plan_digest(plan_stat, best_indices, action=None):
+    """sha256 (hex) of what one planning call decided: every iteration's score vector (float64 bytes, in iteration
+    order), the elite indices of the last iteration and, optionally, the action handed to the agent.  Two ranks - or an
+    N-rank job and the single-GPU job on the same candidates - planned identically iff their digests are equal: the
+    reference's towers can only be compared by eye (``setup_predictor.py:155-162`` concatenates whole videos), here a
+    scaling record proves G-invariance by itself."""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    for key in sorted((k for k in plan_stat if k.startswith('scores_itr')), key=lambda k: int(k[len('scores_itr'):])):
+        h.update(key.encode())
+        h.update(np.ascontiguousarray(plan_stat[key], dtype=np.float64).tobytes())
+    h.update(b'elites')
+    h.update(np.ascontiguousarray(best_indices if best_indices is not None else [], dtype=np.int64).tobytes())
+    if action is not None:
+        h.update(b'action')
+        h.update(np.ascontiguousarray(action, dtype=np.float64).tobytes())
+    return h.hexdigest()
+
+
+def run_digest(call_digests):
+    """One sha256 over the per-call digests of a run (what a bench line prints as ``scores_sha``)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in call_digests:
+        h.update(d.encode())
+    return h.hexdigest()[:16]
+
+
+def gather_plan_digests(call_digests):
+    """Every rank's list of per-call digests -> (identical_across_ranks, [run digest of every rank]).  One object
+    all-gather AFTER the timed region (tens of bytes per call); world 1: trivially identical."""
+    import torch.distributed as dist
+    rank, world = dist_info()
+    if world == 1:
+        return True, [run_digest(call_digests)]
+    everyone = [None] * world
+    dist.all_gather_object(everyone, list(call_digests))
+    same = all(d == everyone[0] for d in everyone)
+    return same, [run_digest(d) for d in everyone]
