@@ -103,3 +103,23 @@ def test_weights_file_roundtrip(tmp_path):
     again = cdna_arch.CdnaWeights.random(cfg, seed=5, bias_scale=0.1, ln_jitter=0.1)
     for k in w.tensors:
         np.testing.assert_array_equal(w.tensors[k], again.tensors[k])
+
+
+def test_c_host_builds_from_the_header_alone(tmp_path):
+    """tools/c_host/vf_c_host.c - the C driver of the boundary (run on the GPU by tests/test_gpu_c_host.py) - compiles
+    with gcc against include/vf_hip.h and links against the shipped library: every entry point it calls is exported
+    with a C-callable signature."""
+    import shutil
+    import subprocess
+    if not shutil.which('gcc') or not os.path.exists('/opt/rocm/include/hip/hip_runtime_api.h'):
+        pytest.skip('gcc or the HIP headers are not available')
+    exe = str(tmp_path / 'vf_c_host')
+    cmd = ['gcc', '-O2', '-std=c11', '-Wall', '-Werror', '-D__HIP_PLATFORM_AMD__', '-I', os.path.join(REPO, 'include'),
+           '-I', '/opt/rocm/include', os.path.join(REPO, 'tools', 'c_host', 'vf_c_host.c'), _lib.LIB_PATH,
+           '-L/opt/rocm/lib', '-lamdhip64', '-Wl,-rpath,/opt/rocm/lib', '-o', exe]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert proc.returncode == 0, proc.stdout
+    # no arguments: usage, exit code 1 - and no HIP call has been made (runs without a GPU)
+    run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         env=dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(_lib.LIB_PATH)))
+    assert run.returncode == 1 and 'usage' in run.stdout

@@ -13,9 +13,12 @@ the cost) to reproduce the outputs from the same inputs.
 
     python tools/make_golden.py        # rewrites tests/golden/*.npz|json
 
-The TF ``HParams`` class does not exist in this image; the stub is this repo's own
-``visual_foresight_amd.hparams.HParams`` - so fixtures pin the *reference's override
-protocol* (policy.py:51-63, cem_base_controller.py:66-76) on top of it, not TF's class.
+The TF ``HParams`` class does not exist in this image; the stub the reference runs on is
+``oracle/tf_hparams.py`` - a restatement of TF 1.6's class from its published source (type
+rules of ``_cast_to_type_if_compatible`` included) that shares no code with this repo's
+``visual_foresight_amd.hparams.HParams`` - so the fixtures pin the reference's override
+protocol (policy.py:51-63, cem_base_controller.py:66-76) AND TF's cast rules against the
+product class instead of pinning the product class against itself.
 """
 import io
 import json
@@ -33,7 +36,7 @@ sys.path.insert(0, REPO)
 sys.dont_write_bytecode = True
 
 from tests.helpers.fake_predictor import make_fake_predictor_class  # noqa: E402
-from visual_foresight_amd.hparams import HParams  # noqa: E402
+from oracle.tf_hparams import HParams  # noqa: E402  (the TF 1.6 restatement, not the product's class)
 
 
 def install_stubs():
@@ -68,6 +71,14 @@ def install_stubs():
     import matplotlib
     matplotlib.use('Agg')
     sys.path.insert(0, REFERENCE)
+
+
+def reference_predictor(fake):
+    """Make ``fake`` the predictor class the reference constructs.  It cannot travel as a ``predictor_class`` override:
+    TF's ``set_hparam`` ends in ``type(value)`` for a class-valued parameter (oracle/tf_hparams.py), the reference never
+    overrides that key, so the stub takes the place of the default class the reference imported
+    (``pixel_cost_controller.py:11-12``: ``VPredEvaluation as DefaultPredClass``)."""
+    sys.modules['visual_mpc.policy.cem_controllers.pixel_cost_controller'].DefaultPredClass = fake
 
 
 @contextlib.contextmanager
@@ -285,7 +296,8 @@ def golden_cost(ref):
     ]
     for name, H, W, nd, M, T, fw, first in cases:
         fake = make_fake_predictor_class(T, H, W)
-        pol = {'predictor_class': fake, 'designated_pixel_count': nd, 'nactions': T, 'repeat': 1,
+        reference_predictor(fake)
+        pol = {'designated_pixel_count': nd, 'nactions': T, 'repeat': 1,
                'rejection_sampling': False, 'verbose': False, 'num_samples': M + 1}
         if nd == 1:
             pol.pop('designated_pixel_count')
@@ -341,7 +353,8 @@ def golden_act(ref):
     for name, over, n_steps in cases:
         from visual_mpc.policy.cem_controllers.samplers import CorrelatedNoiseSampler
         fake = make_fake_predictor_class(T, H, W)
-        pol = {'predictor_class': fake, 'verbose': False}
+        reference_predictor(fake)
+        pol = {'verbose': False}
         if over.get('sampler') == 'corr':
             pol['sampler'] = CorrelatedNoiseSampler
             over = {k: v for k, v in over.items() if k != 'sampler'}

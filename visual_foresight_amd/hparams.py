@@ -51,25 +51,31 @@ class HParams(object):
     # ------------------------------------------------------------------ overrides
     @staticmethod
     def _coerce(name, param_type, value):
-        """Cast ``value`` to ``param_type`` if the two are compatible, else ValueError."""
+        """Cast ``value`` to ``param_type`` if the two are compatible, else ValueError: the four refusals of TF 1.6's
+        ``_cast_to_type_if_compatible`` (``tensorflow/contrib/training/python/training/hparam.py``) in their order.
+        One deliberate departure: TF ends with an unconditional ``param_type(value)``, which turns a class-valued
+        parameter into its metaclass (the reference repairs ``sampler`` by hand for that reason,
+        ``cem_base_controller.py:76``, and never overrides ``predictor_class``); here values of non-scalar parameter
+        types (classes, callables, dicts, arrays) are stored as given - the predictor plug-in seam
+        (``predictor_class=HipVPredEvaluation``) depends on it.  tests/test_hparams_tf_rules.py holds the table."""
         def fail():
             raise ValueError("Could not cast hparam '%s' of type '%s' from value %r"
                              % (name, param_type, value))
 
-        if value is None:
-            return None
+        if issubclass(param_type, type(None)):      # a None default carries no type
+            return value
+        if issubclass(param_type, (str, bytes)) and not isinstance(value, (str, bytes)):
+            fail()
         # bools are never mixed with anything else
         if issubclass(param_type, bool) != isinstance(value, bool):
-            fail()
-        if issubclass(param_type, str) and not isinstance(value, (str, bytes)):
             fail()
         if issubclass(param_type, numbers.Integral) and not isinstance(value, numbers.Integral):
             fail()
         if issubclass(param_type, numbers.Number) and not isinstance(value, numbers.Number):
             fail()
-        if issubclass(param_type, (bool, str, numbers.Number)):
+        if issubclass(param_type, (bool, str, bytes, numbers.Number)):
             return param_type(value)
-        # classes, callables, arrays, NoneType defaults ...: store as given
+        # classes, callables, arrays ...: store as given
         return value
 
     def set_hparam(self, name, value):
