@@ -255,6 +255,11 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
         gs_tap(std::integral_constant<int, 4>{}, gt_row + 5);
     };
 
+    // (yielding, vf_conv_mfma.h: the recurrent chunks of an early-started item step aside for chain-critical work of the
+    // CU's other workgroup - once per kernel row, bounded per item)
+    const bool yielding = late && p.cu_state != nullptr && p.yield_budget > 0;
+    int ybudget = p.yield_budget;
+    const int *yword = yielding ? cu_partner_word(p) : nullptr;
     if constexpr (kInLaunch) VF_TRACE_EVT(TR_MFMAS, (unsigned long long)(25 * K8 * 4 * MR));
     __builtin_amdgcn_s_setprio(0);
     const f32x4 *a4 = reinterpret_cast<const f32x4 *>(smem);
@@ -283,10 +288,14 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
         pf = ci + 1 < total_chunks && !(late && ci + 1 == p.seg[0].nchunk);
         if (pf) issue_batch(chunk_src(ci + 1), 0, pv);
         if constexpr (kInLaunch) VF_TRACE_EVT(TR_KLOOP);
+        const bool ychunk = yielding && ci < p.seg[0].nchunk;
         for (int ky = 0; ky < 5; ++ky) {
+            unsigned yseen = 0;
+            if (ychunk) yseen = yield_peek_issue(yword);
 #pragma unroll
             for (int m = 0; m < MR; ++m) ar[m] = a4 + ab4[m] + ky * LW * 9;
             gs_row(ci * 25 + ky * 5);
+            if (ychunk) yield_to_partner(yword, yseen, ybudget);
         }
     }
     __builtin_amdgcn_s_setprio(2);

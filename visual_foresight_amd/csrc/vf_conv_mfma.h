@@ -162,9 +162,67 @@ struct ConvParams {
     const int *late_cnt;
     int late_expect, late_mode;
     int *late_status;       // the launch's sticky failure word
+    // Cooperative CU-level priority of the persistent launch (vf_persistent.h, "yielding"): the table of per-workgroup
+    // state words (null: off) and how many polls an early-started item may spend yielding to its CU partner
+    int *cu_state;
+    int yield_budget;
 };
 
 constexpr unsigned kLateSpinLimit = 1u << 26;   // polls before a mid-item wait gives up (as kSpinLimit)
+
+// ---- Cooperative CU-level priority ("yielding") of the persistent launch.
+// Machine model: a CU is time-sliced - next to a K loop the other workgroup's instructions are issued about
+// once per 40 cycles whatever their s_setprio, and two K loops share the matrix pipe half and half.  For a batch that fills
+// the chip that is harmless (every cycle of the pipe is somebody's throughput).  For a small shard it is not: the RECURRENT
+// half of an early-started conv-LSTM item is work for later (its layer input does not exist yet), while the partner
+// workgroup's epilogue / staging / light item / input-half K loop is on some sample's dependency chain - and the filler
+// slows the chain down 2x (K loop) to 5x (everything else).  Hardware priorities do not arbitrate the matrix pipe, so the
+// priority is cooperative: every workgroup publishes one word - 1 while it runs chain-critical work, 0 while it waits,
+// polls or runs a recurrent half - and a recurrent half looks at its PARTNER's word once per kernel row (a scalar load
+// issued at the head of the row, consumed at its end: nothing is added between the MFMAs) and sleeps while it is 1.
+// Bounded: an item yields at most ConvParams::yield_budget polls in total, so a stale word costs time, never progress, and
+// the recurrent half never falls behind its own layer input by more than the budget.  Timing only: results cannot change.
+constexpr int kYieldSleep = 8;                  // s_sleep units (64 cycles) per yield poll
+// words of the persistent kernel's LDS control block that hold the ADDRESSES of this workgroup's state word and of its CU
+// partner's (two words each, behind the goal pixels; written once at kernel entry, valid after the first barrier)
+constexpr int kCtlMyState = 40, kCtlPartnerState = 42;
+__device__ __forceinline__ int *ctl_state_word(const int which) {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    return *reinterpret_cast<int *const *>(smem_all + which);
+}
+// publish this workgroup's state (one lane; fire and forget)
+template <class PT>
+__device__ __forceinline__ void cu_publish(const PT &p, const int critical) {
+    if (p.cu_state != nullptr && threadIdx.x == 0)
+        __hip_atomic_store(ctl_state_word(kCtlMyState), critical, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the partner's state word as a wave-uniform address
+template <class PT>
+__device__ __forceinline__ const int *cu_partner_word(const PT &) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ctl_state_word(kCtlPartnerState));
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return reinterpret_cast<const int *>(((unsigned long long)hi << 32) | lo);
+}
+// scalar, L2-coherent load of the partner's word: issue now ...
+__device__ __forceinline__ unsigned yield_peek_issue(const int *word) {
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(v) : "s"(word) : "memory");
+    return v;       // NOT valid before yield_peek_wait
+}
+// ... consume later (the wait also covers the wave's LDS reads in flight: they are the next row's operands, needed next)
+__device__ __forceinline__ unsigned yield_peek_wait(unsigned v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory");
+    return v;
+}
+// end of a kernel row of a recurrent half: sleep while the partner is on a dependency chain (bounded by `budget`)
+__device__ __forceinline__ void yield_to_partner(const int *word, unsigned seen, int &budget) {
+    seen = yield_peek_wait(seen);
+    while (seen != 0u && budget > 0) {
+        __builtin_amdgcn_s_sleep(kYieldSleep);
+        --budget;
+        seen = yield_peek_wait(yield_peek_issue(word));
+    }
+}
 
 // Mid-item wait of a conv-LSTM tile for the producer of its layer input (samples [b0, b1)).  One wave polls
 // (relaxed agent-scope loads, s_sleep), acquires, and the result crosses the workgroup through `flag` (LDS).
@@ -173,6 +231,7 @@ constexpr unsigned kLateSpinLimit = 1u << 26;   // polls before a mid-item wait 
 template <class PT>
 __device__ __forceinline__ bool late_wait(const PT &p, const int b0, const int b1, int *flag) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cu_publish(p, 0);                   // (yielding) waiting: the partner's recurrent half need not step aside
     if (wave == 0) {
         unsigned spins = 0;
         bool ok;
@@ -204,6 +263,7 @@ __device__ __forceinline__ bool late_wait(const PT &p, const int b0, const int b
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
     }
+    cu_publish(p, 1);                   // the layer input is there: from here on this item is on its sample's chain
     __syncthreads();
     return *flag != 0;
 }
@@ -825,6 +885,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     const int bx = __builtin_amdgcn_readfirstlane(bx_), by = __builtin_amdgcn_readfirstlane(by_),
               bz = __builtin_amdgcn_readfirstlane(bz_);
     constexpr bool SPLIT = RB == 1 || RB == 2;
+    [[maybe_unused]] constexpr bool kInLaunch = !std::is_same<PT, ConvParams>::value;     // tile of the persistent rollout
     // gate-split conv-LSTM tiles: wave w = gate w of ALL row blocks of the workgroup - RB 0: 4 * MREP row blocks (128 /
     // 256 rows), RB -2: two row blocks (64 rows, the plan of narrow phases)
     constexpr bool GSPLIT = RB <= 0;
@@ -844,7 +905,6 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     //  * 256-row conv-LSTM tile: straight from L2 with a one-step look-ahead (its input tile needs the LDS, and it
     //    must keep the 32-channel chunks of the other plans so that every plan accumulates in the same K order);
     //  * light layers: straight from L2 through a ring of 4 (5) K steps, see kGRing below.
-    [[maybe_unused]] constexpr bool kInLaunch = !std::is_same<PT, ConvParams>::value;     // tile of the persistent rollout
     //  * gate-split 128-row conv-LSTM tile (RB 0): wave w multiplies gate w's slice with all 128 rows, so nothing
     //    is shared and a tap is long (64 MFMAs): the slice of the NEXT tap goes straight from L2 into registers, no
     //    LDS staging, no barrier and no VALU instruction inside a kernel row (see the K loop).
@@ -888,6 +948,12 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     // item reads them only once the producer of its layer input is known to be done (chunk loop below)
     const bool late = p.late_cnt != nullptr;
     ln_table(p, bimg0, lnTab, 0, late ? 1 : 2);
+    // (yielding, above: the recurrent chunks of an early-started conv-LSTM item step aside for chain-critical work of the
+    // CU's other workgroup - once per kernel row, bounded per item; the small-shard tiles only)
+    [[maybe_unused]] const bool yielding = kInLaunch && EPI == EPI_LSTM && (GSPLIT || (SPLIT && RB == 1)) && late &&
+                                           p.cu_state != nullptr && p.yield_budget > 0;
+    [[maybe_unused]] int ybudget = p.yield_budget;
+    [[maybe_unused]] const int *yword = yielding ? cu_partner_word(p) : nullptr;
 
     // ---- this lane's A rows (GEMM rows wave*WROWS + m*32 + n)
     const int px_per_img = p.TH * p.TW;
@@ -1313,12 +1379,16 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
                 gs_tap(std::integral_constant<int, 3>{}, Y_, X_, gt_row + 4);
                 gs_tap(std::integral_constant<int, 4>{}, X_, Y_, gt_row + 5);
             };
+            const bool ychunk = yielding && ci < p.seg[0].nchunk;
             for (int ky = 0; ky < 5; ++ky) {
                 const int gt_row = ci * 25 + ky * 5;
+                unsigned yseen = 0;
+                if (ychunk) yseen = yield_peek_issue(yword);
 #pragma unroll
                 for (int m = 0; m < MR; ++m) ar[m] = smem4 + ab4[m] + ky * LW * 9;
                 if (gs_par == 0) gs_row(gsA, gsB, gt_row); else gs_row(gsB, gsA, gt_row);
                 gs_par ^= 1;                // five taps: the slice of the next row's first tap sits in the other set
+                if (ychunk) yield_to_partner(yword, yseen, ybudget);
             }
         } else if constexpr (kBLds) {
           if (K8 == 4) {
@@ -1421,7 +1491,10 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
             const int a0 = ab4[0];
 #pragma unroll
             for (int q = 0; q < 4; ++q) aC[q] = smem4[a0 + q * 2];
+            const bool ychunk = yielding && ci < p.seg[0].nchunk;
             for (int ky = 0; ky < 5; ++ky) {
+                unsigned yseen = 0;
+                if (ychunk) yseen = yield_peek_issue(yword);
 #pragma unroll
                 for (int kx = 0; kx < kRing; ++kx) {
                     const int gt = ci * ntaps + ky * 5 + kx;
@@ -1441,6 +1514,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) aC[q] = aN[q];
                 }
+                if (ychunk) yield_to_partner(yword, yseen, ybudget);
             }
         } else if (kGRing && (G > 1 || ring_d != 0)) {      // (transposed convs: 4 taps x K8 steps, always ring_d == 4)
             // ---- K loop of the light layers: B from the register ring (refilled ring_d steps ahead), A one step

@@ -58,8 +58,10 @@ static const int kLstmSizes[7] = {32, 32, 64, 64, 128, 64, 32};
 static const int kEnc00Ch = 16;             // channels of the extra encoder scale of arch 1 (savp_arch.py)
 static const int kNumLn = 11;               // ln1..ln9, lna, lnb
 static const int kSchedRing = 4;            // pinned staging buffers for schedule uploads
-// ints in front of the completion counters: the ticket heads
-static const int kSyncHead = kQueues * kTicketStride;
+// ints in front of the completion counters: the ticket heads ...
+static const int kTicketInts = kQueues * kTicketStride;
+// ... and the per-CU state table of the cooperative priority scheme (vf_persistent.h: kCuKeys x kCuWords)
+static const int kSyncHead = kTicketInts + kCuKeys * kCuWords;
 
 // ------------------------------------------------------------------ canonical tensor table
 struct TensorDesc {
@@ -483,6 +485,8 @@ struct vf_handle {
     bool early_start = true;            // conv-LSTM items start on h(s-1) alone and wait for x(s) mid-item (ConvParams::late_cnt)
     bool fuse_top = true;               // vf_set_fuse_top: top transposed conv + compositing as one item (vf_fused_top.h)
     bool fuse_pair = true;              // ... and enc2 + enc3 as one item (conv_pair_epilogue); follows vf_set_fuse_top
+    int yield_budget = -1;              // cooperative CU priority ("yielding", vf_conv_mfma.h): polls an early-started conv-LSTM
+                                        // item may spend yielding to its CU partner; 0 = off, -1 = by batch size (yield_for)
     bool pair_allowed = true;           // (-DVF_DEBUG_KNOBS: VF_FUSE_PAIR=0, read once in vf_create)
     int *d_status = nullptr;            // sticky failure word of the persistent kernel
     unsigned long long *d_stats = nullptr;  // per-phase wait/run ticks (vf_set_phase_stats)
@@ -802,6 +806,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
             h->mrep_override[k] = e[k] == '2' ? 2 : (e[k] == '1' ? 1 : (e[k] == 'h' ? 3 : (e[k] == 'q' ? 4 : 0)));
 #endif
 #ifdef VF_DEBUG_KNOBS
+    if (const char *e = getenv("VF_YIELD")) h->yield_budget = atoi(e);
     // A/B knob of debug builds, read ONCE per handle (not inside a setter the caller may never invoke)
     static const bool knob_no_pair = getenv("VF_FUSE_PAIR") && atoi(getenv("VF_FUSE_PAIR")) == 0;
     h->pair_allowed = !knob_no_pair;
@@ -1927,8 +1932,19 @@ static int run_steps(vf_handle *h, int view, const BatchView &v, const BatchView
 
 // every toggle emit_rollout / build_schedule read besides (B, dedup, xcd_queues): part of the schedule cache's key, so an
 // option changed between two rollouts can never meet a schedule built for the old value
-static int sched_options(const vf_handle *h) {
-    return (h->fuse_top ? 1 : 0) | (h->fuse_pair ? 2 : 0) | (h->early_start ? 4 : 0);
+#ifndef VF_YIELD_DEFAULT
+#define VF_YIELD_DEFAULT 0          // (A/B builds: -DVF_YIELD_DEFAULT=n)
+#endif
+// Yield budget of a launch of B samples.  The scheme pays where a rollout is bound by the per-sample dependency chain
+// (the shards of the multi-GPU configs); a batch that fills the chip is throughput-bound and keeps it off.
+static int yield_for(const vf_handle *h, int B) {
+    if (!h->early_start) return 0;
+    if (h->yield_budget >= 0) return h->yield_budget;
+    (void)B;
+    return VF_YIELD_DEFAULT;
+}
+static int sched_options(const vf_handle *h, int B) {
+    return (h->fuse_top ? 1 : 0) | (h->fuse_pair ? 2 : 0) | (h->early_start ? 4 : 0) | (yield_for(h, B) << 3);
 }
 
 // Are the shared buffers of configuration `cfg` (launch mode and split) still valid?
@@ -1955,7 +1971,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     const bool skip_shared = shared_cache_hit(h, cfg);
     vf_handle::SchedCache &sc_host = h->sched[skip_shared ? 1 : 0];
     if (sc_host.B != B || sc_host.dedup != h->dedup || sc_host.xcd_queues != h->xcd_queues ||
-        sc_host.options != sched_options(h)) {
+        sc_host.options != sched_options(h, B)) {
         BuiltSchedule bs;
         if ((rc = build_schedule(h, B, skip_shared, bs))) return rc;
         // Upload without synchronising the caller's stream: the copy is stream-ordered behind the
@@ -1972,6 +1988,10 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
                 P.conv.late_expect = P.late.expect;
                 P.conv.late_mode = P.late.mode;
                 P.conv.late_status = h->d_status;
+                if (yield_for(h, B) > 0) {      // every early-started item publishes its state around its mid-item wait;
+                    P.conv.cu_state = h->d_sync + kTicketInts;      // only the conv-LSTMs' recurrent halves yield
+                    P.conv.yield_budget = P.type == PH_LSTM ? yield_for(h, B) : 0;
+                }
             }
             if (P.type == PH_CONV_PAIR) P.conv.fuse_next = &sc_host.d_phases[i].conv2;
             if (P.type != PH_TOP_FUSED) continue;
@@ -1988,7 +2008,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         h->stage_used[slot] = true;
         sc_host.B = B; sc_host.dedup = h->dedup;
         sc_host.xcd_queues = h->xcd_queues;
-        sc_host.options = sched_options(h);
+        sc_host.options = sched_options(h, B);
         sc_host.items = bs.items; sc_host.counters = bs.counters;
         sc_host.nq = bs.nq;
         for (int q = 0; q < kQueues; ++q) sc_host.total_q[q] = bs.total_q[q];
@@ -2009,6 +2029,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
     sc.ticket = h->d_sync; sc.counters = h->d_sync + kSyncHead; sc.status = h->d_status;
     sc.nq = sc_host.nq;
     for (int q = 0; q < kQueues; ++q) sc.total_q[q] = sc_host.total_q[q];
+    sc.cu_tab = yield_for(h, B) > 0 ? h->d_sync + kTicketInts : nullptr;
     sc.stats = nullptr;
     sc.nd = h->ND;
     for (int i = 0; i < h->ncam * h->ND * 2; ++i) sc.goal[i] = goal_pix[i];

@@ -35,6 +35,8 @@ enum PhaseType {
 constexpr int kMaxDeps = 3;
 constexpr int kQueues = 8;                  // one ticket queue per XCD
 constexpr int kTicketStride = 32;           // ints between ticket heads (128 B)
+constexpr int kCuKeys = 8 * 256;            // (XCC id, SE / SH / CU id of HW_REG_HW_ID) keys of the per-CU state table
+constexpr int kCuWords = 4;                 // ints per key: [arrivals, state of slot 0, state of slot 1, -]
 constexpr int kSaPerItem = 4;               // samples per PH_SA item (one per wave)
 constexpr unsigned kSpinLimit = 1u << 26;   // polls before a waiting item gives up (~ seconds)
 
@@ -78,9 +80,10 @@ struct PhaseDesc {
     CompositeParams comp;
 };
 
-constexpr int kCtlWords = 64;               // LDS control block: [0..3] scheduler, [8..8+32) goal pixels
+constexpr int kCtlWords = 64;               // LDS control block: [0..3] scheduler, [8..8+32) goal pixels, [40..44) state words
 constexpr int kCtlGoal = 8;
 static_assert(kCtlGoal == kFusedCtlGoal, "vf_fused_top.h reads the goal pixels from the control block");
+static_assert(kCtlGoal + kMaxCam * kMaxDesig * 2 <= kCtlMyState && kCtlPartnerState + 2 <= kCtlWords, "control block layout");
 
 struct Schedule {
     const PhaseDesc *phases;
@@ -96,6 +99,8 @@ struct Schedule {
     int goal[kMaxCam * kMaxDesig * 2];      // goal pixels [view][desig][row, col]: launch arguments, so
                                             // the device schedule does not depend on them
     int nd;                 // designated pixels per view
+    int *cu_tab;            // [kCuKeys][kCuWords] per-CU state words of the cooperative priority scheme ("yielding",
+                            // vf_conv_mfma.h) or null: off.  Zeroed with the ticket heads before every launch.
 };
 
 __device__ __forceinline__ int ld_relaxed(const int *p) {
@@ -213,6 +218,26 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
     const int nq = sched.nq;
     const int q_own = (int)(xcc & (unsigned)(nq - 1));
 
+    // Yielding (vf_conv_mfma.h): the two workgroups of a CU find each other through the CU's entry of sched.cu_tab - the
+    // first to arrive takes state word 1, the second word 2 - and remember "mine" / "the partner's" in the control block.
+    // (A key shared by more than two workgroups, or a CU with one, only costs the scheme its effect: yields are bounded.)
+    const bool yield_on = sched.cu_tab != nullptr;
+    if (yield_on && tid == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        const int key = (int)((xcc & 7u) * 256u + ((hwid >> 8) & 0xFFu));
+        int *entry = sched.cu_tab + key * kCuWords;
+        const int slot = atomicAdd(entry, 1) & 1;
+        *reinterpret_cast<int **>(s_ctl + kCtlMyState) = entry + 1 + slot;
+        *reinterpret_cast<int **>(s_ctl + kCtlPartnerState) = entry + 1 + (slot ^ 1);
+    }
+    // this workgroup's state word: 1 = on some sample's dependency chain, 0 = waiting / polling / recurrent half
+    auto publish_state = [&](const int critical) {
+        // (the word's address lives in the LDS control block, not in a register: the tile calls clobber every VGPR)
+        if (yield_on && tid == 0)
+            __hip_atomic_store(ctl_state_word(kCtlMyState), critical, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
     for (;;) {
         [[maybe_unused]] const unsigned long long ts_top = VF_TS_NOW();
         // hipcc 7.2 does not put an `s_waitcnt lgkmcnt(0)` in front of a loop-head barrier for an LDS store that is
@@ -304,6 +329,9 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
         }
         __syncthreads();
         if (s_ctl[1] == 0) break;           // a producer never arrived: abandon the rollout
+        // chain-critical from here to the publish - except the part of an early-started item in front of its mid-item
+        // wait (recurrent half / skip-tensor chunks: work for later) and the CDNA FC (needed at the end of the step only)
+        publish_state((P.has_late || P.type == PH_FC_PARTIAL) ? 0 : 1);
         const unsigned long long t_run = sched.stats ? wall_clock64() : 0ull;
         VF_TRACE_EVT(TR_RUN + (unsigned)P.type);
         VF_TRACE_EVT(TR_PHASE, (unsigned long long)ph_run);
@@ -382,9 +410,11 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                                                __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        publish_state(0);                   // back to the ticket counter / a dependency poll
         VF_TS_ADD(15, 6, VF_TS_NOW() - ts_pub);         // drain + barrier + release fence + counters (tid 0's view)
         VF_TRACE_EVT(TR_DONE);
     }
+    publish_state(0);                       // (also on the abandon paths: never leave a stale "critical" behind)
 #ifdef VF_TRACE
     if (tid == 0 && blockIdx.x < kTraceWgs) g_trace_n[blockIdx.x] = (unsigned)s_ctl[5];
 #endif
