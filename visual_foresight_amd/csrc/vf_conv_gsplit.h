@@ -205,6 +205,11 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
         for (int u = 0; u < kBatch; ++u) st_finish(cs, L, u0 + u, v[u], dst);
     };
 
+    // (yielding, vf_conv_mfma.h: the recurrent chunks of an early-started item step aside for chain-critical work of the
+    // CU's other workgroup - once per kernel row, bounded per item)
+    const bool yielding = late && p.cu_state != nullptr && p.yield_budget > 0;
+    int ybudget = p.yield_budget;
+    const int *yword = yielding ? cu_partner_word(p) : nullptr;
     // ---- K loop of one kernel row (vf_conv_mfma.h: the gate-split K loop), reading operand tile `a4`
     constexpr int GSZ = MR < 4 ? MR : 4, NG = MR / GSZ, NS = 4 * NG;
     const f32x4 *ar[MR];
@@ -246,6 +251,8 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
             }
         });
     };
+    bool ychunk = false;                // this chunk is a recurrent chunk of a yielding item
+    unsigned yseen = 0;                 // the partner's state word, requested one check ago
     auto gs_row = [&](const int gt_row) {
         gs_fetch(aP4, 0, 0);
         gs_tap(std::integral_constant<int, 0>{}, gt_row + 1);
@@ -255,11 +262,6 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
         gs_tap(std::integral_constant<int, 4>{}, gt_row + 5);
     };
 
-    // (yielding, vf_conv_mfma.h: the recurrent chunks of an early-started item step aside for chain-critical work of the
-    // CU's other workgroup - once per kernel row, bounded per item)
-    const bool yielding = late && p.cu_state != nullptr && p.yield_budget > 0;
-    int ybudget = p.yield_budget;
-    const int *yword = yielding ? cu_partner_word(p) : nullptr;
     if constexpr (kInLaunch) VF_TRACE_EVT(TR_MFMAS, (unsigned long long)(25 * K8 * 4 * MR));
     __builtin_amdgcn_s_setprio(0);
     const f32x4 *a4 = reinterpret_cast<const f32x4 *>(smem);
@@ -288,9 +290,8 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
         pf = ci + 1 < total_chunks && !(late && ci + 1 == p.seg[0].nchunk);
         if (pf) issue_batch(chunk_src(ci + 1), 0, pv);
         if constexpr (kInLaunch) VF_TRACE_EVT(TR_KLOOP);
-        const bool ychunk = yielding && ci < p.seg[0].nchunk;
+        ychunk = yielding && ci < p.seg[0].nchunk;
         for (int ky = 0; ky < 5; ++ky) {
-            unsigned yseen = 0;
             if (ychunk) yseen = yield_peek_issue(yword);
 #pragma unroll
             for (int m = 0; m < MR; ++m) ar[m] = a4 + ab4[m] + ky * LW * 9;

@@ -1371,6 +1371,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
                     __builtin_amdgcn_sched_barrier(0);
                 });
             };
+            const bool ychunk = yielding && ci < p.seg[0].nchunk;
+            unsigned yseen = 0;
             auto gs_row = [&](f32x4 (&X_)[4], f32x4 (&Y_)[4], const int gt_row) {
                 gs_fetch(aP4, 0, 0);
                 gs_tap(std::integral_constant<int, 0>{}, X_, Y_, gt_row + 1);
@@ -1379,10 +1381,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
                 gs_tap(std::integral_constant<int, 3>{}, Y_, X_, gt_row + 4);
                 gs_tap(std::integral_constant<int, 4>{}, X_, Y_, gt_row + 5);
             };
-            const bool ychunk = yielding && ci < p.seg[0].nchunk;
             for (int ky = 0; ky < 5; ++ky) {
                 const int gt_row = ci * 25 + ky * 5;
-                unsigned yseen = 0;
                 if (ychunk) yseen = yield_peek_issue(yword);
 #pragma unroll
                 for (int m = 0; m < MR; ++m) ar[m] = smem4 + ab4[m] + ky * LW * 9;

@@ -416,6 +416,8 @@ struct vf_handle {
 
     // layers (geometry)
     ConvLayer enc0, lstm[7], enc1, enc2, enc3, convt1, convt2, convt3, fc;
+    ConvLayer fc_wide;                  // the FC as one item per (128-row tile, K split) with all column groups (vf_fc_tile.h)
+    bool fc_wide_ok = false;
     ConvLayer enc00, convt4;            // arch 1 only
     // One-image-per-workgroup plans of the bottleneck's light layers (8x8 images: two fit a 128-row tile): twice the
     // items, each shorter - for batches whose phases do not fill the workgroup slots anyway (same packed weights,
@@ -843,6 +845,10 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         f.chunks_per_split = (total + f.nsplit - 1) / f.nsplit;
         f.nsplit = (total + f.chunks_per_split - 1) / f.chunks_per_split;
         f.n_valid = kTaps * h->K;
+        // the persistent schedule's plan: same packed weights, same chunks and splits, 128 rows x all column groups
+        h->fc_wide = f;
+        h->fc_wide.mrep = 7; h->fc_wide.NI = kFcRows; h->fc_wide.lds_bytes = fc_wide_lds_bytes();
+        h->fc_wide_ok = f.KC == 32 && f.ncg == kFcGroups && f.nseg == 1 && f.segC[0] % 32 == 0;
     }
     h->layers = {&h->enc0, &h->lstm[0], &h->lstm[1], &h->enc1, &h->lstm[2], &h->lstm[3], &h->enc2, &h->enc3,
                  &h->lstm[4], &h->convt1, &h->lstm[5], &h->convt2, &h->lstm[6], &h->convt3, &h->fc};
@@ -879,6 +885,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         h->max_lds = std::max(h->max_lds, h->layers[i]->lds_bytes);
     }
     h->enc2_one.id = h->enc2.id; h->enc3_one.id = h->enc3.id; h->convt1_one.id = h->convt1.id;   // shared packed weights
+    h->fc_wide.id = h->fc.id;
     for (int k = 0; k < 7; ++k)
         if (h->have_big) {
             h->lstm_big[k].id = h->lstm_half[k].id = h->lstm_quarter[k].id = h->lstm[k].id;    // shared packed weights
@@ -1214,6 +1221,7 @@ struct LaunchSink {
     int lstm(const ConvLayer &l, const ConvParams &p, int /*u_prev*/, int /*u_x*/) { return conv(PH_LSTM, l, p, {}); }
     int conv_late(int type, const ConvLayer &l, const ConvParams &p, int /*u_early*/, int /*u_late*/) { return conv(type, l, p, {}); }
     static bool pair_capable() { return false; }    // one launch per layer: enc2 and enc3 stay two kernels
+    static const ConvLayer &fc_plan(const vf_handle *h) { return h->fc; }
     int conv_pair(const ConvLayer &, const ConvParams &, const ConvLayer &, const ConvParams &, std::initializer_list<int>) {
         return VF_ERR_INVALID;
     }
@@ -1301,6 +1309,7 @@ struct ScheduleSink {
         P.NI = l.NI; P.tiles_per_img = l.tilesY * l.tilesX;
         P.gx = l.NI == 1 ? p.B * P.tiles_per_img : (p.B + l.NI - 1) / l.NI;
         P.gy = l.ncg;
+        if (type == PH_FC_PARTIAL && l.mrep == 7) P.gy = 1;     // all column groups in one item (vf_fc_tile.h)
         P.whole = type == PH_FC_PARTIAL;
         P.mrep = l.gsplit ? (l.mrep == 2 ? 4 : (l.mrep == 0 ? 5 : (l.gs_v2 ? 6 : 3))) : l.mrep;
         P.prec = p.tile_variant;
@@ -1320,6 +1329,7 @@ struct ScheduleSink {
     // a conv whose tiles hold whole images + the 1x1 conv that consumes it, as one item per row tile (conv_pair_epilogue):
     // the first conv's two channel groups become the two "gates" of the workgroup (ncg 1, G 2: the same packed weights)
     static bool pair_capable() { return true; }
+    static const ConvLayer &fc_plan(const vf_handle *h) { return h->fc_wide_ok ? h->fc_wide : h->fc; }
     static bool pairable(const ConvLayer &a, const ConvLayer &b) {
         return a.mode == PACK_PLAIN && b.mode == PACK_PLAIN && a.nseg == 1 && b.nseg == 1 && a.ncg == 2 && b.ncg == 2 &&
                a.Cout == 64 && b.segC[0] == 64 && b.Cout <= 64 && b.KH == 1 && b.KW == 1 && b.stride == 1 && b.pad == 0 &&
@@ -1604,9 +1614,10 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         int u_fin = -1, u_fc = -1;
         if (produce) {
             SegArg flat = h5n;      // same LayerNorm, viewed as [B][1][1][H8*W8*128]
-            p = params(h->fc, B, flat, nullptr);
+            const ConvLayer &fc_l = Sink::fc_plan(h);
+            p = params(fc_l, B, flat, nullptr);
             p.out = v.fc_part;
-            VF_EMIT(u_fc_, sink.conv(PH_FC_PARTIAL, h->fc, p, {u_l5}))
+            VF_EMIT(u_fc_, sink.conv(PH_FC_PARTIAL, fc_l, p, {u_l5}))
             u_fc = u_fc_;
         }
 
@@ -1933,15 +1944,21 @@ static int run_steps(vf_handle *h, int view, const BatchView &v, const BatchView
 // every toggle emit_rollout / build_schedule read besides (B, dedup, xcd_queues): part of the schedule cache's key, so an
 // option changed between two rollouts can never meet a schedule built for the old value
 #ifndef VF_YIELD_DEFAULT
-#define VF_YIELD_DEFAULT 0          // (A/B builds: -DVF_YIELD_DEFAULT=n)
+#define VF_YIELD_DEFAULT 120        // polls of ~0.4 us an item may spend yielding (A/B builds: -DVF_YIELD_DEFAULT=n)
 #endif
-// Yield budget of a launch of B samples.  The scheme pays where a rollout is bound by the per-sample dependency chain
-// (the shards of the multi-GPU configs); a batch that fills the chip is throughput-bound and keeps it off.
+#ifndef VF_YIELD_MAX_ITEMS
+#define VF_YIELD_MAX_ITEMS 5        // ... in launches whose widest conv-LSTM phase has fewer items than this many x slots
+#endif
+// Yield budget of a launch of B sequences (vf_conv_mfma.h, "yielding").  The scheme pays where a rollout is bound by the
+// per-sample dependency chain - the shards of the multi-GPU configs: 25 x T13 11.57 -> 11.12 ms, 50: 18.98 -> 18.56, 125 x
+// T15: 46.44 -> 46.08 (same box, bit-identical) - and costs a launch that fills the chip 0.5 % (200: 62.75 -> 63.12 ms:
+// there every K loop is somebody's throughput), so it follows the width of the phases: the 64 x 64 network's widest
+// conv-LSTM phase has 8 items per sample (128-row tiles), 512 slots -> on up to ~160 samples per view.
 static int yield_for(const vf_handle *h, int B) {
     if (!h->early_start) return 0;
     if (h->yield_budget >= 0) return h->yield_budget;
-    (void)B;
-    return VF_YIELD_DEFAULT;
+    const long long widest = (long long)B * h->ncam * ((h->Hc / 2) * (h->Wc / 2) / 128);
+    return widest < (long long)VF_YIELD_MAX_ITEMS * 2 * h->n_cu / 2 ? VF_YIELD_DEFAULT : 0;
 }
 static int sched_options(const vf_handle *h, int B) {
     return (h->fuse_top ? 1 : 0) | (h->fuse_pair ? 2 : 0) | (h->early_start ? 4 : 0) | (yield_for(h, B) << 3);

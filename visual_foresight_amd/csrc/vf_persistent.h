@@ -22,6 +22,7 @@
 #include "vf_conv_bf16x6.h"
 #include "vf_conv_gsplit.h"
 #include "vf_fused_top.h"
+#include "vf_fc_tile.h"
 
 namespace vf {
 
@@ -168,6 +169,9 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void lstm_gsplit
 template <int MREP>
 static __device__ __noinline__ __attribute__((not_tail_called)) void lstm_bf16x6_tile_call(const ConvParams *p, int bx, int by) {
     conv_lstm_bf16x6_tile<MREP>(const_params(p), bx, by, tile_lds());
+}
+static __device__ __noinline__ __attribute__((not_tail_called)) void fc_wide_tile_call(const ConvParams *p, int bx, int bz) {
+    fc_wide_tile(const_params(p), bx, bz, tile_lds());
 }
 template <int ND, bool FIRST>
 static __device__ __noinline__ __attribute__((not_tail_called)) void composite_tile_call(const CompositeParams *p, int tile, int b, int view) {
@@ -365,7 +369,10 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                 case PH_CONVT_RELU: conv_tile_call<4, EPI_CONVT_RELU, 1>(&P.conv, bx, by, 0); break;
                 case PH_CONVT_RAW: conv_tile_call<4, EPI_CONVT_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
                 case PH_FC_PARTIAL:
-                    conv_tile_call<1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx);
+                    // (mrep 7: all eight column groups in one item per (row tile, K split), vf_fc_tile.h - the plan of
+                    // every persistent schedule; the generic tile serves a geometry that one cannot hold)
+                    if (P.mrep == 7) fc_wide_tile_call(&P.conv, bx % P.gx, bx / P.gx);
+                    else conv_tile_call<1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx);
                     break;
                 case PH_CONV_PAIR: conv_tile_call<2, EPI_CONV_PAIR, 1>(&P.conv, bx, 0, 0); break;
                 case PH_TOP_FUSED:
