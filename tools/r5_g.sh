@@ -1,0 +1,12 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5_g; mkdir -p $O
+VF_LIBRARY=build/ab/pre.so timeout 300 python tools/fingerprint.py pre > $O/fingerprint_pre.txt 2>&1; tail -10 $O/fingerprint_pre.txt
+for n in base2 pre base2 pre; do
+  export VF_LIBRARY=build/ab/$n.so
+  python bench.py --samples 25 --no-alt --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | tail -1 > $O/bench_${n}_25.json; python tools/bench_line.py $O/bench_${n}_25.json $n-25
+  python bench.py --samples 50 --no-alt --no-cpu-baseline --steps 8 --warmup 2 2>/dev/null | tail -1 > $O/bench_${n}_50.json; python tools/bench_line.py $O/bench_${n}_50.json $n-50
+  python bench.py --workload c4 --samples 125 --no-alt --no-cpu-baseline --steps 6 --warmup 2 2>/dev/null | tail -1 > $O/bench_${n}_125.json; python tools/bench_line.py $O/bench_${n}_125.json $n-125
+  python bench.py --no-alt --no-cpu-baseline --steps 8 --warmup 2 2>/dev/null | tail -1 > $O/bench_${n}_200.json; python tools/bench_line.py $O/bench_${n}_200.json $n-200
+done
+unset VF_LIBRARY
+VF_LIBRARY=build/ab/trace.so timeout 300 python tools/trace_chain.py 25 > $O/chain_25.txt 2>&1; tail -22 $O/chain_25.txt

@@ -24,6 +24,7 @@ step0 = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 WGS, MAXE, TICK_US = 512, 8192, 0.01
 TR_TICKET, TR_DONE, TR_PHASE, TR_RUN = 1, 3, 21, 32
+TR_STAGE, TR_KLOOP, TR_LATE, TR_LATE_END, TR_EPI = 10, 11, 12, 13, 14
 NAMES = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED', 'CONV_PAIR']
 
 pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2)).restore()
@@ -50,20 +51,40 @@ ev = ev.reshape(WGS, MAXE)
 first = np.full(n_ph, np.inf)
 last = np.zeros(n_ph)
 run_sum, wait_sum, seen = np.zeros(n_ph), np.zeros(n_ph), np.zeros(n_ph, int)
+# the part of an early-started item behind its mid-item wait - what sits on the sample's dependency chain:
+# [late wait, wait end -> first staging (LayerNorm table), staging, K loops, epilogue + publish], n items with a late wait
+tail = np.zeros((n_ph, 5))
+n_late = np.zeros(n_ph, int)
 for w in range(WGS):
     n = int(cnt[w])
     codes = (ev[w, :n] & np.uint64(255)).astype(np.int64)
     vals = (ev[w, :n] >> np.uint64(8)).astype(np.int64)
     t_ticket = t_run = None
     ph = -1
+    seg = []            # (code, time) of the item's events behind TR_LATE
+    t_late = None
     for c, v in zip(codes, vals):
         if c == TR_TICKET:
             t_ticket = v
         elif c >= TR_RUN:
             t_run = v
+            seg, t_late = [], None
         elif c == TR_PHASE:
             ph = int(v)
+        elif c == TR_LATE:
+            t_late = v
+            seg = []
+        elif c in (TR_LATE_END, TR_STAGE, TR_KLOOP, TR_EPI) and t_late is not None:
+            seg.append((int(c), v))
         elif c == TR_DONE and ph >= 0 and t_run is not None:
+            if ph < n_ph and t_late is not None and seg and seg[0][0] == TR_LATE_END:
+                n_late[ph] += 1
+                tail[ph, 0] += seg[0][1] - t_late
+                cur, t_cur = 1, seg[0][1]       # 1 = LayerNorm table, 2 = staging, 3 = K, 4 = epilogue + publish
+                for code, t in seg[1:] + [(TR_DONE, v)]:
+                    tail[ph, cur] += t - t_cur
+                    t_cur = t
+                    cur = {TR_STAGE: 2, TR_KLOOP: 3, TR_EPI: 4}.get(code, cur)
             if ph < n_ph:
                 first[ph] = min(first[ph], t_run)
                 last[ph] = max(last[ph], v)
@@ -88,5 +109,10 @@ for i in range(lo, hi):
     f, l = (first[i] - t0) * TICK_US, (last[i] - t0) * TICK_US
     print('%5d %-11s %6d %9.1f %9.1f %9.1f %10.1f %10.1f' % (i, NAMES[types[i]], items[i], f, l, l - f,
                                                          run_sum[i] / seen[i] * TICK_US, wait_sum[i] / seen[i] * TICK_US))
+print('behind the mid-item wait (us per item): phase type  late-wait | LN table  staging  K loops  epilogue+publish')
+for i in range(lo, hi):
+    if n_late[i]:
+        t = tail[i] / n_late[i] * TICK_US
+        print('%5d %-11s %8.1f | %7.1f %7.1f %7.1f %7.1f   = %.1f on the chain' % (i, NAMES[types[i]], t[0], t[1], t[2], t[3], t[4], t[1:].sum()))
 print('step length: %.1f us' % ((min(first[hi:hi + 3][np.isfinite(first[hi:hi + 3])]) - t0) * TICK_US / nsteps
                                 if hi + 3 <= n_ph else float('nan')))

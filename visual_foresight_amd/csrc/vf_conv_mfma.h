@@ -166,6 +166,11 @@ struct ConvParams {
     // state words (null: off) and how many polls an early-started item may spend yielding to its CU partner
     int *cu_state;
     int yield_budget;
+    // Write-through publish (persistent launch, conv-LSTM tiles with 16-byte epilogue stores): c / h leave the tile as sc1
+    // stores and the LayerNorm partial as agent-scope atomic stores, so the item needs NO release fence before its
+    // completion counter (CDNA guide section 6 G16, recipe R1; a release = buffer_wbl2 costs 1.7 us clean and 6.5 us and
+    // more with the tens of KB a tile has just dirtied in its XCD's L2).  0: plain stores + release fence.
+    int wt_out;
 };
 
 constexpr unsigned kLateSpinLimit = 1u << 26;   // polls before a mid-item wait gives up (as kSpinLimit)
@@ -678,7 +683,9 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
     }
     const int ch = cg * 32 + n;
     float *xch = smem;
-    long long *red = reinterpret_cast<long long *>(smem + kGsXchFloats);
+    // (the reduction scratch lies behind the part of xch this tile height uses: 16 KiB per row block of a round)
+    long long *red = reinterpret_cast<long long *>(smem + (MR < 4 ? MR : 4) * 4 * 16 * 64);
+    const bool wt = p.wt_out != 0;          // write-through publish: sc1 stores, no release fence behind them
 
     // ---- Wave w finishes row block w: 32 pixels x 32 channels.  After the exchange a lane owns FOUR pixels x FOUR
     // consecutive channels (pixel lane / 8 + 8 k, channels 4 (lane % 8) ..): the gates come out of xch as float4 (the
@@ -750,8 +757,13 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
                 cn[e] = c_new; hn[e] = h_new;
                 hstat.add(live ? h_new : 0.f);          // (a dropped pixel adds the integer 0)
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, cn), r_cst, off_o[k], 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, hn), r_out, off_o[k], 0, 0);
+            if (wt) {       // (aux 16 = sc1)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, cn), r_cst, off_o[k], 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, hn), r_out, off_o[k], 0, 16);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, cn), r_cst, off_o[k], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, hn), r_out, off_o[k], 0, 0);
+            }
         }
     }
     // exact integer reduction (the 256-row tile always holds ONE image - plan_geometry - so only the per-tile total is
@@ -769,7 +781,12 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
             }
             long long *dst = p.stats + ((long long)(bimg0 + img) * p.stats_nparts +
                                         (p.NI == 1 ? tile_id * p.ncg + cg : cg)) * 2;
-            dst[0] = su; dst[1] = sq;
+            if (wt) {
+                __hip_atomic_store(dst, su, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                dst[0] = su; dst[1] = sq;
+            }
         }
     }
 }
@@ -1631,6 +1648,9 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     [[maybe_unused]] const unsigned long long ts2 = VF_TS_NOW();
     // (xch = the double-buffered B area: 32 KiB at 32-channel chunks, disjoint from lnTab / red)
     if constexpr (GSPLIT) lstm_gsplit_epilogue<MR>(p, acc, bx, by, smem);
+    // (the 32-row tile: wave w = gate w of its one row block - the gate-split exchange with one row block per round, and
+    // with it the vectorised cell update: 16-byte loads and stores instead of 48 scalar ones per lane)
+    else if constexpr (SPLIT && RB == 1) lstm_gsplit_epilogue<1>(p, acc, bx, by, smem);
     else if constexpr (SPLIT) lstm_split_epilogue<RB>(p, acc, bx, by, red, reinterpret_cast<float *>(bsm));
     else if constexpr (is_top_fused(EPI))
         convt_fused_epilogue<(EPI - EPI_CONVT_FUSED) / 2 + 1, ((EPI - EPI_CONVT_FUSED) & 1) != 0>(p, acc, bx, red, smem);

@@ -38,6 +38,10 @@
 #include "vf_conv_bf16x6.h"
 #include "vf_persistent.h"
 
+#ifndef VF_WT_DEFAULT
+#define VF_WT_DEFAULT 1             // write-through publish of the conv-LSTM tiles (A/B builds: -DVF_WT_DEFAULT=0)
+#endif
+
 namespace vf {
 
 static thread_local std::string g_last_error;
@@ -487,6 +491,7 @@ struct vf_handle {
     bool early_start = true;            // conv-LSTM items start on h(s-1) alone and wait for x(s) mid-item (ConvParams::late_cnt)
     bool fuse_top = true;               // vf_set_fuse_top: top transposed conv + compositing as one item (vf_fused_top.h)
     bool fuse_pair = true;              // ... and enc2 + enc3 as one item (conv_pair_epilogue); follows vf_set_fuse_top
+    bool wt_publish = VF_WT_DEFAULT != 0;   // conv-LSTM tiles publish write-through (ConvParams::wt_out, no release fence)
     int yield_budget = -1;              // cooperative CU priority ("yielding", vf_conv_mfma.h): polls an early-started conv-LSTM
                                         // item may spend yielding to its CU partner; 0 = off, -1 = by batch size (yield_for)
     bool pair_allowed = true;           // (-DVF_DEBUG_KNOBS: VF_FUSE_PAIR=0, read once in vf_create)
@@ -809,6 +814,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
 #endif
 #ifdef VF_DEBUG_KNOBS
     if (const char *e = getenv("VF_YIELD")) h->yield_budget = atoi(e);
+    if (const char *e = getenv("VF_WT")) h->wt_publish = atoi(e) != 0;
     // A/B knob of debug builds, read ONCE per handle (not inside a setter the caller may never invoke)
     static const bool knob_no_pair = getenv("VF_FUSE_PAIR") && atoi(getenv("VF_FUSE_PAIR")) == 0;
     h->pair_allowed = !knob_no_pair;
@@ -1947,21 +1953,23 @@ static int run_steps(vf_handle *h, int view, const BatchView &v, const BatchView
 #define VF_YIELD_DEFAULT 120        // polls of ~0.4 us an item may spend yielding (A/B builds: -DVF_YIELD_DEFAULT=n)
 #endif
 #ifndef VF_YIELD_MAX_ITEMS
-#define VF_YIELD_MAX_ITEMS 5        // ... in launches whose widest conv-LSTM phase has fewer items than this many x slots
+#define VF_YIELD_MAX_ITEMS 3        // ... in launches whose widest conv-LSTM phase has fewer items than this many x CUs
 #endif
 // Yield budget of a launch of B sequences (vf_conv_mfma.h, "yielding").  The scheme pays where a rollout is bound by the
-// per-sample dependency chain - the shards of the multi-GPU configs: 25 x T13 11.57 -> 11.12 ms, 50: 18.98 -> 18.56, 125 x
-// T15: 46.44 -> 46.08 (same box, bit-identical) - and costs a launch that fills the chip 0.5 % (200: 62.75 -> 63.12 ms:
-// there every K loop is somebody's throughput), so it follows the width of the phases: the 64 x 64 network's widest
-// conv-LSTM phase has 8 items per sample (128-row tiles), 512 slots -> on up to ~160 samples per view.
+// per-sample dependency chain - the shards of the multi-GPU configs: 25 x T13 11.57 -> 11.12 ms, 50: 18.98 -> 18.56 (same
+// box, bit-identical) - is a wash from ~100 samples on (100: 32.87 -> 33.37, 125 x T15: 46.44 -> 46.08, 160: equal) and
+// costs a launch that fills the chip 0.5 % (200: 62.75 -> 63.12 ms: there every K loop is somebody's throughput).  So it
+// follows the width of the phases: the widest conv-LSTM phase of the 64 x 64 network has 8 items per sample at 128-row
+// tiles -> on below 96 samples per view.
 static int yield_for(const vf_handle *h, int B) {
     if (!h->early_start) return 0;
     if (h->yield_budget >= 0) return h->yield_budget;
-    const long long widest = (long long)B * h->ncam * ((h->Hc / 2) * (h->Wc / 2) / 128);
-    return widest < (long long)VF_YIELD_MAX_ITEMS * 2 * h->n_cu / 2 ? VF_YIELD_DEFAULT : 0;
+    const long long widest = (long long)B * h->ncam * std::max(1, (h->Hc / 2) * (h->Wc / 2) / 128);
+    return widest < (long long)VF_YIELD_MAX_ITEMS * h->n_cu ? VF_YIELD_DEFAULT : 0;
 }
 static int sched_options(const vf_handle *h, int B) {
-    return (h->fuse_top ? 1 : 0) | (h->fuse_pair ? 2 : 0) | (h->early_start ? 4 : 0) | (yield_for(h, B) << 3);
+    return (h->fuse_top ? 1 : 0) | (h->fuse_pair ? 2 : 0) | (h->early_start ? 4 : 0) | (h->wt_publish ? 8 : 0) |
+           (yield_for(h, B) << 4);
 }
 
 // Are the shared buffers of configuration `cfg` (launch mode and split) still valid?
@@ -2010,6 +2018,9 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
                     P.conv.yield_budget = P.type == PH_LSTM ? yield_for(h, B) : 0;
                 }
             }
+            // the fp32 tiles with 16-byte epilogue stores (gate-split 128 / 64 rows, 32 rows) publish write-through
+            if (P.type == PH_LSTM && h->wt_publish && P.prec == 0 && (P.mrep == 6 || P.mrep == 5 || P.mrep == -1))
+                P.conv.wt_out = 1;
             if (P.type == PH_CONV_PAIR) P.conv.fuse_next = &sc_host.d_phases[i].conv2;
             if (P.type != PH_TOP_FUSED) continue;
             P.conv.fuse_comp = &sc_host.d_phases[i].comp;
