@@ -442,9 +442,11 @@ __device__ __forceinline__ LstmRowAddr lstm_row_addr(const PT &p, const int row,
 
 // Shared epilogue of the fp32 and the split-bf16 tiles: accumulators (MFMA 32x32 C layout) ->
 // bias / activation / cell update / stores + deterministic LayerNorm partial sums.
+constexpr int kEpiVecFloats = 4 * 32 * 36;     // LDS floats of the vectorised light-layer epilogue (wave-private 32 x 36 slabs)
+
 template <int G, int EPI, int MREP, class PT>
 __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G], const int bx, const int by,
-                                              const int bz, long long *red) {
+                                              const int bz, long long *red, float *smem = nullptr) {
     constexpr int WROWS = MREP * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
@@ -497,7 +499,84 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
     // scalar base plus a 32-bit in-image offset per lane; several images: the sample's stride enters through one wide
     // multiply.  (An epilogue next to a K loop pays ~40 cycles per VALU instruction: 64-bit address chains per stored
     // element were most of a transposed conv's item time.)
-    if constexpr (EPI != EPI_LSTM) {
+    // The light layers of the persistent launch / the per-layer kernels (one row block per wave): the outputs leave the
+    // tile as 16-byte stores.  The MFMA layout keeps ONE channel per lane (16 rows of it), so a wave first turns its 32 x 32
+    // block over in a private LDS slab ([row][36]: conflict-free both ways) and every lane then owns four consecutive channels
+    // of four pixels: 4 memory instructions and 4 pixel geometries per gate instead of 16 - and, with ConvParams::wt_out, as
+    // sc1 (write-through) stores, which is what lets the item publish without a release fence (16-byte sc1 stores cost what
+    // plain ones do, 4-byte ones six times as much per byte: CDNA guide, section 6 G16).  Same values, same statistics.
+    constexpr bool kVec = MREP == 1 && (EPI == EPI_BIAS_RELU || EPI == EPI_RAW_STATS || EPI == EPI_CONVT_RELU ||
+                                         EPI == EPI_CONVT_RAW_STATS);
+    if constexpr (kVec) {
+        constexpr bool kT = EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS;
+        constexpr bool kRelu = EPI == EPI_BIAS_RELU || EPI == EPI_CONVT_RELU;
+        constexpr bool kStats = EPI == EPI_RAW_STATS || EPI == EPI_CONVT_RAW_STATS;
+        const bool ni1 = p.NI == 1;
+        const int n_here = ni1 ? (bimg0 < p.B ? 1 : 0) : min(p.NI, p.B - bimg0);
+        const long long out_elems = (long long)(kT ? 4 : 1) * p.Hout * p.Wout * p.Cout;
+        const unsigned out_bytes = (unsigned)out_elems * 4u;
+        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+            p.out + (long long)bimg0 * out_elems, 0, n_here > 0 ? (int)((unsigned)n_here * out_bytes) : 0, 0x00020000);
+        const bool wt = p.wt_out != 0;
+        // ---- values (bias, per-sample bias, relu) and the exact statistics, lane = channel
+        const bool ch_ok = ch < p.Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            int img = 0, rem = row;
+            if (!ni1) { img = div_rpi.div(row); rem = row - img * p.RPI; }
+            const int yy = div_tw.div(rem);
+            const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
+            const bool ok = img < n_here && rem < px_per_img && y < p.Hout && x < p.Wout && ch_ok;
+            float sb = 0.f;
+            if (p.sbias && ok) sb = p.sbias[(long long)(bimg0 + img) * p.sbias_ld + ch];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float v = acc[0][g][r] + bias_g[g];
+                if (p.sbias) v += sb;
+                if (kRelu) v = fmaxf(v, 0.f);
+                acc[0][g][r] = v;
+                if constexpr (kStats) { if (ok) { ssum += stat_q(v); ssq += stat_q2(v); } }
+            }
+        }
+        // ---- where this lane's four pixels (rows lane / 8 + 8 k of the wave's block) go: channels 4 (lane % 8) ..
+        const int pl = lane >> 3, cq = lane & 7;
+        unsigned off_o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = wave * 32 + pl + 8 * k;
+            int img = 0, rem = row;
+            if (!ni1) { img = div_rpi.div(row); rem = row - img * p.RPI; }
+            const int yy = div_tw.div(rem);
+            const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
+            const bool ok = img < n_here && rem < px_per_img && y < p.Hout && x < p.Wout && cg * 32 + 4 * cq < p.Cout;
+            const unsigned in_img = kT ? (unsigned)(((2 * y) * (2 * p.Wout) + 2 * x) * p.Cout + cg * 32 + 4 * cq) * 4u
+                                       : (unsigned)((y * p.Wout + x) * p.Cout + cg * 32 + 4 * cq) * 4u;
+            off_o[k] = ok ? (unsigned)img * out_bytes + in_img : 0xFFFFFFFFu;
+        }
+        __syncthreads();                    // every wave is done reading the operand tile: its LDS becomes the slabs
+        float *T = smem + wave * (32 * 36);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * kh) * 36 + n] = acc[0][g][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned par = kT ? (unsigned)(((g >> 1) * (2 * p.Wout) + (g & 1)) * p.Cout) * 4u : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(T + (pl + 8 * k) * 36 + 4 * cq);
+                const unsigned off = off_o[k] == 0xFFFFFFFFu ? off_o[k] : off_o[k] + par;
+                if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, q), r_out, off, 0, 16);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, q), r_out, off, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    if constexpr (EPI != EPI_LSTM && !kVec) {
         auto rows = [&](auto ni1c) {
             constexpr bool NI1 = decltype(ni1c)::value;
             constexpr bool kT = EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS;
@@ -552,12 +631,20 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
         __syncthreads();
         if (lane == 0) { red[2 * wave] = wsum; red[2 * wave + 1] = wsq; }
         __syncthreads();
+        // (write-through items: the partial leaves as agent-scope atomic stores, like every other output of the tile)
+        auto put = [&](long long *dst, const long long su, const long long sq) {
+            if (p.wt_out != 0) {
+                __hip_atomic_store(dst, su, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                dst[0] = su; dst[1] = sq;
+            }
+        };
         if (p.NI == 1) {
             if (tid == 0 && bimg0 < p.B) {
                 long long su = 0, sq = 0;
                 for (int w = 0; w < 4; ++w) { su += red[2 * w]; sq += red[2 * w + 1]; }
-                long long *dst = p.stats + ((long long)bimg0 * p.stats_nparts + tile_id * p.ncg + cg) * 2;
-                dst[0] = su; dst[1] = sq;
+                put(p.stats + ((long long)bimg0 * p.stats_nparts + tile_id * p.ncg + cg) * 2, su, sq);
             }
         } else {
             // RPI is a multiple of WROWS here: wave w owns image slot (w*WROWS)/RPI entirely or
@@ -569,8 +656,7 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
                 if (img < p.NI && b < p.B) {
                     long long su = 0, sq = 0;
                     for (int w = 0; w < waves_per_img; ++w) { su += red[2 * (wave + w)]; sq += red[2 * (wave + w) + 1]; }
-                    long long *dst = p.stats + ((long long)b * p.stats_nparts + cg) * 2;
-                    dst[0] = su; dst[1] = sq;
+                    put(p.stats + ((long long)b * p.stats_nparts + cg) * 2, su, sq);
                 }
             }
         }
@@ -1655,7 +1741,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     else if constexpr (is_top_fused(EPI))
         convt_fused_epilogue<(EPI - EPI_CONVT_FUSED) / 2 + 1, ((EPI - EPI_CONVT_FUSED) & 1) != 0>(p, acc, bx, red, smem);
     else if constexpr (EPI == EPI_CONV_PAIR) conv_pair_epilogue(p, acc, bx, smem);
-    else conv_epilogue<G, EPI, MREP>(p, acc, bx, by, bz, red);
+    else conv_epilogue<G, EPI, MREP>(p, acc, bx, by, bz, red, smem);
 #ifdef VF_TILE_STATS
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -39,7 +39,7 @@
 #include "vf_persistent.h"
 
 #ifndef VF_WT_DEFAULT
-#define VF_WT_DEFAULT 1             // write-through publish of the conv-LSTM tiles (A/B builds: -DVF_WT_DEFAULT=0)
+#define VF_WT_DEFAULT 3             // write-through publish: bit 0 the conv-LSTM tiles, bit 1 the light layers (A/B: -DVF_WT_DEFAULT=n)
 #endif
 
 namespace vf {
@@ -194,7 +194,9 @@ static size_t conv_lds_bytes(const ConvLayer &l, int KC) {
     const size_t b_lds = (l.mode == PACK_LSTM && l.mrep <= 1) ? (size_t)2 * (KC / 8) * 4 * 64 * 16 : 0;
     // conv-LSTM tiles: LayerNorm gain / offset of every input channel (conv_tile's gbTab)
     const size_t gb_lds = l.mode == PACK_LSTM ? (size_t)2 * round_up(l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0), 4) * 4 : 0;
-    return ((size_t)l.NI * LH * LW * (KC + 4) + 4 * (size_t)l.NI) * 4 + 64 + gb_lds + b_lds;
+    const size_t need = ((size_t)l.NI * LH * LW * (KC + 4) + 4 * (size_t)l.NI) * 4 + 64 + gb_lds + b_lds;
+    // (the light layers' epilogue turns the output tile over in four wave-private LDS slabs: conv_epilogue)
+    return std::max(need, (size_t)vf::kEpiVecFloats * 4 + 64);
 }
 
 // choose tile shape and chunk size for a layer whose GEMM row grid is Hout x Wout
@@ -2021,6 +2023,8 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
             // the fp32 tiles with 16-byte epilogue stores (gate-split 128 / 64 rows, 32 rows) publish write-through
             if (P.type == PH_LSTM && h->wt_publish && P.prec == 0 && (P.mrep == 6 || P.mrep == 5 || P.mrep == -1))
                 P.conv.wt_out = 1;
+            // ... and so do the light layers (conv_epilogue's vectorised form: every conv / transposed-conv tile)
+            if (P.type >= PH_CONV_RELU && P.type <= PH_CONVT_RAW && h->wt_publish && (VF_WT_DEFAULT & 2)) P.conv.wt_out = 1;
             if (P.type == PH_CONV_PAIR) P.conv.fuse_next = &sc_host.d_phases[i].conv2;
             if (P.type != PH_TOP_FUSED) continue;
             P.conv.fuse_comp = &sc_host.d_phases[i].comp;
