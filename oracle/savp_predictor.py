@@ -141,3 +141,99 @@ class OracleSavp(OracleCdna):
         distr_out = torch.stack(out_d, 1).permute(0, 1, 3, 4, 2)[:, :, None]
         return (frames_out.contiguous().numpy(), distr_out.contiguous().numpy(),
                 torch.stack(out_s, 1).numpy())
+
+
+N_WARP2 = 4         # num_transformed_images of the published generator
+
+
+def expected_shapes2(cfg):
+    """Layer table of ``arch = 'savp2'``, stated here from the published generator's structure (the conditioning vector
+    concatenated to the input of every conv-LSTM, four CDNA kernels, seven compositing layers) on this repo's core."""
+    t = expected_shapes(cfg)
+    nsa = cfg.adim + cfg.sdim
+    for k, (cx, ch) in enumerate(((32, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 64), (64, 32))):
+        t['lstm%d/w' % (k + 1)] = (5, 5, cx + nsa + ch, 4 * ch)
+    t['masks/w'], t['masks/b'] = (1, 1, 32, N_WARP2 + 3), (N_WARP2 + 3,)
+    h16, w16 = cfg.height // 16, cfg.width // 16
+    t['cdna/w'], t['cdna/b'] = (h16 * w16 * 128, 25 * N_WARP2), (25 * N_WARP2,)
+    return t
+
+
+class OracleSavp2(OracleSavp):
+    """``arch = 'savp2'``.  PARITY UNPINNED (see the module header).  Restated from arXiv:1804.01523, appendix A, and
+    the structure of the public generator cell it describes, NOT from ``savp_arch.py``:
+
+    * ``state_action_z = concat(action, z, state)`` is tiled over the image and concatenated to the input of every
+      convolutional recurrent layer (``tile_concat([h, state_action_z[:, None, None, :]])`` in front of each conv-LSTM),
+      i.e. the cell convolves ``[x | a, z, s | h_prev]`` with one 5 x 5 kernel;
+    * CDNA kernels: ``dense(flatten(smallest layer)) -> 5 x 5 x num_transformed_images`` (4), ``relu(k - 1e-12) + 1e-12``,
+      normalised over the 25 taps;
+    * compositing: ``transformed = apply_kernels(previous, kernels) + [previous, first context image, scratch]``, masks =
+      channel softmax with one channel per entry of that list IN THAT ORDER, ``next = sum(t * m)``; the designated-pixel
+      distributions go through the same list with the previous distribution standing in for the scratch entry, then
+      they are renormalised over the image.
+    What this class inherits from the arch-1 oracle - layer normalisation, strided / transposed convolutions, channel
+    widths, 1 x 1 heads - are the departures ``savp_arch.Savp2Config`` lists."""
+    expected_shapes = staticmethod(expected_shapes2)
+
+    def _lstm_cond(self, x, cond, state, name, C):
+        c, h = state
+        B, _, hh, ww = x.shape
+        tiled = cond.view(B, -1, 1, 1).expand(B, cond.shape[1], hh, ww)
+        gates = self._conv(torch.cat([x, tiled, h], dim=1), name)
+        i, j, f, o = torch.split(gates, C, dim=1)
+        c_new = c * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+        h_new = torch.tanh(c_new) * torch.sigmoid(o)
+        return h_new, (c_new, h_new)
+
+    def step(self, frame, distrib, state_vec, action, lstm_states, first_frame=None, first_distrib=None):
+        L = LSTM_SIZES
+        B = frame.shape[0]
+        new_states = [None] * 7
+        sa = torch.cat([action, state_vec], dim=1)          # [a, z, s]: the action carries the latent channels
+        lstm = lambda x, k, name: self._lstm_cond(x, sa, lstm_states[k], name, L[k])
+
+        enc00 = F.relu(self._ln(self._conv(frame, 'enc00', 2), 'lna'))
+        enc0 = F.relu(self._ln(self._conv(enc00, 'enc0', 2), 'ln1'))
+        h1, new_states[0] = lstm(enc0, 0, 'lstm1'); h1 = self._ln(h1, 'ln2')
+        h2, new_states[1] = lstm(h1, 1, 'lstm2');   h2 = self._ln(h2, 'ln3')
+        enc1 = F.relu(self._conv(h2, 'enc1', 2))
+        h3, new_states[2] = lstm(enc1, 2, 'lstm3'); h3 = self._ln(h3, 'ln4')
+        h4, new_states[3] = lstm(h3, 3, 'lstm4');   h4 = self._ln(h4, 'ln5')
+        enc2 = F.relu(self._conv(h4, 'enc2', 2))
+        smear = sa.view(B, -1, 1, 1).expand(B, sa.shape[1], enc2.shape[2], enc2.shape[3])
+        enc3 = F.relu(self._conv(torch.cat([enc2, smear], dim=1), 'enc3'))
+        h5, new_states[4] = lstm(enc3, 4, 'lstm5'); h5 = self._ln(h5, 'ln6')
+        enc4 = F.relu(self._convt(h5, 'convt1'))
+        h6, new_states[5] = lstm(enc4, 5, 'lstm6'); h6 = self._ln(h6, 'ln7')
+        enc5 = F.relu(self._convt(torch.cat([h6, enc1], dim=1), 'convt2'))
+        h7, new_states[6] = lstm(enc5, 6, 'lstm7'); h7 = self._ln(h7, 'ln8')
+        enc6 = F.relu(self._ln(self._convt(torch.cat([h7, enc0], dim=1), 'convt3'), 'ln9'))
+        enc7 = F.relu(self._ln(self._convt(torch.cat([enc6, enc00], dim=1), 'convt4'), 'lnb'))
+
+        scratch = torch.sigmoid(self._conv(enc7, 'rgb'))
+        masks = torch.softmax(self._conv(enc7, 'masks'), dim=1)              # [B, 7, H, W], published order
+
+        flat = h5.permute(0, 2, 3, 1).reshape(B, -1)
+        kern = flat @ self.p['cdna/w'] + self.p['cdna/b']
+        kern = F.relu(kern - RELU_SHIFT) + RELU_SHIFT
+        kern = kern.view(B, DNA_KERN * DNA_KERN, N_WARP2)
+        kern = kern / kern.sum(dim=1, keepdim=True)
+        kern = kern.permute(0, 2, 1).reshape(B, N_WARP2, DNA_KERN, DNA_KERN)
+
+        def warp(img):      # [B, C, H, W] -> list of N_WARP2 tensors [B, C, H, W]; correlation, zero padded
+            Bc, C, H, W = img.shape
+            x = _same_pad(img, DNA_KERN, 1).reshape(1, Bc * C, H + 4, W + 4)
+            w = kern.repeat_interleave(C, dim=0).reshape(Bc * C * N_WARP2, 1, DNA_KERN, DNA_KERN)
+            y = F.conv2d(x, w, groups=Bc * C).view(Bc, C, N_WARP2, H, W)
+            return [y[:, :, k] for k in range(N_WARP2)]
+
+        transformed = warp(frame) + [frame, first_frame, scratch]
+        next_frame = sum(t * masks[:, i:i + 1] for i, t in enumerate(transformed))
+        transformed_d = warp(distrib) + [distrib, first_distrib, distrib]
+        next_distrib = sum(t * masks[:, i:i + 1] for i, t in enumerate(transformed_d))
+        next_distrib = next_distrib / next_distrib.sum(dim=(2, 3), keepdim=True)
+
+        next_state = sa @ self.p['state/w'] + self.p['state/b']
+        return next_frame, next_distrib, next_state, new_states
+

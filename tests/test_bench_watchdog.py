@@ -26,7 +26,7 @@ def test_metric_label_names_the_workload():
     import types
     b = bench.Bench.__new__(bench.Bench)
     b.args = types.SimpleNamespace(workload='c2', samples=0, scaling='strong')
-    b.M, b.T, b.H, b.W, b.ncam, b.draws = 200, 13, 64, 64, 1, 0
+    b.M, b.T, b.H, b.W, b.ncam, b.draws, b.ndesig = 200, 13, 64, 64, 1, 0, 1
     assert b.metric_label() == 'predicted frames/sec (whole node), 200-sample x 13-step x 64x64 CEM'
     b.args = types.SimpleNamespace(workload='c5', samples=125, scaling='strong')
     b.M, b.T, b.H, b.W, b.ncam, b.draws = 125, 15, 128, 128, 1, 5
@@ -67,6 +67,8 @@ def test_a_failed_gpu_probe_aborts_instead_of_becoming_a_gloo_dry_run(monkeypatc
         assert 'libamdhip64' in str(e)
     started = []
     monkeypatch.setattr(bench.subprocess, 'Popen', lambda *a, **kw: started.append(a))
+    # (the launcher refuses to run in a process that has imported torch; other tests of this session have)
+    monkeypatch.delitem(bench.sys.modules, 'torch', raising=False)
     assert bench.spawn_ranks(types.SimpleNamespace(gpus=8)) == 3 and not started
 
     def timeout(*a, **kw):
@@ -100,6 +102,7 @@ def test_traffic_is_quoted_only_from_a_profile_of_this_library():
     b = bench.Bench.__new__(bench.Bench)
     b.args = types.SimpleNamespace(workload='c2', samples=0)
     b.world = 1
+    b.ndesig = 1
     matching = [p for p in sorted(glob.glob(os.path.join(bench.REPO, 'profiles', 'r*_hbm_traffic.json')), reverse=True)
                 if json.load(open(p)).get('lib_sources_sha16') == bench.library_hash()]
     roof = {'traffic': None, 'avg_launch_us': 63000.0}

@@ -1,4 +1,6 @@
-"""GPU parity of the SAVP-class generator (vf_config.arch = 1, savp_arch.py) against its CPU oracle.
+"""GPU parity of the SAVP-class generators against their CPU oracles, both architectures: ``savp`` (vf_config.arch = 1,
+SavpConfig / OracleSavp) and ``savp2`` (arch = 2: + the conditioning vector in every conv-LSTM and the published
+seven-layer compositing with four CDNA kernels; Savp2Config / OracleSavp2, restated from arXiv:1804.01523 appendix A).
 
 Parity unpinned (the SAVP source is not part of the reference, oracle/savp_predictor.py); tolerances as
 in test_gpu_parity.py.
@@ -11,16 +13,19 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
 
 from oracle import pixel_cost                                           # noqa: E402
-from oracle.savp_predictor import OracleSavp                            # noqa: E402
-from visual_foresight_amd.video_prediction.savp_arch import SavpConfig, CdnaWeights   # noqa: E402
+from oracle.savp_predictor import OracleSavp, OracleSavp2               # noqa: E402
+from visual_foresight_amd.video_prediction.savp_arch import SavpConfig, Savp2Config, CdnaWeights   # noqa: E402
+
+ARCHS = {'savp': (SavpConfig, OracleSavp), 'savp2': (Savp2Config, OracleSavp2)}
+both_archs = pytest.mark.parametrize('arch', sorted(ARCHS))
 
 
-def _predictor(H, W, T, nd, bs, adim=6, seed=3, **extra):
+def _predictor(H, W, T, nd, bs, adim=6, seed=3, arch='savp', **extra):
     from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
     hp = dict(designated_pixel_count=nd, run_batch_size=bs, adim=adim, sdim=5, image_height=H, image_width=W,
-              sequence_length=T + 2, arch='savp', **extra)
+              sequence_length=T + 2, arch=arch, **extra)
     pred = HipVPredEvaluation('', hp)
-    cfg = SavpConfig(height=H, width=W, adim=adim, ndesig=nd, sequence_length=T + 2)
+    cfg = ARCHS[arch][0](height=H, width=W, adim=adim, ndesig=nd, sequence_length=T + 2)
     weights = CdnaWeights.random(cfg, seed=seed, bias_scale=0.05, ln_jitter=0.1)
     pred.restore(weights)
     return pred, weights
@@ -37,14 +42,17 @@ def _context(H, W, nd, adim, rs, hist=3):
 
 
 def _oracle(weights, ctx, actions, dtype=torch.float32):
-    return OracleSavp(weights, dtype).rollout(ctx['context_frames'], ctx['context_actions'],
+    return ARCHS[weights.cfg.arch][1](weights, dtype).rollout(ctx['context_frames'], ctx['context_actions'],
                                               ctx['context_pixel_distributions'], ctx['context_states'], actions)
 
 
-@pytest.mark.parametrize('H,W,T,M,nd', [(64, 64, 3, 5, 1), (48, 80, 2, 4, 2), (128, 128, 2, 3, 1), (32, 32, 3, 7, 4)])
-def test_savp_rollout_matches_oracle(H, W, T, M, nd):
+@pytest.mark.parametrize('arch,H,W,T,M,nd', [('savp', 64, 64, 3, 5, 1), ('savp', 48, 80, 2, 4, 2), ('savp', 128, 128, 2, 3, 1),
+                                             ('savp', 32, 32, 3, 7, 4), ('savp2', 64, 64, 3, 5, 1), ('savp2', 64, 80, 2, 4, 2),
+                                             ('savp2', 128, 128, 2, 3, 1), ('savp2', 64, 64, 2, 7, 4),
+                                             ('savp2', 64, 64, 3, 33, 1)])
+def test_savp_rollout_matches_oracle(arch, H, W, T, M, nd):
     adim = 6
-    pred, weights = _predictor(H, W, T, nd, bs=M, adim=adim)
+    pred, weights = _predictor(H, W, T, nd, bs=M, adim=adim, arch=arch)
     rs = np.random.RandomState(H + W + T + M)
     ctx = _context(H, W, nd, adim, rs)
     actions = rs.normal(0, 0.1, (M, T, adim))
@@ -63,7 +71,8 @@ def test_savp_rollout_matches_oracle(H, W, T, M, nd):
     assert pred.device_status() == 0
 
 
-def test_savp_launch_strategies_and_chunking_are_bit_identical():
+@both_archs
+def test_savp_launch_strategies_and_chunking_are_bit_identical(arch):
     """Persistent launch == per-layer launches == ragged chunks == one XCD queue, bit for bit; context
     de-duplication off gives the same bits too."""
     H = W = 64
@@ -72,13 +81,13 @@ def test_savp_launch_strategies_and_chunking_are_bit_identical():
     ctx = _context(H, W, 1, 6, rs)
     actions = rs.normal(0, 0.1, (M, T, 6))
     goal = np.array([[[10, 50]]])
-    pred, weights = _predictor(H, W, T, 1, bs=M)
+    pred, weights = _predictor(H, W, T, 1, bs=M, arch=arch)
     base, _ = pred.score(ctx, {'actions': actions}, goal)
     base_out = pred(ctx, {'actions': actions})
     for kw in (dict(persistent=0), dict(xcd_queues=0), dict(dedup=0), dict(run_batch_size=9), dict(fuse_top=0)):
         hp = dict(kw)
         bs = hp.pop('run_batch_size', M)
-        other, _ = _predictor(H, W, T, 1, bs=bs, **hp)
+        other, _ = _predictor(H, W, T, 1, bs=bs, arch=arch, **hp)
         got, _ = other.score(ctx, {'actions': actions}, goal)
         np.testing.assert_array_equal(got, base, err_msg=str(kw))
         out = other(ctx, {'actions': actions})
@@ -105,16 +114,17 @@ def test_savp_split_bf16_mode_matches_oracle():
     np.testing.assert_allclose(scores, want, rtol=1e-5)
 
 
-def test_savp_two_views_one_launch():
+@both_archs
+def test_savp_two_views_one_launch(arch):
     """Two views of the SAVP-class network in one engine (own weights per view, one launch), against the per-view
     oracle; persistent and per-layer launches agree bit for bit."""
     from visual_foresight_amd.video_prediction.multiview_predictor import MultiViewHipPredictor
-    H, W = 32, 48
+    H, W = (32, 48) if arch == 'savp' else (64, 80)
     T, M, nd, ncam, adim = 2, 5, 2, 2, 6
     hp = dict(designated_pixel_count=nd, run_batch_size=M, adim=adim, sdim=5, image_height=H, image_width=W,
-              sequence_length=T + 2, ncam=ncam, arch='savp')
+              sequence_length=T + 2, ncam=ncam, arch=arch)
     pred = MultiViewHipPredictor('', hp)
-    cfg = SavpConfig(height=H, width=W, adim=adim, ndesig=nd, sequence_length=T + 2)
+    cfg = ARCHS[arch][0](height=H, width=W, adim=adim, ndesig=nd, sequence_length=T + 2)
     weights = [CdnaWeights.random(cfg, seed=20 + c, bias_scale=0.05, ln_jitter=0.1) for c in range(ncam)]
     pred.restore(weights)
     rs = np.random.RandomState(31)
@@ -144,7 +154,8 @@ def test_savp_two_views_one_launch():
     assert pred.device_status() == 0
 
 
-def test_savp_fused_top_at_128_matches_the_per_layer_launches():
+@both_archs
+def test_savp_fused_top_at_128_matches_the_per_layer_launches(arch):
     """128x128: 32 transposed-conv tiles per sample wait for each other inside the fused decoder top; the
     persistent launch (fused) and the per-layer launches (never fused) agree bit for bit."""
     H = W = 128
@@ -153,7 +164,7 @@ def test_savp_fused_top_at_128_matches_the_per_layer_launches():
     ctx = _context(H, W, 2, 6, rs)
     actions = rs.normal(0, 0.1, (M, T, 6))
     goal = np.array([[[100, 20], [7, 77]]])
-    pred, _ = _predictor(H, W, T, 2, bs=M)
+    pred, _ = _predictor(H, W, T, 2, bs=M, arch=arch)
     fused, fused_pt = pred.score(ctx, {'actions': actions}, goal)
     out_fused = pred(ctx, {'actions': actions})
     pred.set_persistent(0)
@@ -166,7 +177,8 @@ def test_savp_fused_top_at_128_matches_the_per_layer_launches():
     assert pred.device_status() == 0
 
 
-def test_savp_tile_plans_are_invisible_in_the_results():
+@both_archs
+def test_savp_tile_plans_are_invisible_in_the_results(arch):
     """Arch 1 at 128x128 (64x64 conv-LSTM core): the same 160 sequences rolled as one batch (256-row tiles on the two
     widest conv-LSTMs), in chunks of 70 (128-row tiles) and in chunks of 30 (64- / 32-row tiles) give identical bits
     for scores and materialised predictions - the arch-1 counterpart of
@@ -180,7 +192,7 @@ def test_savp_tile_plans_are_invisible_in_the_results():
     goal = np.array([[[13, 100], [90, 9]]])
     outs = []
     for bs in (M, 70, 30):
-        pred, _ = _predictor(H, W, T, 2, bs=bs)
+        pred, _ = _predictor(H, W, T, 2, bs=bs, arch=arch)
         s, pt = pred.score(ctx, {'actions': actions}, goal)
         got = pred(ctx, {'actions': actions[:20]})
         outs.append((s, pt, got['predicted_frames'], got['predicted_pixel_distributions']))

@@ -3,7 +3,7 @@
 # summaries into profiles/ afterwards).  usage: tools/run_profiles.sh <tag>
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-tag=${1:-r04}
+tag=${1:-r05}
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 cd $R
@@ -33,6 +33,8 @@ python bench.py --workload c4 --samples 125 --no-alt --no-cpu-baseline --steps 8
 python bench.py --workload c4 --no-alt --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_c4_1gpu.json; python tools/bench_line.py $O/bench_c4_1gpu.json c4-1gpu
 python bench.py --samples 25 --no-alt --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | tail -1 > $O/bench_c2_shard25.json; python tools/bench_line.py $O/bench_c2_shard25.json c2-shard25
 python bench.py --workload c5 --samples 125 --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_c5_shard125.json; python tools/bench_line.py $O/bench_c5_shard125.json c5-shard
+python bench.py --ndesig 4 --no-alt --no-cpu-baseline --steps 8 --warmup 2 2>/dev/null | tail -1 > $O/bench_c2_nd4.json; python tools/bench_line.py $O/bench_c2_nd4.json c2-nd4
+python bench.py --samples 50 --no-alt --no-cpu-baseline --steps 8 --warmup 2 2>/dev/null | tail -1 > $O/bench_c2_shard50.json; python tools/bench_line.py $O/bench_c2_shard50.json c2-shard50
 # 5. phase statistics, two-rank dry run
 python tools/persist_stats.py 200 > $O/phase_stats_200.txt 2>&1
 python tools/persist_stats.py 25 > $O/phase_stats_25.txt 2>&1

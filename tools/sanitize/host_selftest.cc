@@ -22,7 +22,7 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
 
 static int run_case(int H, int W, int adim, int sdim, int nd, int nctx, int T, int max_batch, int precision, int ncam,
                     int n_draws, const int *batches, int n_batches, int arch = 0) {
-    vf_config cfg = {H, W, adim, sdim, nd, nctx, nctx + T, 10, max_batch, 0, precision, ncam, n_draws, arch};
+    vf_config cfg = {H, W, adim, sdim, nd, nctx, nctx + T, arch == 2 ? 6 : 10, max_batch, 0, precision, ncam, n_draws, arch};
     const size_t n = vf_weight_count(&cfg);
     if (n == 0) { std::fprintf(stderr, "weight count failed: %s\n", vf_last_error()); return 1; }
     std::vector<float> blob(n * (size_t)ncam);
@@ -72,6 +72,10 @@ int main() {
     // arch 1: the SAVP-class four-scale generator (config 5 shard and a small odd shape)
     rc |= run_case(128, 128, 12, 5, 1, 2, 15, 125, 0, 1, 5, b_c2 + 1, 2, 1);
     rc |= run_case(48, 80, 6, 3, 2, 2, 2, 37, 1, 2, 1, b_small, 4, 1);
+    // arch 2: arch 1 + the conditioning vector in every conv-LSTM (PH_COND items) + the seven-layer compositing
+    rc |= run_case(128, 128, 12, 5, 1, 2, 15, 125, 0, 1, 5, b_c2 + 1, 2, 2);
+    rc |= run_case(64, 80, 6, 3, 2, 2, 2, 37, 0, 2, 1, b_small, 4, 2);
+    rc |= run_case(64, 64, 12, 5, 3, 1, 2, 16, 0, 1, 1, b_small, 3, 2);
     // invalid configurations are refused, not crashed on
     vf_config bad = {60, 64, 4, 5, 1, 2, 15, 10, 8, 0, 0, 1, 1, 0};
     vf_handle *h = nullptr;
@@ -80,6 +84,10 @@ int main() {
     if (vf_create(&bad2, &h) == 0) { std::fprintf(stderr, "ncam 5 accepted\n"); rc = 1; }
     vf_config bad3 = {72, 64, 4, 5, 1, 2, 15, 10, 8, 0, 0, 1, 1, 1};       // arch 1 needs multiples of 16
     if (vf_create(&bad3, &h) == 0) { std::fprintf(stderr, "arch 1 at 72x64 accepted\n"); rc = 1; }
+    vf_config bad4 = {64, 64, 12, 5, 1, 2, 15, 10, 8, 0, 0, 1, 1, 2};      // arch 2 composes four warps: num_masks 6
+    if (vf_create(&bad4, &h) == 0) { std::fprintf(stderr, "arch 2 with num_masks 10 accepted\n"); rc = 1; }
+    vf_config bad5 = {64, 64, 12, 5, 1, 2, 15, 6, 8, 0, 1, 1, 1, 2};       // arch 2 is fp32 only
+    if (vf_create(&bad5, &h) == 0) { std::fprintf(stderr, "arch 2 in the split-bf16 mode accepted\n"); rc = 1; }
     std::printf(rc ? "HOST SELFTEST FAILED\n" : "HOST SELFTEST OK\n");
     return rc;
 }

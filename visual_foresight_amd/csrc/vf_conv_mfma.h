@@ -96,12 +96,15 @@ enum Epilogue {
     EPI_CONVT_RAW_STATS = 4,  // depth-to-space, acc + bias, + LayerNorm partial sums
     EPI_PARTIAL = 5,          // raw accumulators of one K split
     EPI_CONVT_FUSED = 6,      // top transposed conv whose tile is composed into the next frame right away
-                              // (vf_fused_top.h); 6 + 2 * (designated pixels - 1) + (arch 1 first-frame layer)
-    EPI_CONV_PAIR = 20        // a conv whose whole-image tiles feed a 1x1 conv in the same item (conv_pair_epilogue: enc2 ->
+                              // (vf_fused_top.h); 6 + 2 * (designated pixels - 1) + (arch 1 / 2 first-frame layer)
+                              // + 8 for the six-kernel compositing of arch 2 (four CDNA warps + previous + first + scratch)
+    EPI_CONV_PAIR = 30        // a conv whose whole-image tiles feed a 1x1 conv in the same item (conv_pair_epilogue: enc2 ->
                               // enc3, the 8 x 8 bottleneck; G = 2: both 32-channel groups of the first conv in one workgroup)
 };
 __host__ __device__ constexpr bool is_top_fused(int epi) { return epi >= EPI_CONVT_FUSED && epi < EPI_CONV_PAIR; }
-__host__ __device__ constexpr int fused_epi(int nd, bool first) { return EPI_CONVT_FUSED + 2 * (nd - 1) + (first ? 1 : 0); }
+__host__ __device__ constexpr int fused_epi(int nd, bool first, bool k6 = false) {
+    return EPI_CONVT_FUSED + 2 * (nd - 1) + (first ? 1 : 0) + (k6 ? 8 : 0);
+}
 
 struct ConvSeg {
     const float *ptr;       // NHWC activations of this input segment
@@ -171,6 +174,9 @@ struct ConvParams {
     // completion counter (CDNA guide section 6 G16, recipe R1; a release = buffer_wbl2 costs 1.7 us clean and 6.5 us and
     // more with the tens of KB a tile has just dirtied in its XCD's L2).  0: plain stores + release fence.
     int wt_out;
+    // arch 2: the per-sample border-class biases of the tiled conditioning vector, [B][25][4 Cout] (cond_bias_sample,
+    // vf_small_kernels.h), added to the gate pre-activations in the conv-LSTM epilogue; null: none
+    const float *cond_bias;
 };
 
 constexpr unsigned kLateSpinLimit = 1u << 26;   // polls before a mid-item wait gives up (as kSpinLimit)
@@ -823,6 +829,27 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
             c_old[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_cin, off_c, 0, 0));
         }
         __syncthreads();                    // the operand tile / the previous round's gates are no longer read
+        if (p.cond_bias != nullptr) {
+            // arch 2: + the conditioning bias of each row's border class (lane = gate column wave * Cout + ch; the class
+            // is uniform over each half of the wave, the 32 lanes of a half read 128 consecutive bytes)
+            const int C4 = 4 * p.Cout, col = wave * p.Cout + ch;
+            const float *cb = p.cond_bias + (long long)bimg0 * (25 * C4) + col;
+#pragma unroll
+            for (int m = 0; m < RBR; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (half * RBR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    int img = 0, rem = row;
+                    if (!ni1) { img = div_rpi.div(row); rem = row - img * p.RPI; }
+                    const int yy = div_tw.div(rem);
+                    const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
+                    const bool ok = img < n_here && rem < p.TH * p.TW && y < p.Hout && x < p.Wout;
+                    const int cy = y < 2 ? y : (y >= p.Hout - 2 ? y - (p.Hout - 5) : 2);
+                    const int cx = x < 2 ? x : (x >= p.Wout - 2 ? x - (p.Wout - 5) : 2);
+                    const float add = ok ? cb[(long long)(img * 25 + cy * 5 + cx) * C4] : 0.f;
+                    acc[half * RBR + m][0][r] = acc[half * RBR + m][0][r] + add;
+                }
+        }
 #pragma unroll
         for (int m = 0; m < RBR; ++m)
 #pragma unroll
@@ -976,7 +1003,7 @@ __device__ __forceinline__ void conv_pair_epilogue(const PT &p, f32x16 (&acc)[1]
 // 128 - and wave w takes row block w % RB and RB of the four gates, for batches so small that the per-sample
 // dependency chain, not the throughput, bounds a rollout; same chunking and K order, i.e. the same bits.
 // epilogue of EPI_CONVT_FUSED, defined in vf_fused_top.h (it needs the compositing code)
-template <int ND, bool FIRST, class PT>
+template <int ND, bool FIRST, int K, class PT>
 __device__ __forceinline__ void convt_fused_epilogue(const PT &p, f32x16 (&acc)[1][4], int bx, long long *red, float *smem);
 
 template <int G, int EPI, int MREP, class PT, int RB = 4>
@@ -1739,7 +1766,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     else if constexpr (SPLIT && RB == 1) lstm_gsplit_epilogue<1>(p, acc, bx, by, smem);
     else if constexpr (SPLIT) lstm_split_epilogue<RB>(p, acc, bx, by, red, reinterpret_cast<float *>(bsm));
     else if constexpr (is_top_fused(EPI))
-        convt_fused_epilogue<(EPI - EPI_CONVT_FUSED) / 2 + 1, ((EPI - EPI_CONVT_FUSED) & 1) != 0>(p, acc, bx, red, smem);
+        convt_fused_epilogue<((EPI - EPI_CONVT_FUSED) & 7) / 2 + 1, ((EPI - EPI_CONVT_FUSED) & 1) != 0,
+                             (EPI - EPI_CONVT_FUSED) >= 8 ? 6 : 10>(p, acc, bx, red, smem);
     else if constexpr (EPI == EPI_CONV_PAIR) conv_pair_epilogue(p, acc, bx, smem);
     else conv_epilogue<G, EPI, MREP>(p, acc, bx, by, bz, red, smem);
 #ifdef VF_TILE_STATS

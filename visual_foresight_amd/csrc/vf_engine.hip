@@ -80,6 +80,8 @@ struct TensorDesc {
     }
 };
 
+static int a_of(const vf_config &c) { return c.adim + c.sdim; }
+
 static std::vector<TensorDesc> tensor_table(const vf_config &c) {
     std::vector<TensorDesc> t;
     size_t off = 0;
@@ -102,30 +104,34 @@ static std::vector<TensorDesc> tensor_table(const vf_config &c) {
     };
     const int *L = kLstmSizes;
     const int a = c.adim + c.sdim, K = c.num_masks;
-    // arch 1 (savp_arch.py): one more encoder / decoder scale around the three-scale core
-    const bool savp = c.arch == 1;
+    // arch 1 / 2 (savp_arch.py): one more encoder / decoder scale around the three-scale core; arch 2: the conditioning
+    // vector [action, latent, state] is an input of every conv-LSTM (canonical channel order [x | cond | h])
+    const bool savp = c.arch >= 1;
+    const int cc = c.arch == 2 ? a_of(c) : 0;
     const int Hc = savp ? c.height / 2 : c.height, Wc = savp ? c.width / 2 : c.width;
     const int fc_in = (Hc / 8) * (Wc / 8) * L[4];
     if (savp) { conv("enc00", 5, 5, 3, kEnc00Ch); ln("lna", kEnc00Ch); }
     conv("enc0", 5, 5, savp ? kEnc00Ch : 3, 32); ln("ln1", 32);
-    conv("lstm1", 5, 5, 32 + L[0], 4 * L[0]);  ln("ln2", L[0]);
-    conv("lstm2", 5, 5, L[0] + L[1], 4 * L[1]); ln("ln3", L[1]);
+    conv("lstm1", 5, 5, 32 + cc + L[0], 4 * L[0]);  ln("ln2", L[0]);
+    conv("lstm2", 5, 5, L[0] + cc + L[1], 4 * L[1]); ln("ln3", L[1]);
     conv("enc1", 3, 3, L[1], L[1]);
-    conv("lstm3", 5, 5, L[1] + L[2], 4 * L[2]); ln("ln4", L[2]);
-    conv("lstm4", 5, 5, L[2] + L[3], 4 * L[3]); ln("ln5", L[3]);
+    conv("lstm3", 5, 5, L[1] + cc + L[2], 4 * L[2]); ln("ln4", L[2]);
+    conv("lstm4", 5, 5, L[2] + cc + L[3], 4 * L[3]); ln("ln5", L[3]);
     conv("enc2", 3, 3, L[3], L[3]);
     conv("enc3", 1, 1, L[3] + a, L[3]);
-    conv("lstm5", 5, 5, L[3] + L[4], 4 * L[4]); ln("ln6", L[4]);
+    conv("lstm5", 5, 5, L[3] + cc + L[4], 4 * L[4]); ln("ln6", L[4]);
     conv("convt1", 3, 3, L[4], L[4]);
-    conv("lstm6", 5, 5, L[4] + L[5], 4 * L[5]); ln("ln7", L[5]);
+    conv("lstm6", 5, 5, L[4] + cc + L[5], 4 * L[5]); ln("ln7", L[5]);
     conv("convt2", 3, 3, L[5] + L[1], L[5]);
-    conv("lstm7", 5, 5, L[5] + L[6], 4 * L[6]); ln("ln8", L[6]);
+    conv("lstm7", 5, 5, L[5] + cc + L[6], 4 * L[6]); ln("ln8", L[6]);
     conv("convt3", 3, 3, L[6] + 32, 32);        ln("ln9", 32);
     if (savp) { conv("convt4", 3, 3, 32 + kEnc00Ch, 32); ln("lnb", 32); }
     conv("rgb", 1, 1, 32, 3);
     conv("masks", 1, 1, 32, K + 1);
-    add("cdna/w", {fc_in, kTaps * K});
-    add("cdna/b", {kTaps * K});
+    // arch 2: the FOUR CDNA kernels of the published generator (the engine pads them to its num_masks = 6 slots at load)
+    const int KF = c.arch == 2 ? K - 2 : K;
+    add("cdna/w", {fc_in, kTaps * KF});
+    add("cdna/b", {kTaps * KF});
     add("state/w", {a, c.sdim});
     add("state/b", {c.sdim});
     return t;
@@ -388,6 +394,8 @@ struct BatchView {
     float *c_state[7], *h_state[7][2];
     long long *st_enc0, *st_h[7], *st_enc6, *st_enc00, *st_enc7;
     float *sbias, *fc_part, *kern;
+    float *cond_bias[7][2];             // (two buffers, by step parity: the biases of step s + 1 are computed while the
+                                        //  epilogues of step s still read theirs)
     float *frames_all, *distrib_all, *states_all;
     double *sums;
     const float *actions;
@@ -401,6 +409,7 @@ struct ViewData {
     float *ln_g[kNumLn] = {nullptr}, *ln_b[kNumLn] = {nullptr};    // ln1..ln9, lna (enc00), lnb (convt4)
     float *w_rgb = nullptr, *b_rgb = nullptr, *w_mask = nullptr, *b_mask = nullptr;
     float *w_state = nullptr, *b_state = nullptr, *w_sa = nullptr, *b_fc = nullptr;
+    float *w_cond[7] = {nullptr};       // arch 2: conditioning rows of every conv-LSTM's weights, [25][adim + sdim][4C]
     float *ctx_frames = nullptr, *ctx_distrib = nullptr;
 };
 
@@ -410,7 +419,9 @@ struct AllocRec { void *p; size_t bytes; };
 struct vf_handle {
     vf_config cfg;
     int H, W, T, S, ND, K;              // S = steps per rollout = T + n_context - 1
-    bool savp = false;                  // vf_config.arch == 1: four-scale SAVP-class generator (savp_arch.py)
+    bool savp = false;                  // vf_config.arch >= 1: four-scale SAVP-class generator (savp_arch.py)
+    bool cond = false;                  // vf_config.arch == 2: [action, latent, state] conditions every conv-LSTM
+    float *cond_bias[7] = {nullptr};    // ... through per-sample border-class biases [2 step parities][ncam][max_batch][25][4C]
     int Hc, Wc;                         // input size of the three-scale conv-LSTM core (H, W; arch 1: H/2, W/2)
     int ncam = 1, n_draws = 1;
     int ntiles;                         // composite tiles per image
@@ -565,22 +576,29 @@ static int validate(const vf_config *c) {
         return fail(VF_ERR_INVALID, "need n_context >= 1 and sequence_length > n_context");
     if (c->adim < 1 || c->sdim < 1 || c->adim + c->sdim > 32)
         return fail(VF_ERR_INVALID, "need adim, sdim >= 1 and adim + sdim <= 32");
-    if (c->num_masks != 10) return fail(VF_ERR_INVALID, "num_masks must be 10 in this build");
+    if (c->arch == 2 ? c->num_masks != 6 : c->num_masks != 10)
+        return fail(VF_ERR_INVALID, "num_masks must be 10 (arch 0 / 1) or 6 (arch 2: four CDNA warps + previous + first + scratch)");
     if (c->max_batch < 1) return fail(VF_ERR_INVALID, "max_batch must be >= 1");
     if (c->precision != 0 && c->precision != 1) return fail(VF_ERR_INVALID, "precision must be 0 (fp32) or 1 (split bf16)");
     if (c->ncam < 0 || c->ncam > kMaxCam) return fail(VF_ERR_INVALID, "ncam must be 1..4 (0 = 1)");
     if (c->n_draws < 0) return fail(VF_ERR_INVALID, "n_draws must be >= 1 (0 = 1)");
     if (c->n_draws > 1 && c->max_batch % c->n_draws)
         return fail(VF_ERR_INVALID, "max_batch must be a multiple of n_draws");
-    if (c->arch != 0 && c->arch != 1) return fail(VF_ERR_INVALID, "arch must be 0 (CDNA) or 1 (SAVP-class, four scales)");
-    if (c->arch == 1 && (c->height % 16 || c->width % 16))
-        return fail(VF_ERR_INVALID, "arch 1 needs height/width that are multiples of 16");
+    if (c->arch < 0 || c->arch > 2)
+        return fail(VF_ERR_INVALID, "arch must be 0 (CDNA), 1 (SAVP-class, four scales) or 2 (1 + per-layer conditioning, "
+                                    "published compositing)");
+    if (c->arch >= 1 && (c->height % 16 || c->width % 16))
+        return fail(VF_ERR_INVALID, "arch 1 / 2 need height/width that are multiples of 16");
+    if (c->arch == 2 && c->precision != 0)
+        return fail(VF_ERR_INVALID, "arch 2 is built for precision 0 (exact fp32) only");
+    if (c->arch == 2 && (c->height < 64 || c->width < 64))
+        return fail(VF_ERR_INVALID, "arch 2 needs images of at least 64 x 64 (border classes of the 8 x 8 bottleneck)");
     return VF_OK;
 }
 
 static void init_layer(ConvLayer &l, const char *name, PackMode mode, int Hin, int Win, int Hout, int Wout,
                        int KH, int KW, int stride, int pad, int c0, int c1, int Cout, bool stats,
-                       bool fc = false, int mrep = 1, int prec = 0, bool second_first = false) {
+                       bool fc = false, int mrep = 1, int prec = 0, bool second_first = false, int cond_ch = 0) {
     l.name = name; l.mode = mode; l.G = (mode == PACK_PLAIN) ? 1 : 4; l.mrep = prec == 1 ? 1 : mrep; l.prec = prec;
     l.Hin = Hin; l.Win = Win; l.Hout = Hout; l.Wout = Wout;
     l.KH = KH; l.KW = KW; l.stride = stride; l.pad = pad;
@@ -590,8 +608,8 @@ static void init_layer(ConvLayer &l, const char *name, PackMode mode, int Hin, i
     // encoder skip tensor of a decoder conv (second_first) become segment 0: they exist early (ConvParams::late_cnt)
     if (mode == PACK_LSTM || (second_first && c1 > 0)) {
         l.segC[0] = c1; l.segC[1] = c0;
-        l.seg_off[0] = c0; l.seg_off[1] = 0;
-    }
+        l.seg_off[0] = c0 + cond_ch; l.seg_off[1] = 0;     // (arch 2: the conditioning rows sit between x and h and are NOT
+    }                                                       //  part of the GEMM: CondParams, vf_small_kernels.h)
     l.Cout = Cout; l.ncg = (Cout + 31) / 32;
     l.nsplit = 1; l.n_valid = Cout;
     plan_geometry(l, stats, fc);
@@ -750,7 +768,7 @@ size_t vf_weight_count(const vf_config *cfg) {
 
 double vf_macs_per_sample_step(const vf_config *cfg) {
     if (validate(cfg)) return 0.0;
-    const bool savp = cfg->arch == 1;
+    const bool savp = cfg->arch >= 1;
     const int HF = cfg->height, WF = cfg->width;            // full resolution: heads and warps
     const int H = savp ? HF / 2 : HF, W = savp ? WF / 2 : WF;   // core
     auto t = tensor_table(*cfg);
@@ -768,7 +786,7 @@ double vf_macs_per_sample_step(const vf_config *cfg) {
     }
     const TensorDesc *fc = find_tensor(t, "cdna/w"), *sw = find_tensor(t, "state/w");
     macs += (double)fc->shape[0] * fc->shape[1] + (double)sw->shape[0] * sw->shape[1];
-    macs += (double)HF * WF * kTaps * (3 + cfg->ndesig) * cfg->num_masks;
+    macs += (double)HF * WF * kTaps * (3 + cfg->ndesig) * (cfg->arch == 2 ? cfg->num_masks - 2 : cfg->num_masks);
     return macs;
 }
 
@@ -790,7 +808,8 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     h->S = h->T + cfg->n_context - 1;
     h->table = tensor_table(*cfg);
     h->blob_floats = h->table.back().offset + h->table.back().size();
-    h->savp = cfg->arch == 1;
+    h->savp = cfg->arch >= 1;
+    h->cond = cfg->arch == 2;
     h->Hc = h->savp ? h->H / 2 : h->H; h->Wc = h->savp ? h->W / 2 : h->W;
     const int H = h->H, W = h->W, Bc = cfg->max_batch, ND = h->ND, NV = h->ncam;
     const size_t BV = (size_t)Bc * NV;          // samples x views: rows of every per-sample buffer
@@ -822,27 +841,28 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     h->pair_allowed = !knob_no_pair;
     h->fuse_pair = h->fuse_pair && h->pair_allowed;
 #endif
+    const int ccond = h->cond ? cfg->adim + cfg->sdim : 0;     // conditioning rows in every conv-LSTM's canonical weights
     if (h->savp) {
         init_layer(h->enc00, "enc00", PACK_PLAIN, H, W, Hc, Wc, 5, 5, 2, 1, 3, 0, kEnc00Ch, true);
         init_layer(h->convt4, "convt4", PACK_CONVT, Hc, Wc, Hc, Wc, 2, 2, 1, 1, 32, kEnc00Ch, 32, true, false, 1, 0, true);
     }
     init_layer(h->enc0, "enc0", PACK_PLAIN, Hc, Wc, H2, W2, 5, 5, 2, 1, h->savp ? kEnc00Ch : 3, 0, 32, true);
-    init_layer(h->lstm[0], "lstm1", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, 32, L[0], L[0], true, false, lstm_mrep[0], cfg->precision);
-    init_layer(h->lstm[1], "lstm2", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[0], L[1], L[1], true, false, lstm_mrep[1], cfg->precision);
+    init_layer(h->lstm[0], "lstm1", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, 32, L[0], L[0], true, false, lstm_mrep[0], cfg->precision, false, ccond);
+    init_layer(h->lstm[1], "lstm2", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[0], L[1], L[1], true, false, lstm_mrep[1], cfg->precision, false, ccond);
     init_layer(h->enc1, "enc1", PACK_PLAIN, H2, W2, H4, W4, 3, 3, 2, 0, L[1], 0, L[1], false);
-    init_layer(h->lstm[2], "lstm3", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[1], L[2], L[2], true, false, lstm_mrep[2], cfg->precision);
-    init_layer(h->lstm[3], "lstm4", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[2], L[3], L[3], true, false, lstm_mrep[3], cfg->precision);
+    init_layer(h->lstm[2], "lstm3", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[1], L[2], L[2], true, false, lstm_mrep[2], cfg->precision, false, ccond);
+    init_layer(h->lstm[3], "lstm4", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[2], L[3], L[3], true, false, lstm_mrep[3], cfg->precision, false, ccond);
     init_layer(h->enc2, "enc2", PACK_PLAIN, H4, W4, H8, W8, 3, 3, 2, 0, L[3], 0, L[3], false);
     init_layer(h->enc3, "enc3", PACK_PLAIN, H8, W8, H8, W8, 1, 1, 1, 0, L[3], 0, L[3], false);
-    init_layer(h->lstm[4], "lstm5", PACK_LSTM, H8, W8, H8, W8, 5, 5, 1, 2, L[3], L[4], L[4], true, false, lstm_mrep[4], cfg->precision);
+    init_layer(h->lstm[4], "lstm5", PACK_LSTM, H8, W8, H8, W8, 5, 5, 1, 2, L[3], L[4], L[4], true, false, lstm_mrep[4], cfg->precision, false, ccond);
     init_layer(h->convt1, "convt1", PACK_CONVT, H8, W8, H8, W8, 2, 2, 1, 1, L[4], 0, L[4], false);
     h->enc2_one.ni_cap = h->enc3_one.ni_cap = h->convt1_one.ni_cap = 1;
     init_layer(h->enc2_one, "enc2", PACK_PLAIN, H4, W4, H8, W8, 3, 3, 2, 0, L[3], 0, L[3], false);
     init_layer(h->enc3_one, "enc3", PACK_PLAIN, H8, W8, H8, W8, 1, 1, 1, 0, L[3], 0, L[3], false);
     init_layer(h->convt1_one, "convt1", PACK_CONVT, H8, W8, H8, W8, 2, 2, 1, 1, L[4], 0, L[4], false);
-    init_layer(h->lstm[5], "lstm6", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[4], L[5], L[5], true, false, lstm_mrep[5], cfg->precision);
+    init_layer(h->lstm[5], "lstm6", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[4], L[5], L[5], true, false, lstm_mrep[5], cfg->precision, false, ccond);
     init_layer(h->convt2, "convt2", PACK_CONVT, H4, W4, H4, W4, 2, 2, 1, 1, L[5], L[1], L[5], false, false, 1, 0, true);
-    init_layer(h->lstm[6], "lstm7", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[5], L[6], L[6], true, false, lstm_mrep[6], cfg->precision);
+    init_layer(h->lstm[6], "lstm7", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[5], L[6], L[6], true, false, lstm_mrep[6], cfg->precision, false, ccond);
     init_layer(h->convt3, "convt3", PACK_CONVT, H2, W2, H2, W2, 2, 2, 1, 1, L[6], 32, 32, true, false, 1, 0, true);
     // CDNA FC as a K-split GEMM over 1x1 "images"
     init_layer(h->fc, "cdna", PACK_PLAIN, 1, 1, 1, 1, 1, 1, 1, 0, H8 * W8 * L[4], 0, kTaps * h->K, false, true, 2);
@@ -867,7 +887,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         if (!h->have_big) continue;
         const ConvLayer &sm = h->lstm[k];
         init_layer(h->lstm_big[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[1],
-                   sm.segC[0], sm.Cout, true, false, 2, 0);
+                   sm.segC[0], sm.Cout, true, false, 2, 0, false, ccond);
         // same chunking = same K order per output (bit-identical results) and the same packed weights
 #ifdef VF_DEBUG_KNOBS
         h->big_ok[k] = h->lstm_big[k].KC == sm.KC;
@@ -876,14 +896,14 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
 #endif
         if (h->big_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_big[k].stats_nparts);
         init_layer(h->lstm_half[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2, sm.segC[1],
-                   sm.segC[0], sm.Cout, true, false, 0, 0);
+                   sm.segC[0], sm.Cout, true, false, 0, 0, false, ccond);
         h->half_ok[k] = h->lstm_half[k].KC == sm.KC && sm.KC == 32;
 #ifndef VF_DEBUG_KNOBS
         h->half_ok[k] = h->half_ok[k] && h->lstm_half[k].gsplit;     // the only 64-row tile of a production build
 #endif
         if (h->half_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_half[k].stats_nparts);
         init_layer(h->lstm_quarter[k], sm.name.c_str(), PACK_LSTM, sm.Hin, sm.Win, sm.Hout, sm.Wout, 5, 5, 1, 2,
-                   sm.segC[1], sm.segC[0], sm.Cout, true, false, -1, 0);
+                   sm.segC[1], sm.segC[0], sm.Cout, true, false, -1, 0, false, ccond);
         h->quarter_ok[k] = h->lstm_quarter[k].KC == sm.KC && sm.KC == 32;
         if (h->quarter_ok[k]) h->st_rows[k] = std::max(h->st_rows[k], h->lstm_quarter[k].stats_nparts);
     }
@@ -934,6 +954,8 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         VF_ALLOC(vd.w_mask, 32 * (h->K + 1)); VF_ALLOC(vd.b_mask, h->K + 1);
         VF_ALLOC(vd.w_state, (size_t)nsa * cfg->sdim); VF_ALLOC(vd.b_state, cfg->sdim);
         VF_ALLOC(vd.w_sa, (size_t)nsa * L[3]); VF_ALLOC(vd.b_fc, kTaps * h->K);
+        if (h->cond)
+            for (int k = 0; k < 7; ++k) VF_ALLOC(vd.w_cond[k], (size_t)kTaps * nsa * 4 * L[k]);
     }
     VF_ALLOC(h->ctx_frames_all, (size_t)NV * nc * H * W * 3);
     VF_ALLOC(h->ctx_distrib_all, (size_t)NV * nc * H * W * ND);
@@ -968,6 +990,8 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     VF_ALLOC(h->st_enc0, BV * h->enc0.stats_nparts * 2);
     VF_ALLOC(h->st_enc6, BV * h->convt3.stats_nparts * 2);
     VF_ALLOC(h->sbias, BV * L[3]);
+    if (h->cond)
+        for (int k = 0; k < 7; ++k) VF_ALLOC(h->cond_bias[k], 2 * BV * kCondClasses * 4 * L[k]);
     VF_ALLOC(h->fc_part, BV * h->fc.nsplit * kTaps * h->K);
     VF_ALLOC(h->kern, BV * kTaps * h->K);
     VF_ALLOC(h->frames_all, BV * h->T * H * W * 3);
@@ -977,8 +1001,8 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     h->sums_step_stride = h->sums_view_stride * NV;
     VF_ALLOC(h->sums, (size_t)h->T * h->sums_step_stride);
     VF_ALLOC(h->actions_buf, (size_t)Bc * h->T * cfg->adim);
-    h->sched_capacity = ((size_t)h->S * 24 + 8) * NV;
-    h->counter_capacity = ((size_t)h->S * 24 + 8) * ((size_t)Bc + 1) * NV;
+    h->sched_capacity = ((size_t)h->S * 32 + 8) * NV;       // (arch 2: up to 29 phases per step)
+    h->counter_capacity = ((size_t)h->S * 32 + 8) * ((size_t)Bc + 1) * NV;
     VF_ALLOC(h->sched[0].d_phases, h->sched_capacity);
     VF_ALLOC(h->sched[1].d_phases, h->sched_capacity);
     VF_ALLOC(h->d_sync, kSyncHead + h->counter_capacity);
@@ -1006,6 +1030,11 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
             VF_ALLOC(sv.st_enc00, (size_t)h->enc00.stats_nparts * 2);
         }
         VF_ALLOC(sv.sbias, (size_t)L[3]);
+        if (h->cond)
+            for (int k = 0; k < 7; ++k) {
+                VF_ALLOC(sv.cond_bias[k][0], (size_t)2 * kCondClasses * 4 * L[k]);
+                sv.cond_bias[k][1] = sv.cond_bias[k][0] + (size_t)kCondClasses * 4 * L[k];
+            }
         h->shared_views.push_back(sv);
     }
 #undef VF_ALLOC
@@ -1072,7 +1101,18 @@ int vf_load_weights(vf_handle *h, const float *blob_all, size_t n_floats) {
             const ConvLayer &l = *lp;
             const TensorDesc *w = T(l.name + "/w"), *b = T(l.name + "/b");
             std::vector<float> wp, bp;
-            if (l.name == "cdna") {
+            if (l.name == "cdna" && h->cond) {
+                // canonical [fc_in][25 x 4] -> the engine's [fc_in][25 x 6]: two dead kernels of zero weights (they meet a
+                // zero mask in the compositing), so every kernel-count-dependent stride stays num_masks
+                const int KF = h->K - 2, fc_in = w->shape[0];
+                std::vector<float> wide((size_t)fc_in * kTaps * h->K, 0.f);
+                for (int r = 0; r < fc_in; ++r)
+                    for (int tap = 0; tap < kTaps; ++tap)
+                        for (int k = 0; k < KF; ++k)
+                            wide[((size_t)r * kTaps + tap) * h->K + k] = (blob + w->offset)[((size_t)r * kTaps + tap) * KF + k];
+                wp = pack_weights(l, wide.data(), 1, 1, fc_in, kTaps * h->K);
+                bp.assign(l.packed_b(), 0.f);
+            } else if (l.name == "cdna") {
                 wp = pack_weights(l, blob + w->offset, 1, 1, w->shape[0], w->shape[1]);
                 bp.assign(l.packed_b(), 0.f);       // bias is added by cdna_finalize
             } else if (l.name == "enc3") {
@@ -1104,11 +1144,42 @@ int vf_load_weights(vf_handle *h, const float *blob_all, size_t n_floats) {
         const TensorDesc *d;
         d = T("rgb/w");   if ((rc = dev_write(h, vd.w_rgb, blob + d->offset, d->size() * sizeof(float)))) return rc;
         d = T("rgb/b");   if ((rc = dev_write(h, vd.b_rgb, blob + d->offset, d->size() * sizeof(float)))) return rc;
-        d = T("masks/w"); if ((rc = dev_write(h, vd.w_mask, blob + d->offset, d->size() * sizeof(float)))) return rc;
-        d = T("masks/b"); if ((rc = dev_write(h, vd.b_mask, blob + d->offset, d->size() * sizeof(float)))) return rc;
+        {   // mask head.  arch 2 keeps the PUBLISHED order of the compositing layers in the checkpoint - [four CDNA warps,
+            // previous frame, first frame, scratch] - and the kernels' order on the device: [previous, scratch, first, warps]
+            const TensorDesc *mw = T("masks/w"), *mb = T("masks/b");
+            const int NM = h->K + 1;
+            std::vector<float> w(mw->size()), bb(mb->size());
+            for (int j = 0; j < NM; ++j) {
+                const int src = !h->cond ? j : (j == 0 ? NM - 3 : (j == 1 ? NM - 1 : (j == 2 ? NM - 2 : j - 3)));
+                for (int c = 0; c < 32; ++c) w[(size_t)c * NM + j] = (blob + mw->offset)[(size_t)c * NM + src];
+                bb[j] = (blob + mb->offset)[src];
+            }
+            if ((rc = dev_write(h, vd.w_mask, w.data(), w.size() * sizeof(float)))) return rc;
+            if ((rc = dev_write(h, vd.b_mask, bb.data(), bb.size() * sizeof(float)))) return rc;
+        }
+        if (h->cond) {      // conditioning rows [tap][Cx + c][4C] of every conv-LSTM's canonical [5][5][Cx + nsa + Ch][4C]
+            const int nsa = h->cfg.adim + h->cfg.sdim;
+            for (int k = 0; k < 7; ++k) {
+                const ConvLayer &l = h->lstm[k];
+                const TensorDesc *w = T(l.name + "/w");
+                const int Cin = w->shape[2], C4 = w->shape[3], Cx = l.segC[1];
+                std::vector<float> wc((size_t)kTaps * nsa * C4);
+                for (int tap = 0; tap < kTaps; ++tap)
+                    for (int c = 0; c < nsa; ++c)
+                        memcpy(&wc[((size_t)tap * nsa + c) * C4], blob + w->offset + ((size_t)tap * Cin + Cx + c) * C4,
+                               (size_t)C4 * sizeof(float));
+                if ((rc = dev_write(h, vd.w_cond[k], wc.data(), wc.size() * sizeof(float)))) return rc;
+            }
+        }
         d = T("state/w"); if ((rc = dev_write(h, vd.w_state, blob + d->offset, d->size() * sizeof(float)))) return rc;
         d = T("state/b"); if ((rc = dev_write(h, vd.b_state, blob + d->offset, d->size() * sizeof(float)))) return rc;
-        d = T("cdna/b");  if ((rc = dev_write(h, vd.b_fc, blob + d->offset, d->size() * sizeof(float)))) return rc;
+        d = T("cdna/b");
+        if (h->cond) {
+            std::vector<float> bw((size_t)kTaps * h->K, 0.f);
+            for (int tap = 0; tap < kTaps; ++tap)
+                for (int k = 0; k < h->K - 2; ++k) bw[(size_t)tap * h->K + k] = (blob + d->offset)[(size_t)tap * (h->K - 2) + k];
+            if ((rc = dev_write(h, vd.b_fc, bw.data(), bw.size() * sizeof(float)))) return rc;
+        } else if ((rc = dev_write(h, vd.b_fc, blob + d->offset, d->size() * sizeof(float)))) return rc;
         // enc3 rows [L3 .. L3+adim+sdim) x 64: the smeared action/state inputs
         d = T("enc3/w");
         const int L3 = kLstmSizes[3];
@@ -1180,6 +1251,10 @@ static BatchView make_view(vf_handle *h, int view, const float *d_actions, int b
     v.st_enc0 = h->st_enc0 + b * h->enc0.stats_nparts * 2;
     v.st_enc6 = h->st_enc6 + b * h->convt3.stats_nparts * 2;
     v.sbias = h->sbias + b * L[3];
+    if (h->cond)
+        for (int k = 0; k < 7; ++k)
+            for (int par = 0; par < 2; ++par)
+                v.cond_bias[k][par] = h->cond_bias[k] + ((size_t)par * c.max_batch * h->ncam + b) * kCondClasses * 4 * L[k];
     v.fc_part = h->fc_part + b * h->fc.nsplit * kTaps * h->K;
     v.kern = h->kern + b * kTaps * h->K;
     v.frames_all = h->frames_all + b * T * H * W * 3;
@@ -1226,8 +1301,13 @@ struct LaunchSink {
             default: return launch_conv_t<1, EPI_PARTIAL>(l, p, st);
         }
     }
-    int lstm(const ConvLayer &l, const ConvParams &p, int /*u_prev*/, int /*u_x*/) { return conv(PH_LSTM, l, p, {}); }
-    int conv_late(int type, const ConvLayer &l, const ConvParams &p, int /*u_early*/, int /*u_late*/) { return conv(type, l, p, {}); }
+    int lstm(const ConvLayer &l, const ConvParams &p, int /*u_prev*/, int /*u_x*/, int /*u_cond*/ = -1) { return conv(PH_LSTM, l, p, {}); }
+    int cond(const CondParams &p, std::initializer_list<int>) {
+        hipLaunchKernelGGL(cond_bias_kernel, dim3(p.B), dim3(256), 0, st, p);
+        VF_HIP_CHECK(hipGetLastError());
+        return VF_OK;
+    }
+    int conv_late(int type, const ConvLayer &l, const ConvParams &p, int /*u_early*/, int /*u_late*/, int /*u_extra*/ = -1) { return conv(type, l, p, {}); }
     static bool pair_capable() { return false; }    // one launch per layer: enc2 and enc3 stay two kernels
     static const ConvLayer &fc_plan(const vf_handle *h) { return h->fc; }
     int conv_pair(const ConvLayer &, const ConvParams &, const ConvLayer &, const ConvParams &, std::initializer_list<int>) {
@@ -1243,11 +1323,20 @@ struct LaunchSink {
     }
     int composite(const CompositeParams &p, int ntiles, int /*view*/, std::initializer_list<int>) {
         dim3 grid(ntiles, p.B);
-        switch (p.ND) {
-            case 1: hipLaunchKernelGGL((composite_kernel<1, 10>), grid, dim3(256), 0, st, p); break;
-            case 2: hipLaunchKernelGGL((composite_kernel<2, 10>), grid, dim3(256), 0, st, p); break;
-            case 3: hipLaunchKernelGGL((composite_kernel<3, 10>), grid, dim3(256), 0, st, p); break;
-            default: hipLaunchKernelGGL((composite_kernel<4, 10>), grid, dim3(256), 0, st, p); break;
+        if (p.K == 6) {         // arch 2: four CDNA warps + previous + first frame + scratch
+            switch (p.ND) {
+                case 1: hipLaunchKernelGGL((composite_kernel<1, 6>), grid, dim3(256), 0, st, p); break;
+                case 2: hipLaunchKernelGGL((composite_kernel<2, 6>), grid, dim3(256), 0, st, p); break;
+                case 3: hipLaunchKernelGGL((composite_kernel<3, 6>), grid, dim3(256), 0, st, p); break;
+                default: hipLaunchKernelGGL((composite_kernel<4, 6>), grid, dim3(256), 0, st, p); break;
+            }
+        } else {
+            switch (p.ND) {
+                case 1: hipLaunchKernelGGL((composite_kernel<1, 10>), grid, dim3(256), 0, st, p); break;
+                case 2: hipLaunchKernelGGL((composite_kernel<2, 10>), grid, dim3(256), 0, st, p); break;
+                case 3: hipLaunchKernelGGL((composite_kernel<3, 10>), grid, dim3(256), 0, st, p); break;
+                default: hipLaunchKernelGGL((composite_kernel<4, 10>), grid, dim3(256), 0, st, p); break;
+            }
         }
         VF_HIP_CHECK(hipGetLastError());
         return VF_OK;
@@ -1276,7 +1365,7 @@ struct ScheduleSink {
         else {
             dp.mode = (Q.B == 1) ? 1 : 0;       // a batch-1 producer is shared by every sample
             switch (Q.type) {
-                case PH_SA: case PH_CDNA_FIN: dp.expect = 1; break;
+                case PH_SA: case PH_CDNA_FIN: case PH_COND: dp.expect = 1; break;
                 case PH_COMPOSITE: dp.expect = Q.gx; break;
                 default: dp.expect = (Q.NI == 1 ? Q.tiles_per_img : 1) * Q.gy;
             }
@@ -1299,14 +1388,23 @@ struct ScheduleSink {
     // conv-LSTM of one step: u_prev = the same cell at the previous step (producer of the recurrent input and of the
     // cell state), u_x = the producer of the layer input.  Early start: the item is released by u_prev alone and
     // waits for u_x after its recurrent chunks (ConvParams::late_cnt; the counters' address is patched in at upload).
-    int lstm(const ConvLayer &l, const ConvParams &p, int u_prev, int u_x) { return conv_late(PH_LSTM, l, p, u_prev, u_x); }
+    int lstm(const ConvLayer &l, const ConvParams &p, int u_prev, int u_x, int u_cond = -1) {
+        return conv_late(PH_LSTM, l, p, u_prev, u_x, u_cond);
+    }
+    // arch 2: the border-class biases of the tiled conditioning vector for one conv-LSTM, one item per sample
+    int cond(const CondParams &p, std::initializer_list<int> deps) {
+        PhaseDesc P;
+        memset(&P, 0, sizeof(P));
+        P.type = PH_COND; P.cond = p; P.B = p.B;
+        return add(P, p.B, p.B, deps);
+    }
     // a two-input tile whose segment 0 comes from u_early and whose segment 1 from u_late (decoder convs: the encoder
     // skip tensor first, the previous layer's output late)
-    int conv_late(int type, const ConvLayer &l, const ConvParams &p, int u_early, int u_late) {
+    int conv_late(int type, const ConvLayer &l, const ConvParams &p, int u_early, int u_late, int u_extra = -1) {
         const bool late = early_start && u_late >= 0 && u_late != kSkipped;
-        if (!late) return conv(type, l, p, {u_early, u_late});
+        if (!late) return conv(type, l, p, {u_early, u_late, u_extra});
         const PhaseDep ld = dep_on(phases[u_late]);
-        const int u = conv(type, l, p, {u_early});
+        const int u = conv(type, l, p, {u_early, u_extra});
         if (u >= 0) { phases[u].has_late = 1; phases[u].late = ld; }
         return u;
     }
@@ -1474,8 +1572,11 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
     };
     auto all_shared = [&](int s) { return h->dedup && s < nc - 1; };
     auto enc_shared = [&](int s) { return h->dedup && s < nc; };
+    // (arch 2: the action conditions every conv-LSTM, so at step n_context - 1 only the convs in front of lstm1 still see
+    // the same input for every sample)
+    auto core_shared = [&](int s) { return h->cond ? all_shared(s) : enc_shared(s); };
     // is the output of lstm k at step s one shared image?  (s < 0: the shared zero state)
-    auto lstm_shared = [&](int k, int s) { return s < 0 || all_shared(s) || (k < 4 && enc_shared(s)); };
+    auto lstm_shared = [&](int k, int s) { return s < 0 || all_shared(s) || (k < 4 && core_shared(s)); };
 
     auto plain = [](const float *ptr, long long bs) {
         SegArg s; memset(&s, 0, sizeof(s)); s.ptr = ptr; s.bstride = bs; s.gamma_mod = 1; return s;
@@ -1494,15 +1595,17 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
 #define VF_EMIT_SH(var, shared, expr) VF_EMIT(var, ((shared) && skip_shared) ? Sink::skipped() : (expr))
 
     int last = -1;      // terminal unit of the previous step
+    int u_sa_prev = -1; // state FC of the previous step (arch 2: producer of the state the conditioning biases read)
     int u_prev[7] = {-1, -1, -1, -1, -1, -1, -1};   // conv-LSTM k of the previous step
     for (int s = 0; s < h->S; ++s) {
         const int cur = s & 1, nxt = cur ^ 1;
         const bool produce = s >= nc - 1;
         const int t_out = s - (nc - 1);
-        const bool enc_sh = enc_shared(s), all_sh = all_shared(s);
-        const BatchView &E = enc_sh ? sh : v;       // encoder tensors of this step
+        const bool enc0_sh = enc_shared(s), enc_sh = core_shared(s), all_sh = all_shared(s);
+        const BatchView &E0 = enc0_sh ? sh : v;     // enc00 / enc0: the convs in front of lstm1
+        const BatchView &E = enc_sh ? sh : v;       // the other encoder tensors of this step
         const BatchView &D = all_sh ? sh : v;       // tensors from enc3 on
-        const int BE = enc_sh ? 1 : B, BD = all_sh ? 1 : B;
+        const int BE0 = enc0_sh ? 1 : B, BE = enc_sh ? 1 : B, BD = all_sh ? 1 : B;
         auto bs = [](bool shared, long long per) { return shared ? 0LL : per; };
 
         // ---- state FC + action/state bias of enc3
@@ -1518,6 +1621,24 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         sp.sbias = D.sbias;
         VF_EMIT_SH(u_sa, all_sh, sink.sa(sp, {last}))
 
+        // ---- arch 2: the conditioning biases of this step's seven conv-LSTMs (inputs: this step's action / latent and
+        // the state the PREVIOUS step's state FC produced - so they run a step ahead of their consumers' epilogues)
+        int u_cond[7] = {-1, -1, -1, -1, -1, -1, -1};
+        if (h->cond) {
+            for (int k = 0; k < 7; ++k) {
+                const bool shd = lstm_shared(k, s);
+                CondParams cq; memset(&cq, 0, sizeof(cq));
+                cq.action = sp.action; cq.action_bstride = sp.action_bstride;
+                cq.state = sp.state; cq.state_bstride = sp.state_bstride;
+                cq.adim = c.adim; cq.sdim = c.sdim; cq.B = shd ? 1 : B;
+                cq.w = vd.w_cond[k]; cq.C4 = 4 * L[k];
+                cq.out = (shd ? sh : v).cond_bias[k][s & 1];
+                VF_EMIT_SH(u_ck, shd, sink.cond(cq, {u_sa_prev}))
+                u_cond[k] = u_ck;
+            }
+            u_sa_prev = u_sa;
+        }
+
         // ---- encoder
         const float *frame_in; long long frame_bs;
         if (s < nc) { frame_in = vd.ctx_frames + (size_t)s * H * W * 3; frame_bs = 0; }
@@ -1527,20 +1648,20 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         int u_enc00 = last;
         SegArg enc00_n = plain(nullptr, 0);
         if (h->savp) {      // extra encoder scale: enc00 = relu(LNa(conv5x5/2(frame))), applied on staging
-            p = params(h->enc00, BE, plain(frame_in, frame_bs), nullptr);
-            p.out = E.enc00_o; p.stats = E.st_enc00;
-            VF_EMIT_SH(u_e00, enc_sh, sink.conv(PH_CONV_RAW, h->enc00, p, {last}))
+            p = params(h->enc00, BE0, plain(frame_in, frame_bs), nullptr);
+            p.out = E0.enc00_o; p.stats = E0.st_enc00;
+            VF_EMIT_SH(u_e00, enc0_sh, sink.conv(PH_CONV_RAW, h->enc00, p, {last}))
             u_enc00 = u_e00;
-            enc00_n = normed(E.enc00_o, bs(enc_sh, (long long)Hc * Wc * kEnc00Ch), E.st_enc00, h->enc00.stats_nparts,
-                             h->enc00.stats_nparts, enc_sh, (long long)Hc * Wc * kEnc00Ch, vd.ln_g[9], vd.ln_b[9],
+            enc00_n = normed(E0.enc00_o, bs(enc0_sh, (long long)Hc * Wc * kEnc00Ch), E0.st_enc00, h->enc00.stats_nparts,
+                             h->enc00.stats_nparts, enc0_sh, (long long)Hc * Wc * kEnc00Ch, vd.ln_g[9], vd.ln_b[9],
                              kEnc00Ch, 1);
         }
-        p = params(h->enc0, BE, h->savp ? enc00_n : plain(frame_in, frame_bs), nullptr);
-        p.out = E.enc0_o; p.stats = E.st_enc0;
-        VF_EMIT_SH(u_enc0, enc_sh, sink.conv(PH_CONV_RAW, h->enc0, p, {u_enc00}))
+        p = params(h->enc0, BE0, h->savp ? enc00_n : plain(frame_in, frame_bs), nullptr);
+        p.out = E0.enc0_o; p.stats = E0.st_enc0;
+        VF_EMIT_SH(u_enc0, enc0_sh, sink.conv(PH_CONV_RAW, h->enc0, p, {u_enc00}))
 
-        SegArg enc0_n = normed(E.enc0_o, bs(enc_sh, (long long)H2 * W2 * 32), E.st_enc0, h->enc0.stats_nparts,
-                               h->enc0.stats_nparts, enc_sh, (long long)H2 * W2 * 32, vd.ln_g[0], vd.ln_b[0], 32, 1);
+        SegArg enc0_n = normed(E0.enc0_o, bs(enc0_sh, (long long)H2 * W2 * 32), E0.st_enc0, h->enc0.stats_nparts,
+                               h->enc0.stats_nparts, enc0_sh, (long long)H2 * W2 * 32, vd.ln_g[0], vd.ln_b[0], 32, 1);
         // LayerNorm index: ln1 = enc0, ln2..ln8 = lstm1..7, ln9 = convt3
         auto h_normed = [&](int k) {        // normalised new hidden state of lstm k at this step
             const bool shd = lstm_shared(k, s);
@@ -1558,6 +1679,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
             q.out = O.h_state[k][nxt]; q.cstate = O.c_state[k]; q.stats = O.st_h[k];
             q.stats_nparts = h->st_rows[k];
             q.cstate_in = I.c_state[k]; q.cin_bstride = bs(in_sh, per);
+            if (h->cond) q.cond_bias = O.cond_bias[k][s & 1];
 #ifdef VF_DEBUG_KNOBS
             // TIMING ONLY (wrong results): the recurrent half of every conv-LSTM item vanishes - an upper bound on what
             // taking it off the per-sample dependency chain could give a small shard (round 4, EXPERIMENTS.md)
@@ -1566,16 +1688,16 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
 #endif
             return q;
         };
-        VF_EMIT_SH(u_l1, lstm_shared(0, s), sink.lstm(lstm_plan(0, lstm_shared(0, s) ? 1 : B), lstm_params(0, enc0_n), u_prev[0], u_enc0))
-        VF_EMIT_SH(u_l2, lstm_shared(1, s), sink.lstm(lstm_plan(1, lstm_shared(1, s) ? 1 : B), lstm_params(1, h_normed(0)), u_prev[1], u_l1))
+        VF_EMIT_SH(u_l1, lstm_shared(0, s), sink.lstm(lstm_plan(0, lstm_shared(0, s) ? 1 : B), lstm_params(0, enc0_n), u_prev[0], u_enc0, u_cond[0]))
+        VF_EMIT_SH(u_l2, lstm_shared(1, s), sink.lstm(lstm_plan(1, lstm_shared(1, s) ? 1 : B), lstm_params(1, h_normed(0)), u_prev[1], u_l1, u_cond[1]))
 
         p = params(h->enc1, BE, h_normed(1), nullptr);
         p.out = E.enc1_o;
         VF_EMIT_SH(u_enc1, enc_sh, sink.conv(PH_CONV_RELU, h->enc1, p, {u_l2}))
 
         VF_EMIT_SH(u_l3, lstm_shared(2, s), sink.lstm(lstm_plan(2, lstm_shared(2, s) ? 1 : B),
-                                lstm_params(2, plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]))), u_prev[2], u_enc1))
-        VF_EMIT_SH(u_l4, lstm_shared(3, s), sink.lstm(lstm_plan(3, lstm_shared(3, s) ? 1 : B), lstm_params(3, h_normed(2)), u_prev[3], u_l3))
+                                lstm_params(2, plain(E.enc1_o, bs(enc_sh, (long long)H4 * W4 * L[1]))), u_prev[2], u_enc1, u_cond[2]))
+        VF_EMIT_SH(u_l4, lstm_shared(3, s), sink.lstm(lstm_plan(3, lstm_shared(3, s) ? 1 : B), lstm_params(3, h_normed(2)), u_prev[3], u_l3, u_cond[3]))
 
         const ConvLayer &enc2_l = light_plan(h->enc2, h->enc2_one, BE);
         const ConvLayer &enc3_l = light_plan(h->enc3, h->enc3_one, BD);
@@ -1604,7 +1726,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         }
 
         VF_EMIT_SH(u_l5, lstm_shared(4, s), sink.lstm(lstm_plan(4, lstm_shared(4, s) ? 1 : B),
-                                lstm_params(4, plain(D.enc3_o, bs(all_sh, (long long)H8 * W8 * L[3]))), u_prev[4], u_enc3))
+                                lstm_params(4, plain(D.enc3_o, bs(all_sh, (long long)H8 * W8 * L[3]))), u_prev[4], u_enc3, u_cond[4]))
         SegArg h5n = h_normed(4);
 
         // ---- decoder
@@ -1613,7 +1735,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         p.out = D.enc4_o;
         VF_EMIT_SH(u_t1, all_sh, sink.conv(PH_CONVT_RELU, convt1_l, p, {u_l5}))
         VF_EMIT_SH(u_l6, lstm_shared(5, s), sink.lstm(lstm_plan(5, lstm_shared(5, s) ? 1 : B),
-                                lstm_params(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))), u_prev[5], u_t1))
+                                lstm_params(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))), u_prev[5], u_t1, u_cond[5]))
 
         // ---- CDNA kernels (only needed when this step's prediction is used).  The FC needs lstm5 of EVERY sample
         // and its only consumer is the compositing at the end of the step: it is emitted here, behind lstm6, where
@@ -1634,7 +1756,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         p.out = D.enc5_o;
         VF_EMIT_SH(u_t2, all_sh, sink.conv_late(PH_CONVT_RELU, h->convt2, p, u_enc1, u_l6))
         VF_EMIT_SH(u_l7, lstm_shared(6, s), sink.lstm(lstm_plan(6, lstm_shared(6, s) ? 1 : B),
-                                lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))), u_prev[6], u_t2))
+                                lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))), u_prev[6], u_t2, u_cond[6]))
         last = u_l7;
         {
             const int now[7] = {u_l1, u_l2, u_l3, u_l4, u_l5, u_l6, u_l7};
@@ -1865,6 +1987,11 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
         } else if (P.type == PH_SA) {
             ok = ok && in_allocs(h, P.sa.sbias, (size_t)P.B * P.sa.n_out * 4) && in_allocs(h, P.sa.action, 4) &&
                  in_allocs(h, P.sa.state, 4);
+        } else if (P.type == PH_COND) {
+            ok = ok && in_allocs(h, P.cond.out, (size_t)P.B * kCondClasses * P.cond.C4 * 4) &&
+                 in_allocs(h, P.cond.w, (size_t)kTaps * (P.cond.adim + P.cond.sdim) * P.cond.C4 * 4) &&
+                 in_allocs(h, P.cond.action, 4) && in_allocs(h, P.cond.state, 4);
+        } else if (P.type == PH_CONV_PAIR) {
         } else {
             ok = ok && in_allocs(h, P.fin.partial, (size_t)P.fin.nsplit * P.B * kTaps * P.fin.K * 4) &&
                  in_allocs(h, P.fin.kern, (size_t)P.B * kTaps * P.fin.K * 4);

@@ -32,10 +32,9 @@ __host__ __device__ inline size_t fused_top_lds_floats(int TH, int TW, int ND) {
     return (size_t)256 * kCompEncPad + halo * comp_px_stride(ND) + (size_t)kTaps * kCompKernPad + 16 + 64;
 }
 
-template <int ND, bool FIRST, class PT, class CT>
+template <int ND, bool FIRST, int K, class PT, class CT>
 __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 (&acc)[1][4], const int bx,
                                                long long *red, float *smem, const int *goal) {
-    constexpr int K = 10;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kh = lane >> 5;
     const int tiles_per_img = p.tilesY * p.tilesX;
@@ -278,7 +277,7 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
 
 // epilogue hook of conv_tile<4, fused_epi(ND, FIRST), 1>: the compositing parameters (a device address inside the
 // schedule) are read through the constant address space, the goal pixels from the launch's LDS control block
-template <int ND, bool FIRST, class PT>
+template <int ND, bool FIRST, int K, class PT>
 __device__ __forceinline__ void convt_fused_epilogue(const PT &p, f32x16 (&acc)[1][4], int bx, long long *red, float *smem) {
     typedef const __attribute__((address_space(4))) CompositeParams CT;
     const unsigned long long a = reinterpret_cast<unsigned long long>(p.fuse_comp);
@@ -287,7 +286,7 @@ __device__ __forceinline__ void convt_fused_epilogue(const PT &p, f32x16 (&acc)[
     CT &c = *(CT *)(((unsigned long long)hi << 32) | lo);
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int *goal = reinterpret_cast<const int *>(smem_all) + kFusedCtlGoal + p.fuse_view * ND * 2;
-    fused_top_body<ND, FIRST>(p, c, acc, bx, red, smem, goal);
+    fused_top_body<ND, FIRST, K>(p, c, acc, bx, red, smem, goal);
 }
 
 }  // namespace vf

@@ -30,7 +30,8 @@ enum PhaseType {
     PH_LSTM = 0, PH_CONV_RELU, PH_CONV_RAW, PH_CONVT_RELU, PH_CONVT_RAW, PH_FC_PARTIAL,
     PH_SA, PH_CDNA_FIN, PH_COMPOSITE,
     PH_TOP_FUSED,           // top transposed conv + compositing in one item (vf_fused_top.h)
-    PH_CONV_PAIR            // enc2 + enc3 in one item (conv_pair_epilogue, vf_conv_mfma.h)
+    PH_CONV_PAIR,           // enc2 + enc3 in one item (conv_pair_epilogue, vf_conv_mfma.h)
+    PH_COND                 // arch 2: border-class biases of the tiled conditioning vector for one conv-LSTM (cond_bias_sample)
 };
 
 constexpr int kMaxDeps = 3;
@@ -79,6 +80,7 @@ struct PhaseDesc {
     SaParams sa;
     FinParams fin;
     CompositeParams comp;
+    CondParams cond;
 };
 
 constexpr int kCtlWords = 64;               // LDS control block: [0..3] scheduler, [8..8+32) goal pixels, [40..44) state words
@@ -112,7 +114,7 @@ __device__ __forceinline__ int ld_relaxed(const int *p) {
 __device__ __forceinline__ void item_samples(const PhaseDesc &P, int local, int &b0, int &b1) {
     switch (P.type) {
         case PH_SA: b0 = local * kSaPerItem; b1 = min(b0 + kSaPerItem, P.B); break;
-        case PH_CDNA_FIN: b0 = local; b1 = local + 1; break;
+        case PH_CDNA_FIN: case PH_COND: b0 = local; b1 = local + 1; break;
         case PH_COMPOSITE: b0 = local / P.gx; b1 = b0 + 1; break;      // gx = tiles per image
         case PH_FC_PARTIAL: b0 = 0; b1 = P.B; break;
         default: {
@@ -173,17 +175,19 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void lstm_bf16x6
 static __device__ __noinline__ __attribute__((not_tail_called)) void fc_wide_tile_call(const ConvParams *p, int bx, int bz) {
     fc_wide_tile(const_params(p), bx, bz, tile_lds());
 }
-template <int ND, bool FIRST>
+template <int ND, bool FIRST, int K>
 static __device__ __noinline__ __attribute__((not_tail_called)) void composite_tile_call(const CompositeParams *p, int tile, int b, int view) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
-    composite_tile<ND, 10, FIRST>(const_params(p), tile, b, goal, tile_lds());
+    composite_tile<ND, K, FIRST>(const_params(p), tile, b, goal, tile_lds());
 }
 static __device__ __noinline__ __attribute__((not_tail_called)) void small_item_call(const PhaseDesc *P, int type, int b0, int b1) {
     float *smem = tile_lds();
     if (type == PH_SA) {
         const int wave = threadIdx.x >> 6, b = b0 + wave;
         if (b < b1) sa_sample(const_params(&P->sa), b, threadIdx.x & 63, smem + 32 * wave);
+    } else if (type == PH_COND) {
+        cond_bias_sample(const_params(&P->cond), b0, smem);
     } else {
         cdna_finalize_sample(const_params(&P->fin), b0, smem);
     }
@@ -375,13 +379,17 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                     else conv_tile_call<1, EPI_PARTIAL, 2>(&P.conv, bx % P.gx, by, bx / P.gx);
                     break;
                 case PH_CONV_PAIR: conv_tile_call<2, EPI_CONV_PAIR, 1>(&P.conv, bx, 0, 0); break;
+                // (K = 6: the compositing of arch 2 - four CDNA warps + previous + first frame + scratch - always with
+                // the first-frame layer; K = 10 otherwise)
                 case PH_TOP_FUSED:
-                    if (P.comp.first_frame) conv_tile_call<4, fused_epi(ND, true), 1>(&P.conv, bx, 0, 0);
+                    if (P.comp.K == 6) conv_tile_call<4, fused_epi(ND, true, true), 1>(&P.conv, bx, 0, 0);
+                    else if (P.comp.first_frame) conv_tile_call<4, fused_epi(ND, true), 1>(&P.conv, bx, 0, 0);
                     else conv_tile_call<4, fused_epi(ND, false), 1>(&P.conv, bx, 0, 0);
                     break;
                 case PH_COMPOSITE:
-                    if (P.comp.first_frame) composite_tile_call<ND, true>(&P.comp, local % P.gx, b0, P.view);
-                    else composite_tile_call<ND, false>(&P.comp, local % P.gx, b0, P.view);
+                    if (P.comp.K == 6) composite_tile_call<ND, true, 6>(&P.comp, local % P.gx, b0, P.view);
+                    else if (P.comp.first_frame) composite_tile_call<ND, true, 10>(&P.comp, local % P.gx, b0, P.view);
+                    else composite_tile_call<ND, false, 10>(&P.comp, local % P.gx, b0, P.view);
                     break;
                 default: small_item_call(&P, P.type, b0, b1); break;
             }

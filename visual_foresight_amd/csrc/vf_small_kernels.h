@@ -117,6 +117,77 @@ VF_GLOBAL void cdna_finalize_kernel(const FinParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-layer conditioning of arch 2 (savp_arch.py, Savp2Config): the published SAVP generator tiles the vector
+// v = [action, latent, state] over the image and concatenates it to the input of EVERY conv-LSTM (arXiv:1804.01523,
+// appendix A).  A spatially constant input channel needs no GEMM rows: with zero padding its contribution to gate column
+// `col` at pixel (y, x) is  sum over the taps (dy, dx) that fall inside the image of  t[dy][dx][col],
+// t[tap][col] = sum_c W[tap][c][col] v[c],  and which taps fall inside only depends on whether y (x) is one of the two
+// first / two last rows (columns): 5 x 5 border classes.  One item per (conv-LSTM, sample) computes the 25 class biases for
+// all 4C gate columns; the conv-LSTM epilogue adds the row of its pixel's class.  No K growth (as real channels the 17
+// values would cost every cell one more 32-channel chunk: +17 ... +50 % matrix work), same sums as the concatenated
+// convolution up to fp32 association.
+struct CondParams {
+    const float *action; long long action_bstride;     // [adim] per sample (latent channels included; 0 stride: shared)
+    const float *state;  long long state_bstride;      // [sdim]
+    int adim, sdim, B;
+    const float *w;         // [25 taps][adim + sdim][C4]: the conditioning rows of the layer's canonical weights
+    int C4;                 // 4 * cell channels (gate-major columns)
+    float *out;             // [B][25 classes][C4]
+};
+constexpr int kCondClasses = kTaps;
+// border class of coordinate y in an image of H rows (5-tap kernel, pad 2): 0, 1 | 2 = interior | 3, 4
+__host__ __device__ constexpr int cond_class(int y, int H) { return y < 2 ? y : (y >= H - 2 ? y - (H - 5) : 2); }
+// first / one-past-last kernel tap that reads inside the image for class r
+__host__ __device__ constexpr int cond_tap_lo(int r) { return r < 2 ? 2 - r : 0; }
+__host__ __device__ constexpr int cond_tap_hi(int r) { return r > 2 ? 7 - r : 5; }
+
+// one sample per workgroup call; sv = nsa floats of LDS scratch
+template <class PT>
+__device__ __forceinline__ void cond_bias_sample(const PT &p, const int b, float *sv) {
+    const int t = threadIdx.x, nsa = p.adim + p.sdim;
+    if (t < p.adim) sv[t] = p.action[(long long)b * p.action_bstride + t];
+    else if (t < nsa) sv[t] = p.state[(long long)b * p.state_bstride + (t - p.adim)];
+    __syncthreads();
+    for (int col = t; col < p.C4; col += 256) {
+        float tt[kTaps];
+#pragma unroll
+        for (int tap = 0; tap < kTaps; ++tap) {
+            float acc = 0.f;
+            for (int c = 0; c < nsa; ++c) acc = fmaf(sv[c], p.w[((long long)tap * nsa + c) * p.C4 + col], acc);
+            tt[tap] = acc;
+        }
+        // row sums over the columns of class rx, then over the rows of class ry (fixed order: deterministic)
+        float S[5][5];
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+            for (int rx = 0; rx < 5; ++rx) {
+                float a = 0.f;
+#pragma unroll
+                for (int dx = 0; dx < 5; ++dx)
+                    if (dx >= cond_tap_lo(rx) && dx < cond_tap_hi(rx)) a += tt[dy * 5 + dx];
+                S[dy][rx] = a;
+            }
+        float *o = p.out + (long long)b * kCondClasses * p.C4 + col;
+#pragma unroll
+        for (int ry = 0; ry < 5; ++ry)
+#pragma unroll
+            for (int rx = 0; rx < 5; ++rx) {
+                float a = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 5; ++dy)
+                    if (dy >= cond_tap_lo(ry) && dy < cond_tap_hi(ry)) a += S[dy][rx];
+                o[(long long)(ry * 5 + rx) * p.C4] = a;
+            }
+    }
+}
+
+VF_GLOBAL void cond_bias_kernel(const CondParams p) {
+    __shared__ float sv[64];
+    cond_bias_sample(p, blockIdx.x, sv);
+}
+
+// ------------------------------------------------------------------------------------------
 struct CompositeParams {
     int B, H, W, ND, K;                 // K = num_masks (K+1 mask channels, K-1 kernels used)
     const float *enc6;                  // raw convT3 output [B][H][W][32]
@@ -223,8 +294,10 @@ __device__ __forceinline__ void composite_pixel(const PT &p, const int b, const 
         load_px(ctr, fr, di);
 #pragma unroll
         for (int c = 0; c < 3; ++c) of[c] = fmaf(o_m[0], fr[c], o_m[1] * sigmoidf_(o_rgb[c]));
+        // (K == 6, arch 2: the published generator composes the distributions with the PREVIOUS distribution in the
+        // scratch layer's slot too - the scratch image has no distribution of its own)
 #pragma unroll
-        for (int d = 0; d < ND; ++d) od[d] = o_m[0] * di[d];
+        for (int d = 0; d < ND; ++d) od[d] = (K == 6 ? o_m[0] + o_m[1] : o_m[0]) * di[d];
     }
     if constexpr (FIRST) {
         const long long o1 = (long long)y * p.W + x;
@@ -384,8 +457,8 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
 template <int ND, int K>
 VF_GLOBAL VF_LAUNCH_BOUNDS(256) void composite_kernel(const CompositeParams p) {
     __shared__ __attribute__((aligned(16))) float smem[composite_lds_floats<ND, K>()];
-    if (p.first_frame) composite_tile<ND, K, true>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
-    else composite_tile<ND, K, false>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
+    if (K == 6 || p.first_frame) composite_tile<ND, K, true>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
+    else if constexpr (K != 6) composite_tile<ND, K, false>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
 }
 
 // ------------------------------------------------------------------------------------------

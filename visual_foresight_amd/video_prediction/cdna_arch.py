@@ -220,9 +220,9 @@ class CdnaWeights(object):
         arch = manifest.get('arch', 'cdna')
         if arch == 'cdna':
             file_cfg = CdnaConfig(**manifest['config'])
-        elif arch == 'savp':
-            from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
-            file_cfg = SavpConfig(**manifest['config'])
+        elif arch in ('savp', 'savp2'):
+            from visual_foresight_amd.video_prediction.savp_arch import SavpConfig, Savp2Config
+            file_cfg = (SavpConfig if arch == 'savp' else Savp2Config)(**manifest['config'])
         else:
             raise ValueError('unknown architecture %r in %s' % (arch, model_dir))
         if cfg is not None and cfg.arch != arch:

@@ -41,7 +41,7 @@ import numpy as np
 
 from visual_foresight_amd import _lib
 from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights
-from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
+from visual_foresight_amd.video_prediction.savp_arch import SavpConfig, Savp2Config
 from visual_foresight_amd.video_prediction.sharding import dist_info as _dist_info, shard_bounds, all_gather_rows
 
 
@@ -65,11 +65,12 @@ class HipVPredEvaluation(object):
         self.n_draws = int(hp.get('n_draws', 1))        # latent draws per action (stochastic_predictor.py)
         self.run_batch_size = int(hp.get('run_batch_size', 200)) * self.n_draws
         self.seed = int(hp.get('seed', 0))
-        # 'arch': 'cdna' (cdna_arch.py, default) or 'savp' (savp_arch.py: four scales, first-frame compositing)
+        # 'arch': 'cdna' (cdna_arch.py, default), 'savp' (savp_arch.py: four scales, first-frame compositing) or 'savp2'
+        # (savp + the conditioning vector in every conv-LSTM + the published seven-layer compositing)
         self.arch = str(hp.get('arch', 'cdna'))
-        if self.arch not in ('cdna', 'savp'):
-            raise ValueError("arch must be 'cdna' or 'savp', got %r" % (self.arch,))
-        cfg_cls = SavpConfig if self.arch == 'savp' else CdnaConfig
+        if self.arch not in ('cdna', 'savp', 'savp2'):
+            raise ValueError("arch must be 'cdna', 'savp' or 'savp2', got %r" % (self.arch,))
+        cfg_cls = {'cdna': CdnaConfig, 'savp': SavpConfig, 'savp2': Savp2Config}[self.arch]
         self.cfg = cfg_cls(height=hp.get('image_height', 64), width=hp.get('image_width', 64),
                            adim=hp.get('adim', 4), sdim=hp.get('sdim', 5),
                            ndesig=hp.get('designated_pixel_count', 1), n_context=self.n_context,

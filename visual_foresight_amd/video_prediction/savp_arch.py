@@ -111,3 +111,76 @@ class SavpConfig(CdnaConfig):
             if name == 'convt3':
                 out['convt4'] = (H // 2) * (W // 2) * 9 * (32 + ENC00_CH) * TOP_CH
         return out
+
+
+N_WARP2 = 4         # CDNA-warped copies of the previous frame in the published generator (num_transformed_images)
+
+
+class Savp2Config(SavpConfig):
+    """``arch = 'savp2'`` (``vf_config.arch = 2``): the generator above moved two steps closer to the published one
+    (Lee et al. 2018, arXiv:1804.01523, appendix A; the public implementation's ``SAVPCell``):
+
+    * **the conditioning vector enters every conv-LSTM**: ``tile_concat([x, [a_t, z_t, s_t]])`` is the input of each of
+      the seven cells, not only of the bottleneck conv (``lstm{k}/w`` is ``[5, 5, Cx + adim + sdim + Ch, 4 Ch]`` with
+      the channel order ``[x | a, z, s | h]``; ``adim`` includes the latent channels).  The engine does not spend GEMM
+      rows on a spatially constant input: one small item per (cell, sample) turns the 17 values into the 5 x 5
+      border-class biases of the 4 Ch gate columns (zero padding makes the contribution differ only in the two outermost
+      rows / columns), and the cell's epilogue adds the row of its pixel's class - the same sums as the concatenated
+      convolution up to fp32 association, at +0 matrix work instead of one more 32-channel chunk per cell;
+    * **the published compositing**: FOUR CDNA kernels (``cdna/w`` is ``[fc_in, 5 * 5 * 4]``), and seven compositing
+      layers in the published order - ``[warp_0 .. warp_3, previous frame, first frame, scratch image]`` - under one
+      channel softmax (``masks/w`` is ``[1, 1, 32, 7]``); designated-pixel distributions follow the same masks, the
+      scratch layer carrying no mass.
+
+    Still departing from the published network (none of it pinned by the reference): layer normalisation where SAVP
+    normalises per instance and channel (inside the conv-LSTM cells too: gates and cell state), strided / transposed
+    convolutions for conv + average-pool / bilinear-upsample + conv, the channel widths and the seven-cell depth of
+    the CDNA core (SAVP at 64 x 64: five cells of 32 / 64 / 128 / 64 / 32 channels), 1 x 1 heads where SAVP has 3 x 3
+    convolutions with a hidden layer, and masks that do not see the transformed images (``dependent_mask``).
+
+    ``num_masks`` is the ENGINE's slot count (6: the four kernels plus two dead slots whose zero weights meet a zero
+    mask - every stride of the compositing kernels is ``num_masks``); the checkpoint holds four kernels.
+    """
+    arch = 'savp2'
+    arch_id = 2
+
+    def __init__(self, height=128, width=128, adim=12, sdim=5, ndesig=1, n_context=2, sequence_length=17,
+                 num_masks=N_WARP2 + 2, ncam=1):
+        if num_masks != N_WARP2 + 2:
+            raise ValueError('savp2 composes %d CDNA warps (num_masks = %d)' % (N_WARP2, N_WARP2 + 2))
+        if height < 64 or width < 64:
+            raise ValueError('savp2 needs images of at least 64 x 64')
+        super(Savp2Config, self).__init__(height, width, adim, sdim, ndesig, n_context, sequence_length, num_masks, ncam)
+
+    def tensor_shapes(self):
+        nsa = self.adim + self.sdim
+        t = OrderedDict()
+        for name, shape in super(Savp2Config, self).tensor_shapes().items():
+            if name.startswith('lstm') and name.endswith('/w'):
+                shape = (5, 5, shape[2] + nsa, shape[3])
+            elif name == 'masks/w':
+                shape = (1, 1, TOP_CH, N_WARP2 + 3)
+            elif name == 'masks/b':
+                shape = (N_WARP2 + 3,)
+            elif name == 'cdna/w':
+                shape = (shape[0], DNA_KERN * DNA_KERN * N_WARP2)
+            elif name == 'cdna/b':
+                shape = (DNA_KERN * DNA_KERN * N_WARP2,)
+            t[name] = shape
+        return t
+
+    def macs_per_sample_step(self):
+        H, W = self.height, self.width
+        nsa = self.adim + self.sdim
+        out = super(Savp2Config, self).macs_per_sample_step()
+        shp = self.tensor_shapes()
+        res = {'lstm1': 4, 'lstm2': 4, 'lstm3': 8, 'lstm4': 8, 'lstm5': 16, 'lstm6': 8, 'lstm7': 4}
+        for name, div in res.items():       # the concatenated convolution the checkpoint describes (algorithmic count)
+            kh, kw, cin, cout = shp[name + '/w']
+            out[name] = (H // div) * (W // div) * kh * kw * cin * cout
+        out['masks'] = H * W * TOP_CH * (N_WARP2 + 3)
+        out['cdna_fc'] = shp['cdna/w'][0] * shp['cdna/w'][1]
+        out['warp_frame'] = H * W * DNA_KERN * DNA_KERN * 3 * N_WARP2
+        out['warp_distrib'] = H * W * DNA_KERN * DNA_KERN * self.ndesig * N_WARP2
+        return out
+
