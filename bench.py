@@ -82,6 +82,9 @@ def parse():
                          'pixel_cost_controller.py:57)')
     ap.add_argument('--precision', choices=('fp32', 'bf16x6'), default=os.environ.get('VF_PRECISION', 'fp32'),
                     help='primary precision mode (the other one is reported as alt_precision)')
+    ap.add_argument('--network', choices=('savp', 'savp2'), default='savp',
+                    help='generator of the c5 workload: savp (vf_config.arch 1) or savp2 (arch 2: the conditioning vector in '
+                         'every conv-LSTM, published seven-layer compositing; exact fp32 only)')
     ap.add_argument('--no-alt', action='store_true', help='skip the alt_precision measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
@@ -361,7 +364,7 @@ class Bench(object):
             policy.update(registration_warper=smooth_flow_warper, register_region=True)
         if self.draws:
             from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
-            policy['predictor_class'] = StochasticHipPredictor.with_options(n_latent=self.draws)
+            policy['predictor_class'] = StochasticHipPredictor.with_options(n_latent=self.draws, arch=self.args.network)
         if self.per_rank != 200:
             policy['vpred_batch_size'] = self.per_rank      # engine buffers sized for one rank's shard
         if self.ndesig != 1:
@@ -596,7 +599,7 @@ class Bench(object):
         }
         self.attach_traffic(result['roofline'], primary)
 
-        if not a.no_alt:
+        if not a.no_alt and not (self.draws and a.network == 'savp2'):       # (arch 2 is built for exact fp32 only)
             other = 'bf16x6' if primary == 'fp32' else 'fp32'
             am = self.measure(other)
             result['alt_precision'] = {

@@ -282,23 +282,27 @@ def test_config5_fifth_of_a_shard_latent_draws_128():
     assert pred.device_status() == 0
 
 
-def test_config5_full_rank_share_625_sequences_elites_match_oracle():
-    """One rank's REAL share of configs[4]: 125 actions x 5 latent draws = 625 sequences x horizon 15 x 128x128 in
+@pytest.mark.parametrize('arch', ['savp', 'savp2'])
+def test_config5_full_rank_share_625_sequences_elites_match_oracle(arch):
+    """(Both SAVP-class generators: ``savp`` and ``savp2`` - the conditioning vector in every conv-LSTM, published
+    compositing - each against its own oracle.)
+    One rank's REAL share of configs[4]: 125 actions x 5 latent draws = 625 sequences x horizon 15 x 128x128 in
     one launch (the batch size at which every conv-LSTM takes the 256-row tile plan), through
     ``StochasticHipPredictor``.  Chunked into 25-action launches (128- and 64-row plans): the same bits.  The first
     25 actions are a CEM sub-problem whose every sequence also goes through the CPU oracle: mean-over-draws scores
     to 1e-5 and the identical K = 10 elite set, with a margin assert at the K / K+1 boundary.
     Shapes: BASELINE.json configs[4]; latent repeats: reference samplers/gaussian_sampler.py:140-141."""
-    from oracle.savp_predictor import OracleSavp
-    from visual_foresight_amd.video_prediction.savp_arch import SavpConfig
+    from oracle.savp_predictor import OracleSavp, OracleSavp2
+    from visual_foresight_amd.video_prediction.savp_arch import SavpConfig, Savp2Config
     from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
     torch.set_num_threads(min(32, torch.get_num_threads()))     # the oracle is fastest at 32 threads (bench.py)
+    cfg_cls, oracle_cls = {'savp': (SavpConfig, OracleSavp), 'savp2': (Savp2Config, OracleSavp2)}[arch]
     H = W = 128
     T, M, nl, zd, sub = 15, 125, 5, 8, 25
     hp = dict(designated_pixel_count=1, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,
-              sequence_length=T + 2, n_latent=nl, zdim=zd, latent_seed=9)
+              sequence_length=T + 2, n_latent=nl, zdim=zd, latent_seed=9, arch=arch)
     pred = StochasticHipPredictor('', hp)
-    cfg = SavpConfig(height=H, width=W, adim=4 + zd, sdim=5, sequence_length=T + 2)
+    cfg = cfg_cls(height=H, width=W, adim=4 + zd, sdim=5, sequence_length=T + 2)
     weights = CdnaWeights.random(cfg, seed=6, bias_scale=0.05, ln_jitter=0.1)
     pred.restore(weights)
     rs = np.random.RandomState(13)
@@ -323,7 +327,7 @@ def test_config5_full_rank_share_625_sequences_elites_match_oracle():
     # the oracle on ALL sequences of the 25-action sub-problem
     ctx_o = dict(ctx, context_actions=np.concatenate([ctx['context_actions'], np.zeros((1, zd))], axis=1))
     aug = np.concatenate([np.repeat(actions[:sub], nl, axis=0), np.tile(z, (sub, 1, 1))], axis=2)
-    ora = OracleSavp(weights, torch.float32)
+    ora = oracle_cls(weights, torch.float32)
     want_seq = []
     for c0 in range(0, sub * nl, 25):
         _, d, _ = ora.rollout(ctx_o['context_frames'], ctx_o['context_actions'], ctx_o['context_pixel_distributions'],
