@@ -876,7 +876,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         // the persistent schedule's plan: same packed weights, same chunks and splits, 128 rows x all column groups
         h->fc_wide = f;
         h->fc_wide.mrep = 7; h->fc_wide.NI = kFcRows; h->fc_wide.lds_bytes = fc_wide_lds_bytes();
-        h->fc_wide_ok = f.KC == 32 && f.ncg == kFcGroups && f.nseg == 1 && f.segC[0] % 32 == 0;
+        h->fc_wide_ok = f.KC == 32 && f.ncg <= kFcGroups && f.nseg == 1 && f.segC[0] % 32 == 0;
     }
     h->layers = {&h->enc0, &h->lstm[0], &h->lstm[1], &h->enc1, &h->lstm[2], &h->lstm[3], &h->enc2, &h->enc3,
                  &h->lstm[4], &h->convt1, &h->lstm[5], &h->convt2, &h->lstm[6], &h->convt3, &h->fc};

@@ -49,7 +49,8 @@ __device__ __forceinline__ void fc_wide_tile(const PT &p, const int bx_, const i
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 
-    const int Ntot = p.ncg * 32;
+    const int ncg = p.ncg;              // column groups of this layer (<= kFcGroups)
+    const int Ntot = ncg * 32;
     const unsigned w_loff = (unsigned)(((kh * Ntot + n) * 4) * 4);          // this lane's column inside a (chunk, k8) block
     const unsigned wstep_b = (unsigned)(2 * Ntot * 4) * 4u;                 // bytes per (chunk, k8) block
     const __amdgpu_buffer_rsrc_t w_rsrc =
@@ -59,7 +60,8 @@ __device__ __forceinline__ void fc_wide_tile(const PT &p, const int bx_, const i
         const unsigned so_ = (unsigned)(min(ci, sg.nchunk - 1) * 4 + k8) * wstep_b;
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            D_[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_loff, so_ + 512u * g, 0));
+            if (g < ncg)        // (fewer than eight column groups - arch 2: 150 columns - leave the last tiles idle)
+                D_[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_loff, so_ + 512u * g, 0));
     };
 
     // ---- staging: thread = (row lane tid / 8, channel quad tid % 8); rows tid / 8 + 32 u
@@ -119,7 +121,7 @@ __device__ __forceinline__ void fc_wide_tile(const PT &p, const int bx_, const i
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int g = 0; g < G; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], cur[g][j], acc[g], 0, 0, 0);
+                    if (g < ncg) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], cur[g][j], acc[g], 0, 0, 0);
         }
     }
 
