@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 5
+#define VF_ABI_VERSION 6
 
 typedef enum vf_status {
     VF_OK = 0,
@@ -61,7 +61,8 @@ typedef struct vf_config {
     int32_t ndesig;             /* designated pixels per view (1..4) */
     int32_t n_context;          /* context frames (>= 1) */
     int32_t sequence_length;    /* n_context + T */
-    int32_t num_masks;          /* CDNA kernels K (masks = K + 1) */
+    int32_t num_masks;          /* CDNA kernel slots K (masks = K + 1): 10 for arch 0 / 1; 6 for arch 2 (four kernels in
+                                 * the checkpoint, seven compositing layers) */
     int32_t max_batch;          /* run_batch_size: most samples per vf_rollout call */
     int32_t device;             /* HIP device ordinal */
     int32_t precision;          /* arithmetic of the conv-LSTM gate GEMMs (96 % of the work):
@@ -82,8 +83,12 @@ typedef struct vf_config {
                                  * width multiples of 8); 1 = SAVP-class stochastic generator (savp_arch.py:
                                  * the same conv-LSTM core between one more encoder and decoder scale, the
                                  * first context frame as an extra compositing layer, the per-step latent as
-                                 * extra action channels; multiples of 16).  The reference selects the class
-                                 * through conf['model'], vpred_model_interface.py:52-58 */
+                                 * extra action channels; multiples of 16); 2 = arch 1 moved closer to the
+                                 * published SAVP generator (savp_arch.py, Savp2Config: the vector [action, latent,
+                                 * state] conditions EVERY conv-LSTM - lstm weights [5][5][Cx + adim + sdim + Ch][4Ch] -
+                                 * and the compositing is the published one: four CDNA kernels, layers [warps,
+                                 * previous, first, scratch]; exact fp32 only, at least 64 x 64).  The reference
+                                 * selects the class through conf['model'], vpred_model_interface.py:52-58 */
 } vf_config;
 
 typedef struct vf_handle vf_handle;
@@ -214,6 +219,17 @@ int vf_set_xcd_queues(vf_handle *h, int32_t enable);
  * second GEMM in its stand-alone K order (conv_pair_epilogue, visual_foresight_amd/csrc/vf_conv_mfma.h) - one dependency
  * hop per sample-step less, bit-identical as well.  enable = 0 switches both off (A/B measurements, tests). */
 int vf_set_fuse_top(vf_handle *h, int32_t enable);
+
+/* Scheduling options of the persistent rollout that change timing only, never results (no reference counterpart; round 5).
+ *   VF_OPT_YIELD_BUDGET (0): cooperative CU-level priority - the recurrent half of an early-started conv-LSTM item sleeps
+ *       while the other workgroup of its CU runs chain-critical work, at most `value` polls of ~0.4 us per item
+ *       (visual_foresight_amd/csrc/vf_conv_mfma.h, "yielding"); 0 = off, -1 = automatic (on for small shards).
+ *   VF_OPT_WRITE_THROUGH (1): tiles with 16-byte epilogue stores publish their outputs as sc1 (write-through) stores and
+ *       skip the release fence in front of their completion counters; 0 = plain stores + release, 1 = on (default).
+ * Exists for A/B measurements and for the tests that hold every setting to the same bits. */
+#define VF_OPT_YIELD_BUDGET 0
+#define VF_OPT_WRITE_THROUGH 1
+int vf_set_sched_option(vf_handle *h, int32_t option, int32_t value);
 
 /* Context de-duplication (default on).  While a step's inputs are context, part of the network
  * sees identical inputs for every sample (step < n_context-1: everything; step < n_context: the

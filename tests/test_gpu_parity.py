@@ -136,6 +136,35 @@ def test_tile_plans_are_invisible_in_the_results():
             np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize('H,W,T,M,nd', [(64, 64, 4, 25, 1), (64, 64, 3, 60, 2), (48, 64, 3, 9, 1), (64, 64, 2, 130, 1)])
+def test_yielding_and_write_through_publish_are_invisible_in_the_results(H, W, T, M, nd):
+    """The two timing-only mechanisms of round 5 (``vf_set_sched_option``): the cooperative CU priority - recurrent halves
+    of early-started conv-LSTM items sleeping while their CU partner is on a dependency chain, any budget - and the
+    write-through publish (sc1 stores, no release fence).  Every combination, small shards (where yielding is on by
+    default) and a batch beyond its threshold: the same bits for scores and materialised predictions, repeated rollouts
+    (cached context) included, and a healthy device status."""
+    pred, _ = _predictor(H, W, T, nd, bs=M)
+    rs = np.random.RandomState(H + M)
+    ctx = _context(H, W, nd, rs)
+    actions = rs.normal(0, 0.1, (M, T, 4))
+    goal = rs.randint(0, min(H, W), (1, nd, 2))
+    outs = []
+    for budget, wt in ((-1, 1), (0, 0), (0, 1), (7, 1), (120, 0), (4000, 1)):
+        pred.set_sched_option('yield_budget', budget)
+        pred.set_sched_option('write_through', wt)
+        for rep in range(2):
+            s, pt = pred.score(ctx, {'actions': actions}, goal)
+            assert pred.device_status() == 0
+        got = pred(ctx, {'actions': actions[:24]})
+        outs.append((s, pt, got['predicted_frames'], got['predicted_pixel_distributions'], got['predicted_states']))
+        pred._ctx_key = None
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)
+    with pytest.raises(Exception):
+        pred.set_sched_option('yield_budget', -5)
+
+
 @pytest.mark.parametrize('H,W,T,M,nd', [(64, 64, 3, 37, 2), (48, 64, 3, 9, 1), (32, 32, 3, 21, 1), (64, 64, 2, 160, 1)])
 def test_fused_items_are_invisible_in_the_results(H, W, T, M, nd):
     """The two fusions of the persistent schedule - decoder top + compositing, and the two convolutions of the 8 x 8

@@ -24,8 +24,8 @@ EXPORTS = ('vf_abi_version', 'vf_last_error', 'vf_weight_count', 'vf_create', 'v
            'vf_allgather_scores', 'vf_comm_init_all', 'vf_comm_destroy', 'vf_allgather_scores_group',
            'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile',
            'vf_set_dedup', 'vf_set_persistent', 'vf_set_xcd_queues', 'vf_set_fuse_top', 'vf_device_status',
-           'vf_set_phase_stats', 'vf_debug_phase_stats', 'vf_debug_poison_status')
-ABI_VERSION = 5
+           'vf_set_phase_stats', 'vf_debug_phase_stats', 'vf_debug_poison_status', 'vf_set_sched_option')
+ABI_VERSION = 6
 
 
 class VfError(RuntimeError):
@@ -119,6 +119,8 @@ def load_library():
     lib.vf_set_persistent.argtypes = [P, ctypes.c_int32]
     lib.vf_set_xcd_queues.argtypes = [P, ctypes.c_int32]
     lib.vf_set_fuse_top.argtypes = [P, ctypes.c_int32]
+    lib.vf_set_sched_option.argtypes = [P, ctypes.c_int32, ctypes.c_int32]
+    lib.vf_set_sched_option.restype = ctypes.c_int
     lib.vf_set_fuse_top.restype = ctypes.c_int
     lib.vf_set_xcd_queues.restype = ctypes.c_int
     lib.vf_device_status.argtypes = [P, ctypes.POINTER(ctypes.c_int32)]

@@ -2286,6 +2286,21 @@ int vf_set_fuse_top(vf_handle *h, int32_t enable) {
     return VF_OK;
 }
 
+int vf_set_sched_option(vf_handle *h, int32_t option, int32_t value) {
+    if (!h) return fail(VF_ERR_INVALID, "null handle");
+    switch (option) {
+        case VF_OPT_YIELD_BUDGET:
+            if (value < -1 || value > 100000) return fail(VF_ERR_INVALID, "yield budget must be -1 (automatic) or 0..100000");
+            h->yield_budget = value;
+            return VF_OK;
+        case VF_OPT_WRITE_THROUGH:
+            h->wt_publish = value != 0;
+            return VF_OK;
+        default:
+            return fail(VF_ERR_INVALID, "unknown scheduling option " + std::to_string(option));
+    }
+}
+
 int vf_set_xcd_queues(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->xcd_queues = enable ? kQueues : 1;

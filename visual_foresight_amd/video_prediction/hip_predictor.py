@@ -191,6 +191,14 @@ class HipVPredEvaluation(object):
                 _lib.check(lane._libh.vf_set_fuse_top(lane._handle, int(bool(enable))))
             lane.fuse_top = bool(enable)
 
+    def set_sched_option(self, option, value):
+        """Timing-only options of the persistent launch (``vf_set_sched_option``): ``'yield_budget'`` (0 = off, -1 = automatic)
+        and ``'write_through'`` (0 / 1).  Results are bit-identical for every setting."""
+        code = {'yield_budget': 0, 'write_through': 1}[option]
+        for lane in self._all_lanes():
+            with self._torch.cuda.device(lane.device):
+                _lib.check(lane._libh.vf_set_sched_option(lane._handle, code, int(value)))
+
     def device_status(self):
         """Synchronise, return the sticky failure word of the persistent kernel (0 = healthy), re-arm it."""
         worst = 0
