@@ -37,9 +37,6 @@
 
 namespace vf {
 
-#ifndef VF_CHUNK_PREFETCH
-#define VF_CHUNK_PREFETCH 0
-#endif
 constexpr int kPollSleep = 16;      // s_sleep units (64 cycles) between two polls of a dependency counter (2, 4: no gain)
 
 #ifdef VF_TILE_STATS
@@ -1238,13 +1235,7 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
     // latency chain that others wait for; it runs at priority 2 (set by the persistent kernel) and the long matrix
     // loops step down to 0, so a co-resident light item or epilogue gets its few instructions issued first.
     if constexpr (EPI == EPI_LSTM) __builtin_amdgcn_s_setprio(0);
-    // Staging runs in batches of kStageU elements per thread (below).  In the small gate-split / 32-row conv-LSTM tiles the
-    // first batch of chunk c + 1 is REQUESTED before the K loop of chunk c (as the 128-row tile of vf_conv_gsplit.h does):
-    // the loads and their addresses had to be issued anyway, and behind the loop only the LayerNorm / LDS stores remain.
-    constexpr int kStageU = 4;
-    constexpr bool kPrefetch = VF_CHUNK_PREFETCH && EPI == EPI_LSTM && (RB == -2 || RB == 1);
-    [[maybe_unused]] f32x4 pre_v[kStageU];
-    [[maybe_unused]] bool pre_have = false;
+    constexpr int kStageU = 4;      // staging runs in batches of kStageU elements per thread (below)
     for (int ci = ch_begin; ci < ch_end; ++ci) {
         const int s = (ci < p.seg[0].nchunk) ? 0 : 1;
         const auto &sg = p.seg[s];
@@ -1345,10 +1336,8 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
                             imgs[u] = img; oks[u] = ok;
                             unsigned off = ((unsigned)(iy * p.Win + ix) * Cs + (unsigned)c) * 4u;
                             if constexpr (!NI1) off += (unsigned)img * img_step;
-                            if (kPrefetch && NI1 && pre_have && pix0 == pl) v[u] = pre_v[u];    // requested under the previous K loop
-                            else v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : 0xFFFFFFFFu, 0, 0));
+                            v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : 0xFFFFFFFFu, 0, 0));
                         }
-                        if constexpr (kPrefetch) { if (pix0 == pl) pre_have = false; }
                         if constexpr (kInLaunch) { if (pix0 == pl) VF_TRACE_EVT(TR_ST_LOADED); }
 #pragma unroll
                         for (int u = 0; u < kStageU; ++u) {
@@ -1444,33 +1433,6 @@ __device__ __forceinline__ void conv_tile(const PT &p, const int bx_, const int 
             VF_TRACE_EVT(TR_KLOOP);
         }
 
-        if constexpr (kPrefetch) {
-            const int cn = ci + 1;
-            if (cn < ch_end && !(late && cn == p.seg[0].nchunk) && p.NI == 1 && bimg0 < p.B) {
-                const int sn = (cn < p.seg[0].nchunk) ? 0 : 1;
-                const auto &sgn = p.seg[sn];
-                if ((sgn.C & 3) == 0 && sgn.C % KC == 0) {
-                    // (the expressions of stage_fast<NI1> for the batch pix0 = pl of chunk cn: same addresses)
-                    const int pl_ = tid >> q4_log2, ppp_ = kConvThreads >> q4_log2;
-                    const int y0_ = ty0 * p.stride - p.pad, x0_ = tx0 * p.stride - p.pad;
-                    const unsigned Cs_ = (unsigned)sgn.C;
-                    const __amdgpu_buffer_rsrc_t rsrc_ = __builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<float *>(sgn.ptr + (long long)bimg0 * sgn.bstride), 0,
-                        (int)((unsigned)(p.Hin * p.Win) * Cs_ * 4u), 0x00020000);
-                    const int cq_ = (sn == 0 ? cn : cn - p.seg[0].nchunk) * KC + 4 * (tid & (q4 - 1));
-#pragma unroll
-                    for (int u = 0; u < kStageU; ++u) {
-                        const int pix = pl_ + u * ppp_;
-                        const int ly = LW == 1 ? pix : (int)__umulhi((unsigned)pix, magic_lw), lx = pix - ly * LW;
-                        const int iy = y0_ + ly, ix = x0_ + lx;
-                        const bool ok = pix < tile_px && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                        const unsigned off = ((unsigned)(iy * p.Win + ix) * Cs_ + (unsigned)cq_) * 4u;
-                        pre_v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_, ok ? off : 0xFFFFFFFFu, 0, 0));
-                    }
-                    pre_have = true;
-                }
-            }
-        }
         const f32x4 *smem4 = reinterpret_cast<const f32x4 *>(smem);
         int ab4[MR];                                                // in float4 units
 #pragma unroll
