@@ -27,6 +27,7 @@ WGS, MAXE = 512, 8192
 TICK_US = 0.01
 TR_TICKET, TR_DONE, TR_STAGE, TR_KLOOP, TR_LATE, TR_LATE_END, TR_EPI, TR_MFMAS, TR_HWID, TR_RUN = 1, 3, 10, 11, 12, 13, 14, 15, 20, 32
 TR_ST_LOADED, TR_ST_WRITTEN = 16, 17
+TR_YIELD, TR_YIELD_END = 18, 19    # a recurrent half asleep for its CU partner (round 5), inside a K loop
 PH_LSTM = 0
 PH_NAMES = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED', 'CONV_PAIR']
 
@@ -59,12 +60,12 @@ for w in range(WGS):
     codes = (ev[w, :n] & np.uint64(255)).astype(np.int64)
     vals = (ev[w, :n] >> np.uint64(8)).astype(np.int64)
     iv = []
-    state, t_state, lstm, mf = None, None, False, 0
+    state, t_state, lstm, mf, cid = None, None, False, 0, 0
 
     def close(t, new_state):
         global state, t_state
         if state is not None and t > t_state:
-            iv.append((t_state, t, state, mf if state == 'K' else 0))
+            iv.append((t_state, t, state, mf if state == 'K' else 0, cid))
         state, t_state = new_state, t
 
     for c, v in zip(codes, vals):
@@ -92,6 +93,11 @@ for w in range(WGS):
                 close(v, 'stage')
             elif c == TR_KLOOP:
                 close(v, 'K')
+                cid += 1                # the K loop of one chunk: one sample of the rate regression, yields cut out
+            elif c == TR_YIELD:
+                close(v, 'yield')
+            elif c == TR_YIELD_END:
+                close(v, 'K')
             elif c == TR_ST_LOADED:
                 close(v, 'stage:ln+write')
             elif c == TR_ST_WRITTEN:
@@ -111,13 +117,13 @@ span = (t_max - t_min) * TICK_US
 print('traced span %.2f ms' % (span / 1e3))
 tot = defaultdict(float)
 for w, iv in wg_iv.items():
-    for t0, t1, s, _ in iv:
+    for t0, t1, s, _, _c in iv:
         tot[s.split(':')[0] if s.startswith(('light', 'wait')) else s] += (t1 - t0) * TICK_US
 nw = len(wg_iv)
 print('per workgroup slot (mean over %d), ms: ' % nw + '  '.join('%s %.2f' % (k, v / nw / 1e3) for k, v in sorted(tot.items())))
 light, lightn = defaultdict(float), defaultdict(int)
 for w, iv in wg_iv.items():
-    for t0, t1, s, _ in iv:
+    for t0, t1, s, _, _c in iv:
         if s.startswith('light:'):
             parts = s.split(':')
             light[(parts[1], ':'.join(parts[2:]) if len(parts) > 2 else 'pro')] += (t1 - t0) * TICK_US
@@ -139,7 +145,7 @@ print('%d CUs host exactly two workgroups (%d CUs seen)' % (len(pairs), len(by_c
 
 
 def simplify(s):
-    return 'K' if s == 'K' else ('idle' if s in ('wait', 'late', 'sched', 'stage:barrier') or s.startswith('wait:') else 'other')
+    return 'K' if s == 'K' else ('idle' if s in ('wait', 'late', 'sched', 'stage:barrier', 'yield') or s.startswith('wait:') else 'other')
 
 
 joint = defaultdict(float)
@@ -150,7 +156,8 @@ for a, b in pairs:
     for me, other in ((a, b), (b, a)):
         oiv = wg_iv[other]
         j = 0
-        for t0, t1, s, mf in wg_iv[me]:
+        chunk = {}      # chunk id -> [overlap with the partner's K, rest, MFMAs]
+        for t0, t1, s, mf, cid in wg_iv[me]:
             # walk the partner's intervals overlapping [t0, t1)
             while j < len(oiv) and oiv[j][1] <= t0:
                 j += 1
@@ -167,10 +174,12 @@ for a, b in pairs:
                     cover += hi - lo
                 k += 1
             if s == 'K' and mf > 0:
-                X.append((ovK * TICK_US, (t1 - t0 - ovK) * TICK_US))
-                Y.append(mf)
-            elif s.startswith('wait') or s == 'late' or s.endswith(':late') or s.endswith(':mates'):
-                key = s if s.startswith('wait') else ('late (conv-LSTM)' if s == 'late' else s.replace('light:', ''))
+                acc = chunk.setdefault(cid, [0.0, 0.0, mf])
+                acc[0] += ovK * TICK_US
+                acc[1] += (t1 - t0 - ovK) * TICK_US
+            elif s.startswith('wait') or s in ('late', 'yield') or s.endswith(':late') or s.endswith(':mates'):
+                key = s if s.startswith('wait') else ('late (conv-LSTM)' if s == 'late' else
+                                                      'yield (recurrent half)' if s == 'yield' else s.replace('light:', ''))
                 unc[key][0] += (t1 - t0) * TICK_US
                 unc[key][1] += (t1 - t0 - ovK) * TICK_US
             elif s in ('epi', 'pro', 'stage') or s.startswith('light:'):
@@ -178,9 +187,12 @@ for a, b in pairs:
                 if s.startswith('light:') and (s.endswith(':late') or s.endswith(':mates')):
                     continue
                 starve[cls].append(((t1 - t0) * TICK_US, ovK * TICK_US))
+        for ov_us, rest_us, mf in chunk.values():
+            X.append((ov_us, rest_us))
+            Y.append(mf)
 npair = len(pairs)
 print('joint state of a CU, %% of the traced span (K = issuing MFMAs of a conv-LSTM K loop, idle = waiting for a ticket / '
-      'dependency / late input, other = prologue, staging, epilogue, light items):')
+      'dependency / late input or asleep for the CU partner, other = prologue, staging, epilogue, light items):')
 keys = ['K', 'other', 'idle']
 sym = defaultdict(float)
 for (s1, s2), v in joint.items():
@@ -231,10 +243,10 @@ if os.environ.get('VF_TRACE_TIMELINE'):
     edges = np.linspace(lo_t, hi_t, nb + 1)
     occ = defaultdict(lambda: np.zeros(nb))
     for w, iv in wg_iv.items():
-        for t0, t1, s, _ in iv:
+        for t0, t1, s, _, _c in iv:
             if t1 <= lo_t or t0 >= hi_t:
                 continue
-            key = 'K' if s == 'K' else ('idle' if s in ('wait', 'late', 'sched') or s.startswith('wait:') or s.endswith(':late') else
+            key = 'K' if s == 'K' else ('idle' if s in ('wait', 'late', 'sched', 'yield') or s.startswith('wait:') or s.endswith(':late') else
                                         (s.split(':')[1] if s.startswith('light') else 'lstm-other'))
             a, b = max(t0, lo_t), min(t1, hi_t)
             i0, i1 = int((a - lo_t) / (hi_t - lo_t) * nb), min(nb - 1, int((b - lo_t) / (hi_t - lo_t) * nb))

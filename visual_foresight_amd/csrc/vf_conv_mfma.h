@@ -62,7 +62,7 @@ constexpr int kTraceWgs = 512;
 __device__ unsigned long long g_trace[(size_t)kTraceWgs * kTraceMax];
 __device__ unsigned g_trace_n[kTraceWgs];
 enum TraceCode { TR_TICKET = 1, TR_DONE = 3, TR_STAGE = 10, TR_KLOOP = 11, TR_LATE = 12, TR_LATE_END = 13, TR_EPI = 14,
-                 TR_MFMAS = 15 /* value: MFMAs per wave per chunk */, TR_ST_LOADED = 16, TR_ST_WRITTEN = 17, TR_TOP_STATS = 24, TR_TOP_HALO = 25, TR_TOP_MATES = 26, TR_HWID = 20 /* value: xcc << 16 | hw_id */, TR_PHASE = 21 /* value: index of the phase the item belongs to */,
+                 TR_MFMAS = 15 /* value: MFMAs per wave per chunk */, TR_ST_LOADED = 16, TR_ST_WRITTEN = 17, TR_YIELD = 18, TR_YIELD_END = 19, TR_TOP_STATS = 24, TR_TOP_HALO = 25, TR_TOP_MATES = 26, TR_HWID = 20 /* value: xcc << 16 | hw_id */, TR_PHASE = 21 /* value: index of the phase the item belongs to */,
                  TR_RUN = 32 /* + phase type */ };
 __device__ __forceinline__ void vf_trace(const unsigned code, const unsigned long long val = ~0ull) {
     if (threadIdx.x == 0 && blockIdx.x < kTraceWgs) {
@@ -228,11 +228,14 @@ __device__ __forceinline__ unsigned yield_peek_wait(unsigned v) {
 // end of a kernel row of a recurrent half: sleep while the partner is on a dependency chain (bounded by `budget`)
 __device__ __forceinline__ void yield_to_partner(const int *word, unsigned seen, int &budget) {
     seen = yield_peek_wait(seen);
-    while (seen != 0u && budget > 0) {
+    if (seen == 0u || budget <= 0) return;
+    VF_TRACE_EVT(TR_YIELD);
+    do {
         __builtin_amdgcn_s_sleep(kYieldSleep);
         --budget;
         seen = yield_peek_wait(yield_peek_issue(word));
-    }
+    } while (seen != 0u && budget > 0);
+    VF_TRACE_EVT(TR_YIELD_END);
 }
 
 // Mid-item wait of a conv-LSTM tile for the producer of its layer input (samples [b0, b1)).  One wave polls
