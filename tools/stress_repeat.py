@@ -14,7 +14,7 @@ import numpy as np  # noqa: E402
 from oracle import pixel_cost  # noqa: E402  (one_hot_distrib only: input construction)
 from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights  # noqa: E402
 from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation  # noqa: E402
-from visual_foresight_amd.video_prediction.savp_arch import SavpConfig  # noqa: E402
+from visual_foresight_amd.video_prediction.savp_arch import Savp2Config, SavpConfig  # noqa: E402
 from visual_foresight_amd.video_prediction.savp_arch import CdnaWeights as SavpWeights  # noqa: E402
 
 
@@ -26,7 +26,7 @@ def run(arch, H, W, T, M, nd, prec, seed, reps, ncam=1):
         cfg = CdnaConfig(height=H, width=W, ndesig=nd, sequence_length=T + 2)
         weights = [CdnaWeights.random(cfg, seed=seed + v, bias_scale=0.05, ln_jitter=0.1) for v in range(ncam)]
     else:
-        cfg = SavpConfig(height=H, width=W, adim=adim, ndesig=nd, sequence_length=T + 2)
+        cfg = (Savp2Config if arch == 'savp2' else SavpConfig)(height=H, width=W, adim=adim, ndesig=nd, sequence_length=T + 2)
         weights = [SavpWeights.random(cfg, seed=seed + v, bias_scale=0.05, ln_jitter=0.1) for v in range(ncam)]
     pred = HipVPredEvaluation('', hp)
     pred.restore(weights if ncam > 1 else weights[0])
@@ -74,5 +74,13 @@ if __name__ == '__main__':
     total += run('cdna', 64, 64, 4, 120, 2, 'bf16x6', 6, reps)
     total += run('savp', 64, 64, 3, 150, 2, 'fp32', 9, reps)
     total += run('savp', 128, 128, 3, 40, 2, 'fp32', 8, max(reps // 3, 3))
+    # small shards: the recurrent halves yield to their CU partner there (fewer than 96 samples per view), and every
+    # item publishes write-through
+    total += run('cdna', 64, 64, 13, 25, 1, 'fp32', 11, reps)
+    total += run('cdna', 64, 64, 6, 50, 2, 'fp32', 12, reps)
+    total += run('cdna', 64, 64, 5, 7, 4, 'fp32', 13, reps)
+    total += run('cdna', 64, 64, 4, 40, 2, 'fp32', 14, reps, ncam=2)
+    total += run('savp2', 64, 64, 3, 60, 2, 'fp32', 15, reps)
+    total += run('savp2', 128, 128, 3, 20, 1, 'fp32', 16, max(reps // 3, 3))
     print('TOTAL differing repetitions:', total)
     sys.exit(1 if total else 0)
