@@ -18,6 +18,7 @@ from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeig
 from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation  # noqa: E402
 from visual_foresight_amd.video_prediction.savp_arch import SavpConfig  # noqa: E402
 from visual_foresight_amd.video_prediction.savp_arch import CdnaWeights as SavpWeights  # noqa: E402
+from visual_foresight_amd.video_prediction.savp_arch import Savp2Config  # noqa: E402
 
 
 def digest(*arrays):
@@ -35,7 +36,7 @@ def run(name, arch, H, W, T, M, nd, prec, export, seed, ncam=1):
         cfg = CdnaConfig(height=H, width=W, ndesig=nd, sequence_length=T + 2)
         weights = [CdnaWeights.random(cfg, seed=seed + v, bias_scale=0.05, ln_jitter=0.1) for v in range(ncam)]
     else:
-        cfg = SavpConfig(height=H, width=W, adim=adim, ndesig=nd, sequence_length=T + 2)
+        cfg = (Savp2Config if arch == 'savp2' else SavpConfig)(height=H, width=W, adim=adim, ndesig=nd, sequence_length=T + 2)
         weights = [SavpWeights.random(cfg, seed=seed + v, bias_scale=0.05, ln_jitter=0.1) for v in range(ncam)]
     pred = HipVPredEvaluation('', hp)
     pred.restore(weights if ncam > 1 else weights[0])
@@ -66,3 +67,6 @@ if __name__ == '__main__':
     run('savp 128x128 M40 T3', 'savp', 128, 128, 3, 40, 1, 'fp32', True, 8)
     run('savp 64x64 M150 T3 nd2', 'savp', 64, 64, 3, 150, 2, 'fp32', True, 9)
     run('savp 128x128 M20 T2 bf16x6', 'savp', 128, 128, 2, 20, 1, 'bf16x6', False, 10)
+    run('savp2 128x128 M30 T3', 'savp2', 128, 128, 3, 30, 1, 'fp32', True, 11)
+    run('savp2 64x64 M101 T3 nd2', 'savp2', 64, 64, 3, 101, 2, 'fp32', True, 12)
+    run('savp2 64x64 M7 T4', 'savp2', 64, 64, 4, 7, 1, 'fp32', True, 13)

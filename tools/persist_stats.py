@@ -8,12 +8,12 @@ from visual_foresight_amd import _lib
 from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
 from oracle import pixel_cost
 
-# usage: persist_stats.py [M [H [arch [T]]]]   (arch: cdna | savp; savp runs with 12 action channels)
+# usage: persist_stats.py [M [H [arch [T]]]]   (arch: cdna | savp | savp2; the SAVP-class networks run with 12 action channels)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 arch = sys.argv[3] if len(sys.argv) > 3 else 'cdna'
 T = int(sys.argv[4]) if len(sys.argv) > 4 else 13
-adim = 12 if arch == 'savp' else 4
+adim = 12 if arch in ('savp', 'savp2') else 4
 pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2, image_height=H,
                                    image_width=H, arch=arch, adim=adim)).restore()
 lib = _lib.load_library()
@@ -27,7 +27,7 @@ for _ in range(2):
 N = 500
 types, items, wr = (ctypes.c_int32 * N)(), (ctypes.c_int32 * N)(), (ctypes.c_uint64 * (2 * N))()
 n = lib.vf_debug_phase_stats(pred._handle, N, types, items, wr)
-names = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED', 'CONV_PAIR']
+names = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED', 'CONV_PAIR', 'COND']
 tick = 1e-8     # wall_clock64: 100 MHz
 agg = {}
 print('phase type items  wait_ms(sum over items)  run_ms(sum)  run_us/item')

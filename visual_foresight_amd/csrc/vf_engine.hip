@@ -1303,7 +1303,7 @@ struct LaunchSink {
     }
     int lstm(const ConvLayer &l, const ConvParams &p, int /*u_prev*/, int /*u_x*/, int /*u_cond*/ = -1) { return conv(PH_LSTM, l, p, {}); }
     int cond(const CondParams &p, std::initializer_list<int>) {
-        hipLaunchKernelGGL(cond_bias_kernel, dim3(p.B), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(cond_bias_kernel, dim3((p.B + kCondPerItem - 1) / kCondPerItem), dim3(256), 0, st, p);
         VF_HIP_CHECK(hipGetLastError());
         return VF_OK;
     }
@@ -1391,12 +1391,13 @@ struct ScheduleSink {
     int lstm(const ConvLayer &l, const ConvParams &p, int u_prev, int u_x, int u_cond = -1) {
         return conv_late(PH_LSTM, l, p, u_prev, u_x, u_cond);
     }
-    // arch 2: the border-class biases of the tiled conditioning vector for one conv-LSTM, one item per sample
+    // arch 2: the border-class biases of the tiled conditioning vector for one conv-LSTM, kCondPerItem samples per item
+    // (the layer's conditioning weights are read once per item)
     int cond(const CondParams &p, std::initializer_list<int> deps) {
         PhaseDesc P;
         memset(&P, 0, sizeof(P));
         P.type = PH_COND; P.cond = p; P.B = p.B;
-        return add(P, p.B, p.B, deps);
+        return add(P, (p.B + kCondPerItem - 1) / kCondPerItem, p.B, deps);
     }
     // a two-input tile whose segment 0 comes from u_early and whose segment 1 from u_late (decoder convs: the encoder
     // skip tensor first, the previous layer's output late)

@@ -114,7 +114,8 @@ __device__ __forceinline__ int ld_relaxed(const int *p) {
 __device__ __forceinline__ void item_samples(const PhaseDesc &P, int local, int &b0, int &b1) {
     switch (P.type) {
         case PH_SA: b0 = local * kSaPerItem; b1 = min(b0 + kSaPerItem, P.B); break;
-        case PH_CDNA_FIN: case PH_COND: b0 = local; b1 = local + 1; break;
+        case PH_COND: b0 = local * kCondPerItem; b1 = min(b0 + kCondPerItem, P.B); break;
+        case PH_CDNA_FIN: b0 = local; b1 = local + 1; break;
         case PH_COMPOSITE: b0 = local / P.gx; b1 = b0 + 1; break;      // gx = tiles per image
         case PH_FC_PARTIAL: b0 = 0; b1 = P.B; break;
         default: {
@@ -187,7 +188,7 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void small_item_
         const int wave = threadIdx.x >> 6, b = b0 + wave;
         if (b < b1) sa_sample(const_params(&P->sa), b, threadIdx.x & 63, smem + 32 * wave);
     } else if (type == PH_COND) {
-        cond_bias_sample(const_params(&P->cond), b0, smem);
+        cond_bias_sample(const_params(&P->cond), b0, b1, smem);
     } else {
         cdna_finalize_sample(const_params(&P->fin), b0, smem);
     }

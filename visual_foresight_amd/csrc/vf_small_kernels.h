@@ -141,50 +141,71 @@ __host__ __device__ constexpr int cond_class(int y, int H) { return y < 2 ? y : 
 __host__ __device__ constexpr int cond_tap_lo(int r) { return r < 2 ? 2 - r : 0; }
 __host__ __device__ constexpr int cond_tap_hi(int r) { return r > 2 ? 7 - r : 5; }
 
-// one sample per workgroup call; sv = nsa floats of LDS scratch
+// samples [b0, b1) (at most kCondPerItem) per workgroup call; sv = kCondPerItem * 32 floats of LDS scratch.  A weight is
+// loaded once for all samples of the call; every sample's sums run in the same order as in a one-sample call (same bits).
+constexpr int kCondPerItem = 4;
 template <class PT>
-__device__ __forceinline__ void cond_bias_sample(const PT &p, const int b, float *sv) {
-    const int t = threadIdx.x, nsa = p.adim + p.sdim;
-    if (t < p.adim) sv[t] = p.action[(long long)b * p.action_bstride + t];
-    else if (t < nsa) sv[t] = p.state[(long long)b * p.state_bstride + (t - p.adim)];
+__device__ __forceinline__ void cond_bias_sample(const PT &p, const int b0, const int b1, float *sv) {
+    const int t = threadIdx.x, nsa = p.adim + p.sdim, ns = b1 - b0;
+    if (t < kCondPerItem * 32) {
+        const int s = t >> 5, c = t & 31;
+        float v = 0.f;
+        if (s < ns) {
+            if (c < p.adim) v = p.action[(long long)(b0 + s) * p.action_bstride + c];
+            else if (c < nsa) v = p.state[(long long)(b0 + s) * p.state_bstride + (c - p.adim)];
+        }
+        sv[t] = v;
+    }
     __syncthreads();
     for (int col = t; col < p.C4; col += 256) {
-        float tt[kTaps];
+        float tt[kCondPerItem][kTaps];
 #pragma unroll
         for (int tap = 0; tap < kTaps; ++tap) {
-            float acc = 0.f;
-            for (int c = 0; c < nsa; ++c) acc = fmaf(sv[c], p.w[((long long)tap * nsa + c) * p.C4 + col], acc);
-            tt[tap] = acc;
+            float acc[kCondPerItem];
+#pragma unroll
+            for (int s = 0; s < kCondPerItem; ++s) acc[s] = 0.f;
+            for (int c = 0; c < nsa; ++c) {
+                const float w = p.w[((long long)tap * nsa + c) * p.C4 + col];
+#pragma unroll
+                for (int s = 0; s < kCondPerItem; ++s) acc[s] = fmaf(sv[s * 32 + c], w, acc[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < kCondPerItem; ++s) tt[s][tap] = acc[s];
         }
-        // row sums over the columns of class rx, then over the rows of class ry (fixed order: deterministic)
-        float S[5][5];
 #pragma unroll
-        for (int dy = 0; dy < 5; ++dy)
+        for (int s = 0; s < kCondPerItem; ++s) {
+            if (s >= ns) break;
+            // row sums over the columns of class rx, then over the rows of class ry (fixed order: deterministic)
+            float S[5][5];
 #pragma unroll
-            for (int rx = 0; rx < 5; ++rx) {
-                float a = 0.f;
+            for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 5; ++dx)
-                    if (dx >= cond_tap_lo(rx) && dx < cond_tap_hi(rx)) a += tt[dy * 5 + dx];
-                S[dy][rx] = a;
-            }
-        float *o = p.out + (long long)b * kCondClasses * p.C4 + col;
+                for (int rx = 0; rx < 5; ++rx) {
+                    float a = 0.f;
 #pragma unroll
-        for (int ry = 0; ry < 5; ++ry)
+                    for (int dx = 0; dx < 5; ++dx)
+                        if (dx >= cond_tap_lo(rx) && dx < cond_tap_hi(rx)) a += tt[s][dy * 5 + dx];
+                    S[dy][rx] = a;
+                }
+            float *o = p.out + (long long)(b0 + s) * kCondClasses * p.C4 + col;
 #pragma unroll
-            for (int rx = 0; rx < 5; ++rx) {
-                float a = 0.f;
+            for (int ry = 0; ry < 5; ++ry)
 #pragma unroll
-                for (int dy = 0; dy < 5; ++dy)
-                    if (dy >= cond_tap_lo(ry) && dy < cond_tap_hi(ry)) a += S[dy][rx];
-                o[(long long)(ry * 5 + rx) * p.C4] = a;
-            }
+                for (int rx = 0; rx < 5; ++rx) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int dy = 0; dy < 5; ++dy)
+                        if (dy >= cond_tap_lo(ry) && dy < cond_tap_hi(ry)) a += S[dy][rx];
+                    o[(long long)(ry * 5 + rx) * p.C4] = a;
+                }
+        }
     }
 }
 
 VF_GLOBAL void cond_bias_kernel(const CondParams p) {
-    __shared__ float sv[64];
-    cond_bias_sample(p, blockIdx.x, sv);
+    __shared__ float sv[kCondPerItem * 32];
+    const int b0 = blockIdx.x * kCondPerItem;
+    cond_bias_sample(p, b0, min(b0 + kCondPerItem, p.B), sv);
 }
 
 // ------------------------------------------------------------------------------------------
