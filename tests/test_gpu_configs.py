@@ -124,7 +124,7 @@ def test_config3_two_view_registration_planning_call(trade_off):
 
 def test_config3_full_size_properties():
     """600 samples x 2 views x 2 pixels: invariances over the whole batch, both views in one launch."""
-    from visual_foresight_amd.video_prediction.multiview_predictor import MultiViewHipPredictor
+    from visual_foresight_amd.video_prediction.hip_predictor import MultiViewHipPredictor
     H = W = 64
     ncam, nd, M, T = 2, 2, 600, 13
     hp = dict(designated_pixel_count=nd, adim=4, sdim=5, image_height=H, image_width=W, sequence_length=T + 2)

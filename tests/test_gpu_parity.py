@@ -298,7 +298,7 @@ def test_launch_strategies_are_bit_identical():
 def test_two_view_predictor_matches_per_view_oracle():
     """BASELINE configs[2] shape in miniature: 2 views x 2 designated pixels, both views in one launch,
     every launch strategy."""
-    from visual_foresight_amd.video_prediction.multiview_predictor import MultiViewHipPredictor
+    from visual_foresight_amd.video_prediction.hip_predictor import MultiViewHipPredictor
     H = W = 32
     T, M, nd, ncam = 2, 6, 2, 2
     hp = dict(designated_pixel_count=nd, run_batch_size=M, adim=4, sdim=5, image_height=H, image_width=W,

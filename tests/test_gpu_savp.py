@@ -118,7 +118,7 @@ def test_savp_split_bf16_mode_matches_oracle():
 def test_savp_two_views_one_launch(arch):
     """Two views of the SAVP-class network in one engine (own weights per view, one launch), against the per-view
     oracle; persistent and per-layer launches agree bit for bit."""
-    from visual_foresight_amd.video_prediction.multiview_predictor import MultiViewHipPredictor
+    from visual_foresight_amd.video_prediction.hip_predictor import MultiViewHipPredictor
     H, W = (32, 48) if arch == 'savp' else (64, 80)
     T, M, nd, ncam, adim = 2, 5, 2, 2, 6
     hp = dict(designated_pixel_count=nd, run_batch_size=M, adim=adim, sdim=5, image_height=H, image_width=W,

@@ -672,3 +672,24 @@ class HipVPredEvaluation(object):
                 self._last_lo, self._last_M = index_base, 0
         return {'predicted_frames': frames, 'predicted_pixel_distributions': distrib,
                 'predicted_states': states}
+
+
+class MultiViewHipPredictor(HipVPredEvaluation):
+    """``ncam`` independent single-view networks behind the ``VPredEvaluation`` duck-type (the reference's
+    ``IndepMultiSAVPVideoPredictionModel``: one network per view sharing actions and states, outputs stacked on a camera
+    axis, ``visual_mpc/video_prediction/vpred_model_interface.py:60-88``).  The engine is the base class's - every view
+    of every sample rolls in the SAME persistent launch, per-task scores come back camera-major - this class only fixes
+    the construction conventions: ``ncam`` defaults to 2, ``model_path`` is a list of per-view directories or a directory
+    with ``view0/``, ``view1/`` ... inside, random-init seeds are ``seed + view``."""
+
+    def __init__(self, model_path, hparams, n_gpus=1, first_gpu=0):
+        hp = dict(hparams)
+        hp.setdefault('ncam', 2)
+        super(MultiViewHipPredictor, self).__init__(model_path, hp, n_gpus=n_gpus, first_gpu=first_gpu)
+
+    @staticmethod
+    def view_context(context, c):
+        """The single-view slice of a multi-view context (what one view's network sees)."""
+        return {'context_frames': np.asarray(context['context_frames'])[:, c:c + 1],
+                'context_pixel_distributions': np.asarray(context['context_pixel_distributions'])[:, c:c + 1],
+                'context_actions': context['context_actions'], 'context_states': context['context_states']}

@@ -123,7 +123,7 @@ class Savp2Config(SavpConfig):
     * **the conditioning vector enters every conv-LSTM**: ``tile_concat([x, [a_t, z_t, s_t]])`` is the input of each of
       the seven cells, not only of the bottleneck conv (``lstm{k}/w`` is ``[5, 5, Cx + adim + sdim + Ch, 4 Ch]`` with
       the channel order ``[x | a, z, s | h]``; ``adim`` includes the latent channels).  The engine does not spend GEMM
-      rows on a spatially constant input: one small item per (cell, sample) turns the 17 values into the 5 x 5
+      rows on a spatially constant input: one small item per (cell, four samples) turns the 17 values into the 5 x 5
       border-class biases of the 4 Ch gate columns (zero padding makes the contribution differ only in the two outermost
       rows / columns), and the cell's epilogue adds the row of its pixel's class - the same sums as the concatenated
       convolution up to fp32 association, at +0 matrix work instead of one more 32-channel chunk per cell;
