@@ -170,6 +170,7 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
                                     // gate w of all four row blocks, weights from L2 into registers, no barrier per tap)
     int NI, TH, TW, RPI, tilesY, tilesX;
     int ni_cap = 0;                 // > 0: at most this many whole images per workgroup (plans for narrow phases)
+    int kc_cap = 0;                 // > 0: chunk size at most this (a narrow-phase plan that shares the regular plan's packed weights)
     int ncg, Cout;
     int nsplit, chunks_per_split, n_valid;
     int stats_nparts;               // partial sums this layer's epilogue writes per sample
@@ -233,7 +234,7 @@ static void plan_geometry(ConvLayer &l, bool needs_stats, bool one_pixel_images)
     }
     const int maxC = std::max(l.segC[0], l.nseg > 1 ? l.segC[1] : 0);
     int KC = 32;
-    while (KC > 8 && (KC > round_up(maxC, 8) || conv_lds_bytes(l, KC) > 78 * 1024 ||
+    while (KC > 8 && (KC > round_up(maxC, 8) || conv_lds_bytes(l, KC) > 78 * 1024 || (l.kc_cap > 0 && KC > l.kc_cap) ||
                       l.segC[0] % KC || (l.nseg > 1 && l.segC[1] % KC)))
         KC >>= 1;
     if (l.prec == 1) KC = kBfKC;        // the split-bf16 tile stages 16-channel chunks
@@ -857,7 +858,10 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     init_layer(h->lstm[4], "lstm5", PACK_LSTM, H8, W8, H8, W8, 5, 5, 1, 2, L[3], L[4], L[4], true, false, lstm_mrep[4], cfg->precision, false, ccond);
     init_layer(h->convt1, "convt1", PACK_CONVT, H8, W8, H8, W8, 2, 2, 1, 1, L[4], 0, L[4], false);
     h->enc2_one.ni_cap = h->enc3_one.ni_cap = h->convt1_one.ni_cap = 1;
+    h->enc2_one.kc_cap = h->enc2.KC;   // the one-image plan of enc2 chunks like the regular one: it shares its packed weights,
+                                       // and enc2 + enc3 can be one item per IMAGE where a phase is narrow (conv_pair)
     init_layer(h->enc2_one, "enc2", PACK_PLAIN, H4, W4, H8, W8, 3, 3, 2, 0, L[3], 0, L[3], false);
+    h->enc2_one.lds_bytes = std::max(h->enc2_one.lds_bytes, (size_t)2 * 128 * 36 * 4);     // (room for the pair's hand-over tile)
     init_layer(h->enc3_one, "enc3", PACK_PLAIN, H8, W8, H8, W8, 1, 1, 1, 0, L[3], 0, L[3], false);
     init_layer(h->convt1_one, "convt1", PACK_CONVT, H8, W8, H8, W8, 2, 2, 1, 1, L[4], 0, L[4], false);
     init_layer(h->lstm[5], "lstm6", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[4], L[5], L[5], true, false, lstm_mrep[5], cfg->precision, false, ccond);
