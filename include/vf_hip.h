@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 6
+#define VF_ABI_VERSION 7
 
 typedef enum vf_status {
     VF_OK = 0,
@@ -62,7 +62,7 @@ typedef struct vf_config {
     int32_t n_context;          /* context frames (>= 1) */
     int32_t sequence_length;    /* n_context + T */
     int32_t num_masks;          /* CDNA kernel slots K (masks = K + 1): 10 for arch 0 / 1; 6 for arch 2 (four kernels in
-                                 * the checkpoint, seven compositing layers) */
+                                 * the checkpoint, seven compositing layers); 4 for arch 3 (four kernels, seven layers) */
     int32_t max_batch;          /* run_batch_size: most samples per vf_rollout call */
     int32_t device;             /* HIP device ordinal */
     int32_t precision;          /* arithmetic of the conv-LSTM gate GEMMs (96 % of the work):
@@ -87,8 +87,17 @@ typedef struct vf_config {
                                  * published SAVP generator (savp_arch.py, Savp2Config: the vector [action, latent,
                                  * state] conditions EVERY conv-LSTM - lstm weights [5][5][Cx + adim + sdim + Ch][4Ch] -
                                  * and the compositing is the published one: four CDNA kernels, layers [warps,
-                                 * previous, first, scratch]; exact fp32 only, at least 64 x 64).  The reference
-                                 * selects the class through conf['model'], vpred_model_interface.py:52-58 */
+                                 * previous, first, scratch]; exact fp32 only, at least 64 x 64); 3 = the PUBLISHED SAVP
+                                 * generator (savp3_arch.py; arXiv:1804.01523 appendix A: instance norm after every conv and
+                                 * inside the conv-LSTM cells, conv + average pool / bilinear up-sampling + conv, the layer
+                                 * table by image size, [action, state, rnn_z(latent)] tile-concatenated in front of every
+                                 * conv and conv-LSTM, 3x3 heads, dependent masks, symmetric-padded CDNA warps; exact fp32
+                                 * only).  The reference selects the class through conf['model'],
+                                 * vpred_model_interface.py:52-58 */
+    int32_t zdim;               /* arch 3: how many of the adim action channels are the per-step latent z_t (they go
+                                 * through the rnn_z cell and do not reach the state predictor); 0 for arch 0 - 2 */
+    int32_t layer_spec;         /* arch 3: 0 = encoder / decoder table by min(height, width) as the public code selects it;
+                                 * 32 / 64 / 128 force a table (64 = the paper's five-cell network); 0 for arch 0 - 2 */
 } vf_config;
 
 typedef struct vf_handle vf_handle;

@@ -26,7 +26,7 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vf_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.vf_abi_version() == _lib.ABI_VERSION == 7
 
 
 @pytest.mark.parametrize('H,W,adim,sdim,nd', [(64, 64, 4, 5, 1), (48, 64, 3, 3, 2), (128, 128, 5, 5, 4)])

@@ -21,8 +21,9 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
                                     uint64_t *out_upload_checksum);
 
 static int run_case(int H, int W, int adim, int sdim, int nd, int nctx, int T, int max_batch, int precision, int ncam,
-                    int n_draws, const int *batches, int n_batches, int arch = 0) {
-    vf_config cfg = {H, W, adim, sdim, nd, nctx, nctx + T, arch == 2 ? 6 : 10, max_batch, 0, precision, ncam, n_draws, arch};
+                    int n_draws, const int *batches, int n_batches, int arch = 0, int zdim = 0, int layer_spec = 0) {
+    vf_config cfg = {H, W, adim, sdim, nd, nctx, nctx + T, arch == 3 ? 4 : (arch == 2 ? 6 : 10), max_batch, 0, precision, ncam, n_draws, arch,
+                     zdim, layer_spec};
     const size_t n = vf_weight_count(&cfg);
     if (n == 0) { std::fprintf(stderr, "weight count failed: %s\n", vf_last_error()); return 1; }
     std::vector<float> blob(n * (size_t)ncam);
@@ -76,6 +77,13 @@ int main() {
     rc |= run_case(128, 128, 12, 5, 1, 2, 15, 125, 0, 1, 5, b_c2 + 1, 2, 2);
     rc |= run_case(64, 80, 6, 3, 2, 2, 2, 37, 0, 2, 1, b_small, 4, 2);
     rc |= run_case(64, 64, 12, 5, 3, 1, 2, 16, 0, 1, 1, b_small, 3, 2);
+    // arch 3: the published SAVP generator - every layer table (32 / 64 / 128 pixels, the paper's table forced on 128 x 128),
+    // a config-5 shard, two views, an odd shape
+    rc |= run_case(32, 32, 12, 5, 1, 2, 3, 37, 0, 1, 1, b_small, 4, 3, 8);
+    rc |= run_case(64, 64, 12, 5, 2, 2, 3, 37, 0, 2, 1, b_small, 4, 3, 8);
+    rc |= run_case(48, 64, 6, 3, 4, 1, 2, 16, 0, 1, 1, b_small, 3, 3, 2);
+    rc |= run_case(128, 128, 12, 5, 1, 2, 15, 125, 0, 1, 5, b_c2 + 1, 2, 3, 8);
+    rc |= run_case(128, 128, 12, 5, 1, 2, 4, 10, 0, 1, 5, b_c5 + 1, 1, 3, 8, 64);
     // invalid configurations are refused, not crashed on
     vf_config bad = {60, 64, 4, 5, 1, 2, 15, 10, 8, 0, 0, 1, 1, 0};
     vf_handle *h = nullptr;
@@ -88,6 +96,12 @@ int main() {
     if (vf_create(&bad4, &h) == 0) { std::fprintf(stderr, "arch 2 with num_masks 10 accepted\n"); rc = 1; }
     vf_config bad5 = {64, 64, 12, 5, 1, 2, 15, 6, 8, 0, 1, 1, 1, 2};       // arch 2 is fp32 only
     if (vf_create(&bad5, &h) == 0) { std::fprintf(stderr, "arch 2 in the split-bf16 mode accepted\n"); rc = 1; }
+    vf_config bad6 = {64, 64, 12, 5, 1, 2, 15, 4, 8, 0, 0, 1, 1, 3, 0, 0};     // arch 3 needs zdim
+    if (vf_create(&bad6, &h) == 0) { std::fprintf(stderr, "arch 3 without latent channels accepted\n"); rc = 1; }
+    vf_config bad7 = {64, 64, 12, 5, 1, 2, 15, 10, 8, 0, 0, 1, 1, 0, 8, 0};    // zdim belongs to arch 3
+    if (vf_create(&bad7, &h) == 0) { std::fprintf(stderr, "zdim with arch 0 accepted\n"); rc = 1; }
+    vf_config bad8 = {72, 64, 12, 5, 1, 2, 15, 4, 8, 0, 0, 1, 1, 3, 8, 128};   // four scales need multiples of 16
+    if (vf_create(&bad8, &h) == 0) { std::fprintf(stderr, "arch 3 / four scales at 72x64 accepted\n"); rc = 1; }
     std::printf(rc ? "HOST SELFTEST FAILED\n" : "HOST SELFTEST OK\n");
     return rc;
 }

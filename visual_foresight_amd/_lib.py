@@ -15,7 +15,7 @@ REPO = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get('VF_LIBRARY') or os.path.join(_HERE, 'libvf_hip.so')     # override: experiments only
 SOURCES = [os.path.join(_HERE, 'csrc', f) for f in
            ('vf_engine.hip', 'vf_conv_mfma.h', 'vf_conv_gsplit.h', 'vf_small_kernels.h', 'vf_persistent.h',
-            'vf_conv_bf16x6.h', 'vf_fused_top.h', 'vf_fc_tile.h')] + \
+            'vf_conv_bf16x6.h', 'vf_fused_top.h', 'vf_fc_tile.h', 'vf_savp3.h', 'vf_engine_savp3.inc')] + \
           [os.path.join(REPO, 'include', 'vf_hip.h')]
 
 # every symbol include/vf_hip.h declares
@@ -25,7 +25,7 @@ EXPORTS = ('vf_abi_version', 'vf_last_error', 'vf_weight_count', 'vf_create', 'v
            'vf_macs_per_sample_step', 'vf_set_profiling', 'vf_get_profile',
            'vf_set_dedup', 'vf_set_persistent', 'vf_set_xcd_queues', 'vf_set_fuse_top', 'vf_device_status',
            'vf_set_phase_stats', 'vf_debug_phase_stats', 'vf_debug_poison_status', 'vf_set_sched_option')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class VfError(RuntimeError):
@@ -35,7 +35,7 @@ class VfError(RuntimeError):
 class VfConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ('height', 'width', 'adim', 'sdim', 'ndesig', 'n_context', 'sequence_length',
-                 'num_masks', 'max_batch', 'device', 'precision', 'ncam', 'n_draws', 'arch')]
+                 'num_masks', 'max_batch', 'device', 'precision', 'ncam', 'n_draws', 'arch', 'zdim', 'layer_spec')]
 
 
 def _hipcc():

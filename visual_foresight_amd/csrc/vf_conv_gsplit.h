@@ -29,7 +29,8 @@ namespace vf {
 
 // MR = 4: 128 rows per workgroup (MR = 2, 64 rows, compiles too).  5 x 5 kernel, stride 1, 32-channel chunks of whole
 // channel quads (vf_engine.hip plans this tile only then).
-template <int MR, class PT>
+// RAW (arch 3): the tile ends with the GEMM and stores the raw gate pre-activations (gates_raw_epilogue)
+template <int MR, class PT, bool RAW = false>
 __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx_, const int by_, float *smem) {
     [[maybe_unused]] constexpr bool kInLaunch = !std::is_same<PT, ConvParams>::value;
     const int bx = __builtin_amdgcn_readfirstlane(bx_), by = __builtin_amdgcn_readfirstlane(by_);
@@ -301,13 +302,18 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
     }
     __builtin_amdgcn_s_setprio(2);
     if constexpr (kInLaunch) VF_TRACE_EVT(TR_EPI);
-    lstm_gsplit_epilogue<MR>(p, acc, bx, by, smem);
+    if constexpr (RAW) gates_raw_epilogue<MR>(p, acc, bx, by, smem);
+    else lstm_gsplit_epilogue<MR>(p, acc, bx, by, smem);
 }
 
 template <int MR>
 VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_lstm_gsplit2_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     conv_lstm_gsplit2_tile<MR>(p, blockIdx.x, blockIdx.y, smem);
+}
+VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void conv_gates_raw_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_lstm_gsplit2_tile<4, ConvParams, true>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 }  // namespace vf

@@ -98,8 +98,10 @@ enum Epilogue {
     EPI_CONVT_FUSED = 6,      // top transposed conv whose tile is composed into the next frame right away
                               // (vf_fused_top.h); 6 + 2 * (designated pixels - 1) + (arch 1 / 2 first-frame layer)
                               // + 8 for the six-kernel compositing of arch 2 (four CDNA warps + previous + first + scratch)
-    EPI_CONV_PAIR = 30        // a conv whose whole-image tiles feed a 1x1 conv in the same item (conv_pair_epilogue: enc2 ->
+    EPI_CONV_PAIR = 30,       // a conv whose whole-image tiles feed a 1x1 conv in the same item (conv_pair_epilogue: enc2 ->
                               // enc3, the 8 x 8 bottleneck; G = 2: both 32-channel groups of the first conv in one workgroup)
+    EPI_RAW = 31              // acc + bias, nothing else (arch 3: instance norm needs the whole image's statistics first; the
+                              // element-wise items of vf_savp3.h normalise)
 };
 __host__ __device__ constexpr bool is_top_fused(int epi) { return epi >= EPI_CONVT_FUSED && epi < EPI_CONV_PAIR; }
 __host__ __device__ constexpr int fused_epi(int nd, bool first, bool k6 = false) {
@@ -515,7 +517,7 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
     // sc1 (write-through) stores, which is what lets the item publish without a release fence (16-byte sc1 stores cost what
     // plain ones do, 4-byte ones six times as much per byte: CDNA guide, section 6 G16).  Same values, same statistics.
     constexpr bool kVec = MREP == 1 && (EPI == EPI_BIAS_RELU || EPI == EPI_RAW_STATS || EPI == EPI_CONVT_RELU ||
-                                         EPI == EPI_CONVT_RAW_STATS);
+                                         EPI == EPI_CONVT_RAW_STATS || EPI == EPI_RAW);
     if constexpr (kVec) {
         constexpr bool kT = EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS;
         constexpr bool kRelu = EPI == EPI_BIAS_RELU || EPI == EPI_CONVT_RELU;
@@ -905,6 +907,67 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
             }
         }
     }
+}
+
+// Raw epilogue of the gate-split 128-row tile (arch 3, vf_savp3.h): the published SAVP cell normalises the gate
+// pre-activations per sample and channel over the whole image before the cell update, so the tile's job ends with the
+// GEMM - the gates leave as they are, [pixel][4C] with gate-major columns, for the element-wise cell item.  Same
+// exchange through LDS as lstm_gsplit_epilogue (wave w holds gate w of all four row blocks and finishes row block w):
+// a lane stores four pixels x four consecutive channels x four gates as sixteen 16-byte stores.
+template <int MR, class PT>
+__device__ __forceinline__ void gates_raw_epilogue(const PT &p, f32x16 (&acc)[MR][1], const int bx, const int by, float *smem) {
+    static_assert(MR == 4, "raw gate epilogue: 128-row tile");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = by;
+    const int tiles_per_img = p.tilesY * p.tilesX;
+    int bimg0, ty0, tx0;
+    if (p.NI == 1) {
+        bimg0 = bx / tiles_per_img;
+        const int tile_id = bx % tiles_per_img;
+        ty0 = (tile_id / p.tilesX) * p.TH;
+        tx0 = (tile_id % p.tilesX) * p.TW;
+    } else {
+        bimg0 = bx * p.NI; ty0 = 0; tx0 = 0;
+    }
+    float *xch = smem;
+    const bool wt = p.wt_out != 0;
+    const int C4 = 4 * p.Cout;
+    const long long img_elems = (long long)p.Hout * p.Wout * C4;
+    const TileDiv div_rpi(p.RPI), div_tw(p.TW);
+    const int n_here = min(p.NI, p.B - bimg0);
+    const unsigned img_bytes = (unsigned)img_elems * 4u;
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+        p.out + (long long)bimg0 * img_elems, 0, n_here > 0 ? (int)((unsigned)n_here * img_bytes) : 0, 0x00020000);
+    const int pl = lane >> 3, cq = lane & 7;
+    const bool ni1 = p.NI == 1;
+    unsigned off_o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = wave * 32 + pl + 8 * k;
+        int img = 0, rem = row;
+        if (!ni1) { img = div_rpi.div(row); rem = row - img * p.RPI; }
+        const int yy = div_tw.div(rem);
+        const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
+        const bool ok = img < n_here && rem < p.TH * p.TW && y < p.Hout && x < p.Wout;
+        off_o[k] = ok ? (unsigned)img * img_bytes + (unsigned)((y * p.Wout + x) * C4 + cg * 32 + 4 * cq) * 4u : 0xFFFFFFFFu;
+    }
+    __syncthreads();                        // the operand tile is no longer read: its LDS becomes xch
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[((m * 4 + wave) * 16 + r) * 64 + lane] = acc[m][0][r];
+    __syncthreads();
+    const float *xw = xch + ((wave * 4) * 16 + (pl & 3)) * 64 + 32 * ((pl >> 2) & 1) + 4 * cq;
+    const unsigned gstep = (unsigned)p.Cout * 4u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xw + (g * 16 + 4 * k) * 64);
+            const unsigned off = off_o[k] == 0xFFFFFFFFu ? off_o[k] : off_o[k] + g * gstep;
+            if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r_out, off, 0, 16);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r_out, off, 0, 0);
+        }
 }
 
 // Epilogue of conv_tile<2, EPI_CONV_PAIR, 1>: conv -> relu -> 1x1 conv (+ per-sample bias) -> relu in ONE item.

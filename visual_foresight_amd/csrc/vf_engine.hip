@@ -82,7 +82,14 @@ struct TensorDesc {
 
 static int a_of(const vf_config &c) { return c.adim + c.sdim; }
 
+// arch 3 (the published SAVP generator): vf_engine_savp3.inc
+struct Savp3;
+static std::vector<TensorDesc> s3_tensor_table(const vf_config &c);
+static double s3_macs(const vf_config &c);
+static int s3_validate(const vf_config *c);
+
 static std::vector<TensorDesc> tensor_table(const vf_config &c) {
+    if (c.arch == 3) return s3_tensor_table(c);
     std::vector<TensorDesc> t;
     size_t off = 0;
     auto add = [&](const std::string &name, std::vector<int> shape) {
@@ -148,7 +155,7 @@ static const TensorDesc *find_tensor(const std::vector<TensorDesc> &t, const std
 
 // ------------------------------------------------------------------ one dense layer
 enum PackMode { PACK_PLAIN, PACK_LSTM, PACK_CONVT };
-static const int kNumConvLayers = 17;
+static const int kNumConvLayers = 24;
 
 struct ConvLayer {          // geometry only: shared by every view; the packed weights are per view
     std::string name;
@@ -421,6 +428,7 @@ struct vf_handle {
     vf_config cfg;
     int H, W, T, S, ND, K;              // S = steps per rollout = T + n_context - 1
     bool savp = false;                  // vf_config.arch >= 1: four-scale SAVP-class generator (savp_arch.py)
+    vf::Savp3 *s3 = nullptr;            // vf_config.arch == 3: the published SAVP generator (vf_engine_savp3.inc)
     bool cond = false;                  // vf_config.arch == 2: [action, latent, state] conditions every conv-LSTM
     float *cond_bias[7] = {nullptr};    // ... through per-sample border-class biases [2 step parities][ncam][max_batch][25][4C]
     int Hc, Wc;                         // input size of the three-scale conv-LSTM core (H, W; arch 1: H/2, W/2)
@@ -577,17 +585,26 @@ static int validate(const vf_config *c) {
         return fail(VF_ERR_INVALID, "need n_context >= 1 and sequence_length > n_context");
     if (c->adim < 1 || c->sdim < 1 || c->adim + c->sdim > 32)
         return fail(VF_ERR_INVALID, "need adim, sdim >= 1 and adim + sdim <= 32");
+    if (c->arch == 3) {
+        if (c->max_batch < 1) return fail(VF_ERR_INVALID, "max_batch must be >= 1");
+        if (c->ncam < 0 || c->ncam > kMaxCam) return fail(VF_ERR_INVALID, "ncam must be 1..4 (0 = 1)");
+        if (c->n_draws < 0) return fail(VF_ERR_INVALID, "n_draws must be >= 1 (0 = 1)");
+        if (c->n_draws > 1 && c->max_batch % c->n_draws) return fail(VF_ERR_INVALID, "max_batch must be a multiple of n_draws");
+        return s3_validate(c);
+    }
+    if (c->zdim != 0 || c->layer_spec != 0)
+        return fail(VF_ERR_INVALID, "zdim / layer_spec belong to arch 3 (must be 0 otherwise)");
     if (c->arch == 2 ? c->num_masks != 6 : c->num_masks != 10)
-        return fail(VF_ERR_INVALID, "num_masks must be 10 (arch 0 / 1) or 6 (arch 2: four CDNA warps + previous + first + scratch)");
+        return fail(VF_ERR_INVALID, "num_masks must be 10 (arch 0 / 1), 6 (arch 2: four CDNA warps + previous + first + scratch) or 4 (arch 3)");
     if (c->max_batch < 1) return fail(VF_ERR_INVALID, "max_batch must be >= 1");
     if (c->precision != 0 && c->precision != 1) return fail(VF_ERR_INVALID, "precision must be 0 (fp32) or 1 (split bf16)");
     if (c->ncam < 0 || c->ncam > kMaxCam) return fail(VF_ERR_INVALID, "ncam must be 1..4 (0 = 1)");
     if (c->n_draws < 0) return fail(VF_ERR_INVALID, "n_draws must be >= 1 (0 = 1)");
     if (c->n_draws > 1 && c->max_batch % c->n_draws)
         return fail(VF_ERR_INVALID, "max_batch must be a multiple of n_draws");
-    if (c->arch < 0 || c->arch > 2)
-        return fail(VF_ERR_INVALID, "arch must be 0 (CDNA), 1 (SAVP-class, four scales) or 2 (1 + per-layer conditioning, "
-                                    "published compositing)");
+    if (c->arch < 0 || c->arch > 3)
+        return fail(VF_ERR_INVALID, "arch must be 0 (CDNA), 1 (SAVP-class, four scales), 2 (1 + per-layer conditioning, "
+                                    "published compositing) or 3 (the published SAVP generator)");
     if (c->arch >= 1 && (c->height % 16 || c->width % 16))
         return fail(VF_ERR_INVALID, "arch 1 / 2 need height/width that are multiples of 16");
     if (c->arch == 2 && c->precision != 0)
@@ -650,6 +667,8 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_lstm_gsplit64_kernel, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_gsplit2_kernel<4>, n))) return rc;
     if ((rc = allow_lds(&conv_lstm_split_kernel<1>, n))) return rc;
+    if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_RAW, 1>, n))) return rc;
+    if ((rc = allow_lds(&conv_gates_raw_kernel, n))) return rc;
     const size_t np = n + kCtlWords * sizeof(int);
     if ((rc = allow_lds(&rollout_persistent_kernel<1>, np))) return rc;
     if ((rc = allow_lds(&rollout_persistent_kernel<2>, np))) return rc;
@@ -754,6 +773,8 @@ static ConvParams make_params(const ConvLayer &l, const LayerW &w, int B, const 
 
 }  // namespace vf
 
+#include "vf_engine_savp3.inc"
+
 // ================================================================== C ABI
 extern "C" {
 
@@ -769,6 +790,7 @@ size_t vf_weight_count(const vf_config *cfg) {
 
 double vf_macs_per_sample_step(const vf_config *cfg) {
     if (validate(cfg)) return 0.0;
+    if (cfg->arch == 3) return s3_macs(*cfg);
     const bool savp = cfg->arch >= 1;
     const int HF = cfg->height, WF = cfg->width;            // full resolution: heads and warps
     const int H = savp ? HF / 2 : HF, W = savp ? WF / 2 : WF;   // core
@@ -791,41 +813,17 @@ double vf_macs_per_sample_step(const vf_config *cfg) {
     return macs;
 }
 
-int vf_create(const vf_config *cfg, vf_handle **out) {
-    if (!out) return fail(VF_ERR_INVALID, "null out pointer");
-    *out = nullptr;
-    int rc = validate(cfg);
-    if (rc) return rc;
-#ifndef VF_HOST_SELFTEST
-    VF_HIP_CHECK(hipSetDevice(cfg->device));
-#endif
-    vf_handle *h = new vf_handle();
-    h->cfg = *cfg;
-    h->ncam = std::max(1, cfg->ncam);
-    h->n_draws = std::max(1, cfg->n_draws);
-    h->cfg.ncam = h->ncam; h->cfg.n_draws = h->n_draws;
-    h->H = cfg->height; h->W = cfg->width; h->ND = cfg->ndesig; h->K = cfg->num_masks;
-    h->T = cfg->sequence_length - cfg->n_context;
-    h->S = h->T + cfg->n_context - 1;
-    h->table = tensor_table(*cfg);
-    h->blob_floats = h->table.back().offset + h->table.back().size();
-    h->savp = cfg->arch >= 1;
-    h->cond = cfg->arch == 2;
-    h->Hc = h->savp ? h->H / 2 : h->H; h->Wc = h->savp ? h->W / 2 : h->W;
+}  // extern "C"
+
+// layers, plans and buffers of the CDNA-core networks (arch 0 - 2)
+static int cdna_create(vf_handle *h) {
+    const vf_config *cfg = &h->cfg;
+    int rc;
     const int H = h->H, W = h->W, Bc = cfg->max_batch, ND = h->ND, NV = h->ncam;
     const size_t BV = (size_t)Bc * NV;          // samples x views: rows of every per-sample buffer
     const int Hc = h->Hc, Wc = h->Wc;           // the three-scale core works on Hc x Wc
     const int H2 = Hc / 2, W2 = Wc / 2, H4 = Hc / 4, W4 = Wc / 4, H8 = Hc / 8, W8 = Wc / 8;
     const int *L = kLstmSizes;
-    h->ntiles = ((H + kCompTile - 1) / kCompTile) * ((W + kCompTile - 1) / kCompTile);
-    h->nblocks = sum_blocks(H, W);
-#ifdef VF_HOST_SELFTEST
-    h->fake_size = (size_t)1 << 40;
-    void *base = mmap(nullptr, h->fake_size, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    if (base == MAP_FAILED) { delete h; return fail(VF_ERR_NOMEM, "self-test address reservation failed"); }
-    h->fake_base = static_cast<char *>(base);
-#endif
-
     // rows per LSTM workgroup: 128 (mrep 1) keeps items short - the per-sample dependency chain,
     // not the MFMA rate, bounds a 200-sample rollout
     const int lstm_mrep[7] = {1, 1, 1, 1, 1, 1, 1};
@@ -935,7 +933,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
 #define VF_ALLOC(ptr, n)                           \
     do {                                           \
         rc = dev_alloc(h, &(ptr), (size_t)(n));    \
-        if (rc) { vf_destroy(h); return rc; }      \
+        if (rc) return rc;      \
     } while (0)
 
     // ---- per-view parameters and context: sized from the layer plans, filled by vf_load_weights
@@ -1042,6 +1040,44 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
         h->shared_views.push_back(sv);
     }
 #undef VF_ALLOC
+    return VF_OK;
+}
+
+extern "C" {
+
+int vf_create(const vf_config *cfg, vf_handle **out) {
+    if (!out) return fail(VF_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    int rc = validate(cfg);
+    if (rc) return rc;
+#ifndef VF_HOST_SELFTEST
+    VF_HIP_CHECK(hipSetDevice(cfg->device));
+#endif
+    vf_handle *h = new vf_handle();
+    h->cfg = *cfg;
+    h->ncam = std::max(1, cfg->ncam);
+    h->n_draws = std::max(1, cfg->n_draws);
+    h->cfg.ncam = h->ncam; h->cfg.n_draws = h->n_draws;
+    h->H = cfg->height; h->W = cfg->width; h->ND = cfg->ndesig; h->K = cfg->num_masks;
+    h->T = cfg->sequence_length - cfg->n_context;
+    h->S = h->T + cfg->n_context - 1;
+    h->table = tensor_table(*cfg);
+    h->blob_floats = h->table.back().offset + h->table.back().size();
+    h->savp = cfg->arch == 1 || cfg->arch == 2;
+    h->cond = cfg->arch == 2;
+    h->Hc = h->savp ? h->H / 2 : h->H; h->Wc = h->savp ? h->W / 2 : h->W;
+    const int H = h->H, W = h->W;
+    h->ntiles = ((H + kCompTile - 1) / kCompTile) * ((W + kCompTile - 1) / kCompTile);
+    h->nblocks = sum_blocks(H, W);
+#ifdef VF_HOST_SELFTEST
+    h->fake_size = (size_t)1 << 40;
+    void *base = mmap(nullptr, h->fake_size, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (base == MAP_FAILED) { delete h; return fail(VF_ERR_NOMEM, "self-test address reservation failed"); }
+    h->fake_base = static_cast<char *>(base);
+#endif
+
+    rc = cfg->arch == 3 ? s3_create(h) : cdna_create(h);
+    if (rc) { vf_destroy(h); return rc; }
 #ifndef VF_HOST_SELFTEST
     if (hipMemset(h->d_sync, 0, kSyncHead * sizeof(int)) != hipSuccess || hipMemset(h->d_status, 0, sizeof(int)) != hipSuccess) {
         vf_destroy(h);
@@ -1081,6 +1117,7 @@ int vf_destroy(vf_handle *h) {
     }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
 #endif
+    s3_free(h);
     delete h;
     return VF_OK;
 }
@@ -1097,6 +1134,16 @@ int vf_load_weights(vf_handle *h, const float *blob_all, size_t n_floats) {
     VF_HIP_CHECK(hipDeviceSynchronize());
 #endif
     int rc;
+    if (h->cfg.arch == 3) {
+        for (int view = 0; view < h->ncam; ++view)
+            if ((rc = s3_load_weights(h, blob_all + (size_t)view * h->blob_floats, view))) return rc;
+#ifndef VF_HOST_SELFTEST
+        VF_HIP_CHECK(hipDeviceSynchronize());
+#endif
+        h->have_weights = true;
+        h->shared_valid = false;
+        return VF_OK;
+    }
     auto T = [&](const std::string &name) { return find_tensor(h->table, name); };
     for (int view = 0; view < h->ncam; ++view) {
         const float *blob = blob_all + (size_t)view * h->blob_floats;
@@ -1302,8 +1349,27 @@ struct LaunchSink {
             case PH_CONV_RAW: return launch_conv_t<1, EPI_RAW_STATS>(l, p, st);
             case PH_CONVT_RELU: return launch_conv_t<4, EPI_CONVT_RELU>(l, p, st);
             case PH_CONVT_RAW: return launch_conv_t<4, EPI_CONVT_RAW_STATS>(l, p, st);
+            case PH_CONV_RAW3: return launch_conv_t<1, EPI_RAW>(l, p, st);
+            case PH_GATES_RAW: {
+                const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
+                hipLaunchKernelGGL(conv_gates_raw_kernel, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
+                VF_HIP_CHECK(hipGetLastError());
+                return VF_OK;
+            }
             default: return launch_conv_t<1, EPI_PARTIAL>(l, p, st);
         }
+    }
+    // element-wise items of arch 3 (vf_savp3.h): one workgroup per item
+    int ew(const EwParams &p, int /*view*/, std::initializer_list<int>) {
+        const int items = p.spi > 0 ? (p.B + p.spi - 1) / p.spi : p.B * p.gx;
+        switch (h->ND) {
+            case 1: hipLaunchKernelGGL(ew_kernel<1>, dim3(items), dim3(kConvThreads), 0, st, p); break;
+            case 2: hipLaunchKernelGGL(ew_kernel<2>, dim3(items), dim3(kConvThreads), 0, st, p); break;
+            case 3: hipLaunchKernelGGL(ew_kernel<3>, dim3(items), dim3(kConvThreads), 0, st, p); break;
+            default: hipLaunchKernelGGL(ew_kernel<4>, dim3(items), dim3(kConvThreads), 0, st, p); break;
+        }
+        VF_HIP_CHECK(hipGetLastError());
+        return VF_OK;
     }
     int lstm(const ConvLayer &l, const ConvParams &p, int /*u_prev*/, int /*u_x*/, int /*u_cond*/ = -1) { return conv(PH_LSTM, l, p, {}); }
     int cond(const CondParams &p, std::initializer_list<int>) {
@@ -1371,6 +1437,7 @@ struct ScheduleSink {
             switch (Q.type) {
                 case PH_SA: case PH_CDNA_FIN: case PH_COND: dp.expect = 1; break;
                 case PH_COMPOSITE: dp.expect = Q.gx; break;
+                case PH_EW: dp.expect = Q.ew.spi > 0 ? 1 : Q.gx; break;
                 default: dp.expect = (Q.NI == 1 ? Q.tiles_per_img : 1) * Q.gy;
             }
         }
@@ -1402,6 +1469,16 @@ struct ScheduleSink {
         memset(&P, 0, sizeof(P));
         P.type = PH_COND; P.cond = p; P.B = p.B;
         return add(P, (p.B + kCondPerItem - 1) / kCondPerItem, p.B, deps);
+    }
+    // element-wise items of arch 3 (vf_savp3.h): gx items per sample, or one item per spi samples
+    int ew(const EwParams &p, int view, std::initializer_list<int> deps) {
+        PhaseDesc P;
+        memset(&P, 0, sizeof(P));
+        P.type = PH_EW; P.ew = p; P.B = p.B; P.view = view;
+        P.gx = p.spi > 0 ? 1 : p.gx; P.gy = 1;
+        const int items = p.spi > 0 ? (p.B + p.spi - 1) / p.spi : p.B * p.gx;
+        max_lds = std::max(max_lds, (size_t)kEwLdsFloats * 4);
+        return add(P, items, p.B, deps);
     }
     // a two-input tile whose segment 0 comes from u_early and whose segment 1 from u_late (decoder convs: the encoder
     // skip tensor first, the previous layer's output late)
@@ -1849,8 +1926,11 @@ static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &
     for (int v = 0; v < h->ncam; ++v) {
         sinks[v].next_counter = counters;
         sinks[v].early_start = h->early_start;
-        rc = emit_rollout(h, v, make_view(h, v, h->actions_buf, 0), h->shared_views[(size_t)v], B, nullptr, sinks[v],
-                          skip_shared);
+        if (h->cfg.arch == 3)
+            rc = emit_rollout_s3(h, v, B, h->actions_buf, nullptr, sinks[v]);
+        else
+            rc = emit_rollout(h, v, make_view(h, v, h->actions_buf, 0), h->shared_views[(size_t)v], B, nullptr, sinks[v],
+                              skip_shared);
         if (rc < 0) return rc;
         counters = sinks[v].next_counter;
         out.flops += sinks[v].flops;
@@ -1883,18 +1963,18 @@ static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &
     for (PhaseDesc &P : out.phases) {
         P.q_gy = 1; P.q_inner = 1;
         if (nq > 1) {
-            if (P.type <= PH_CONVT_RAW || P.type == PH_TOP_FUSED) {     // (fused: a sample's tiles MUST share a queue)
+            if (ph_is_conv(P.type) || P.type == PH_TOP_FUSED) {     // (fused: a sample's tiles MUST share a queue)
                 if (P.gy <= nq && nq % P.gy == 0) P.q_gy = P.gy;
                 if (P.NI == 1 && P.n_items == P.gx * P.gy) P.q_inner = P.tiles_per_img;
                 if (P.n_items % (P.q_gy * P.q_inner)) { P.q_gy = 1; P.q_inner = 1; }
-            } else if (P.type == PH_COMPOSITE) {
-                P.q_inner = P.gx;
+            } else if (P.type == PH_COMPOSITE || (P.type == PH_EW && P.ew.spi == 0)) {
+                P.q_inner = P.gx;      // (a sample's items stay in one queue - the one its GEMM tiles' outputs are warm in)
             }
         }
         const int units = P.n_items / (P.q_gy * P.q_inner), per = nq / P.q_gy;
         // The units that do not fill a whole round of the queue groups are dealt tile by tile (PhaseDesc::q_full) -
         // except where a sample's tiles must meet in one queue (fused top: its tiles wait for each other; compositing).
-        const bool split_tail = nq > 1 && P.q_inner > 1 && P.type <= PH_CONVT_RAW;
+        const bool split_tail = nq > 1 && P.q_inner > 1 && ph_is_conv(P.type);
         const int full_units = split_tail ? (units / per) * per : units;
         const int n_tail = (units - full_units) * P.q_inner;       // (unit, tile) pairs dealt one by one
         P.q_full = split_tail ? (full_units / per) * P.q_inner : 0x7FFFFFFF;
@@ -1951,7 +2031,7 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
         if (P.has_late) {
             bool found = false;
             for (size_t j = 0; j < i && !found; ++j) found = bs.phases[j].cnt_base == P.late.cnt_base;
-            if (!found || !(P.type <= PH_CONVT_RAW || P.type == PH_TOP_FUSED) || P.late.expect <= 0)
+            if (!found || !(ph_is_conv(P.type) || P.type == PH_TOP_FUSED) || P.late.expect <= 0)
                 return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": bad late dependency");
         }
         const int ncnt = P.whole ? 1 : (P.type == PH_TOP_FUSED ? 2 * P.B : P.B);
@@ -1965,7 +2045,7 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
             ok = ok && in_allocs(h, c2.out, (size_t)P.B * c2.Hout * c2.Wout * c2.Cout * 4);
             ok = ok && in_allocs(h, c2.sbias, c2.sbias ? (size_t)((P.B - 1) * c2.sbias_ld + c2.Cout) * 4 : 0);
         }
-        if (P.type <= PH_FC_PARTIAL || P.type == PH_TOP_FUSED || P.type == PH_CONV_PAIR) {
+        if (P.type <= PH_FC_PARTIAL || ph_is_conv(P.type) || P.type == PH_TOP_FUSED || P.type == PH_CONV_PAIR) {
             const ConvParams &c = P.conv;
             for (int s = 0; s < c.nseg; ++s) {
                 const long long span = (long long)(P.B - 1) * c.seg[s].bstride + (long long)c.Hin * c.Win * c.seg[s].C;
@@ -1977,7 +2057,47 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
         }
         if (P.type == PH_TOP_FUSED && (P.aux_base != P.cnt_base + P.B || P.aux_base + P.B > bs.counters))
             return fail(VF_ERR_INVALID, "fused phase: bad auxiliary counters");
-        if (P.type <= PH_FC_PARTIAL) {
+        if (P.type <= PH_FC_PARTIAL || ph_is_conv(P.type)) {
+        } else if (P.type == PH_EW) {
+            const EwParams &e = P.ew;
+            if (e.op == EW_INORM || e.op == EW_INCELL) {
+                const NormParams &q = e.norm;
+                const size_t hw = (size_t)q.H * q.W, ctot = (size_t)(e.op == EW_INCELL ? 4 : 1) * q.C;
+                ok = ok && in_allocs(h, q.in, ((size_t)(P.B - 1) * q.in_bs + hw * ctot) * 4);
+                ok = ok && in_allocs(h, q.out, ((size_t)(P.B - 1) * q.out_bs + hw * q.C) * 4);
+                ok = ok && in_allocs(h, q.cond, q.cond ? ((size_t)(P.B - 1) * q.cond_bs + 25 * ctot) * 4 : 0);
+                ok = ok && in_allocs(h, q.g0, ctot * 4) && in_allocs(h, q.b0, ctot * 4) && q.C % q.cpi == 0 && e.gx == q.C / q.cpi;
+                if (e.op == EW_INCELL)
+                    ok = ok && in_allocs(h, q.cout, ((size_t)(P.B - 1) * q.cout_bs + hw * q.C) * 4) &&
+                         in_allocs(h, q.cprev, q.cprev ? ((size_t)(P.B - 1) * q.cprev_bs + hw * q.C) * 4 : 0) &&
+                         in_allocs(h, q.g1, (size_t)q.C * 4) && in_allocs(h, q.b1, (size_t)q.C * 4);
+            } else if (e.op == EW_UPSAMPLE) {
+                const UpParams &q = e.up;
+                const size_t hw = (size_t)q.h * q.w;
+                ok = ok && in_allocs(h, q.in0, ((size_t)(P.B - 1) * q.in0_bs + hw * q.C0) * 4);
+                ok = ok && in_allocs(h, q.in1, q.C1 ? ((size_t)(P.B - 1) * q.in1_bs + hw * q.C1) * 4 : 0);
+                ok = ok && in_allocs(h, q.out, ((size_t)(P.B - 1) * q.out_bs + 4 * hw * (q.C0 + q.C1)) * 4);
+                ok = ok && e.gx * q.rows >= 2 * q.h && (size_t)q.rows * 2 * q.w * ((q.C0 + q.C1) / 4) < 65536;
+            } else if (e.op == EW_SA3) {
+                const Sa3Params &q = e.sa;
+                const int ncond = q.adim + q.sdim;
+                ok = ok && in_allocs(h, q.condvec, (size_t)P.B * ncond * 4) && in_allocs(h, q.rnn_state, (size_t)P.B * 2 * q.zdim * 4) &&
+                     in_allocs(h, q.action, 4) && in_allocs(h, q.state, 4);
+            } else if (e.op == EW_COND3) {
+                const Cond3Params &q = e.cond;
+                ok = ok && in_allocs(h, q.condvec, (size_t)P.B * q.ncond * 4) && in_allocs(h, q.out, (size_t)P.B * 25 * q.Ctot * 4) &&
+                     in_allocs(h, q.w, (size_t)q.KH * q.KH * q.ncond * q.Ctot * 4) && q.KH <= 6;
+            } else {
+                const TopParams &q = e.top;
+                const size_t hw = (size_t)q.H * q.W;
+                ok = ok && in_allocs(h, q.trans, (size_t)P.B * hw * kTransCh * 4) && in_allocs(h, q.transd, (size_t)P.B * hw * kNumWarp3 * q.ND * 4);
+                ok = ok && in_allocs(h, q.mlog, (size_t)P.B * hw * kMaskCh * 4) && in_allocs(h, q.scr_raw, (size_t)P.B * hw * kScrCh * 4);
+                ok = ok && in_allocs(h, q.prev_frame, ((size_t)(P.B - 1) * q.prev_frame_bs + hw * 3) * 4);
+                ok = ok && in_allocs(h, q.prev_distrib, ((size_t)(P.B - 1) * q.prev_distrib_bs + hw * q.ND) * 4);
+                ok = ok && in_allocs(h, q.out_frame, ((size_t)(P.B - 1) * q.out_frame_bs + hw * 3) * 4);
+                ok = ok && in_allocs(h, q.out_distrib, ((size_t)(P.B - 1) * q.out_distrib_bs + hw * q.ND) * 4);
+                ok = ok && in_allocs(h, q.out_sums, (size_t)P.B * q.ND * h->nblocks * 2 * 8) && in_allocs(h, q.kern, (size_t)P.B * kTaps * kNumWarp3 * 4);
+            }
         } else if (P.type == PH_COMPOSITE || P.type == PH_TOP_FUSED) {
             const CompositeParams &c = P.comp;
             const size_t hw = (size_t)c.H * c.W;
@@ -2033,7 +2153,7 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
                 head[q] += P.n_q[q];
                 total += P.n_q[q];
             }
-            if (bs.nq > 1 && P.q_inner > 1 && P.type <= PH_CONVT_RAW) {    // tile-by-tile tail: balanced to one item
+            if (bs.nq > 1 && P.q_inner > 1 && ph_is_conv(P.type)) {    // tile-by-tile tail: balanced to one item
                 int lo = P.n_q[0], hi = P.n_q[0];
                 for (int q = 0; q < bs.nq; ++q) { lo = std::min(lo, P.n_q[q]); hi = std::max(hi, P.n_q[q]); }
                 if (hi - lo > 1) return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": queues are not balanced");
@@ -2071,8 +2191,28 @@ static int zero_shared_state(vf_handle *h, const BatchView &sh, hipStream_t st) 
     return VF_OK;
 }
 
+// arch 3: the recurrent input of step 0 is read from parity 0 of every conv-LSTM's hidden state
+static int s3_zero_state(vf_handle *h, int B, hipStream_t st) {
+    for (int i = 0; i < h->s3->nl; ++i) {
+        const S3Layer &l = h->s3->L[i];
+        if (!l.rnn) continue;
+        const size_t per = (size_t)l.ho * l.wo * l.C;
+        for (int v = 0; v < h->ncam; ++v)
+            VF_HIP_CHECK(hipMemsetAsync(l.hst[0] + (size_t)v * h->cfg.max_batch * per, 0, (size_t)B * per * sizeof(float), st));
+    }
+    return VF_OK;
+}
+
 static int run_steps(vf_handle *h, int view, const BatchView &v, const BatchView &sh, int B,
                      const int32_t *goal_pix, hipStream_t st, bool skip_shared) {
+    if (h->cfg.arch == 3) {
+        if (view == 0) {
+            int rc = s3_zero_state(h, B, st);
+            if (rc) return rc;
+        }
+        LaunchSink sink{h, st};
+        return emit_rollout_s3(h, view, B, v.actions, goal_pix + (size_t)view * h->ND * 2, sink);
+    }
     if (!skip_shared) {
         int rc = zero_shared_state(h, sh, st);
         if (rc) return rc;
@@ -2096,7 +2236,7 @@ static int run_steps(vf_handle *h, int view, const BatchView &v, const BatchView
 // follows the width of the phases: the widest conv-LSTM phase of the 64 x 64 network has 8 items per sample at 128-row
 // tiles -> on below 96 samples per view.
 static int yield_for(const vf_handle *h, int B) {
-    if (!h->early_start) return 0;
+    if (!h->early_start || h->cfg.arch == 3) return 0;
     if (h->yield_budget >= 0) return h->yield_budget;
     const long long widest = (long long)B * h->ncam * std::max(1, (h->Hc / 2) * (h->Wc / 2) / 128);
     return widest < (long long)VF_YIELD_MAX_ITEMS * h->n_cu ? VF_YIELD_DEFAULT : 0;
@@ -2157,6 +2297,9 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
                 P.conv.wt_out = 1;
             // ... and so do the light layers (conv_epilogue's vectorised form: every conv / transposed-conv tile)
             if (P.type >= PH_CONV_RELU && P.type <= PH_CONVT_RAW && h->wt_publish && (VF_WT_DEFAULT & 2)) P.conv.wt_out = 1;
+            // arch 3: the raw epilogues store 16 bytes per lane (EPI_RAW needs whole channel quads; gates_raw_epilogue always)
+            if (P.type == PH_CONV_RAW3 && h->wt_publish && (VF_WT_DEFAULT & 2) && P.conv.Cout % 4 == 0) P.conv.wt_out = 1;
+            if (P.type == PH_GATES_RAW && h->wt_publish) P.conv.wt_out = 1;
             if (P.type == PH_CONV_PAIR) P.conv.fuse_next = &sc_host.d_phases[i].conv2;
             if (P.type != PH_TOP_FUSED) continue;
             P.conv.fuse_comp = &sc_host.d_phases[i].comp;
@@ -2183,7 +2326,9 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         sc_host.lds = bs.lds;
     }
     h->last_sched = skip_shared ? 1 : 0;
-    if (!skip_shared)
+    if (h->cfg.arch == 3) {
+        if ((rc = s3_zero_state(h, B, st))) return rc;
+    } else if (!skip_shared)
         for (int v = 0; v < h->ncam; ++v)
             if ((rc = zero_shared_state(h, h->shared_views[(size_t)v], st))) return rc;
     VF_HIP_CHECK(hipMemsetAsync(h->d_sync, 0, (kSyncHead + (size_t)sc_host.counters) * sizeof(int), st));
@@ -2254,9 +2399,12 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
         if ((rc = run_persistent(h, d_actions, B, goal_pix, st))) return rc;
     } else {
         const bool skip = shared_cache_hit(h, 1);
-        for (int v = 0; v < h->ncam; ++v)
-            if ((rc = run_steps(h, v, make_view(h, v, d_actions, 0), h->shared_views[(size_t)v], B, goal_pix, st, skip)))
-                return rc;
+        for (int v = 0; v < h->ncam; ++v) {
+            BatchView bv;
+            if (h->cfg.arch == 3) { memset(&bv, 0, sizeof(bv)); bv.actions = d_actions; }      // (arch 3 keeps its buffers in Savp3)
+            else bv = make_view(h, v, d_actions, 0);
+            if ((rc = run_steps(h, v, bv, h->shared_views[(size_t)v], B, goal_pix, st, skip))) return rc;
+        }
         h->shared_valid = h->dedup; h->shared_cfg = 1;
     }
     TaskWeights tw;
@@ -2377,7 +2525,7 @@ extern "C" int vf_debug_trace(uint64_t *events, uint32_t *counts) {
 
 int vf_set_dedup(vf_handle *h, int32_t enable) {
     if (!h) return fail(VF_ERR_INVALID, "null handle");
-    h->dedup = enable != 0;
+    h->dedup = enable != 0 && h->cfg.arch != 3;     // (arch 3 has no context de-duplication)
     h->shared_valid = false;
     return VF_OK;
 }

@@ -23,6 +23,7 @@
 #include "vf_conv_gsplit.h"
 #include "vf_fused_top.h"
 #include "vf_fc_tile.h"
+#include "vf_savp3.h"
 
 namespace vf {
 
@@ -31,8 +32,13 @@ enum PhaseType {
     PH_SA, PH_CDNA_FIN, PH_COMPOSITE,
     PH_TOP_FUSED,           // top transposed conv + compositing in one item (vf_fused_top.h)
     PH_CONV_PAIR,           // enc2 + enc3 in one item (conv_pair_epilogue, vf_conv_mfma.h)
-    PH_COND                 // arch 2: border-class biases of the tiled conditioning vector for one conv-LSTM (cond_bias_sample)
+    PH_COND,                // arch 2: border-class biases of the tiled conditioning vector for one conv-LSTM (cond_bias_sample)
+    // arch 3 (the published SAVP generator, vf_savp3.h): GEMM tiles that store raw outputs, element-wise items
+    PH_CONV_RAW3,           // conv, acc + bias (EPI_RAW)
+    PH_GATES_RAW,           // conv-LSTM gate GEMM on the gate-split 128-row tile, raw gate pre-activations (gates_raw_epilogue)
+    PH_EW                   // state FC / class biases / instance norm / cell / up-sampling / compositing layers (EwParams::op)
 };
+__host__ __device__ constexpr bool ph_is_conv(const int t) { return t <= PH_CONVT_RAW || t == PH_CONV_RAW3 || t == PH_GATES_RAW; }
 
 constexpr int kMaxDeps = 3;
 constexpr int kQueues = 8;                  // one ticket queue per XCD
@@ -81,6 +87,7 @@ struct PhaseDesc {
     FinParams fin;
     CompositeParams comp;
     CondParams cond;
+    EwParams ew;            // PH_EW
 };
 
 constexpr int kCtlWords = 64;               // LDS control block: [0..3] scheduler, [8..8+32) goal pixels, [40..44) state words
@@ -118,6 +125,10 @@ __device__ __forceinline__ void item_samples(const PhaseDesc &P, int local, int 
         case PH_CDNA_FIN: b0 = local; b1 = local + 1; break;
         case PH_COMPOSITE: b0 = local / P.gx; b1 = b0 + 1; break;      // gx = tiles per image
         case PH_FC_PARTIAL: b0 = 0; b1 = P.B; break;
+        case PH_EW:
+            if (P.ew.spi > 0) { b0 = local * P.ew.spi; b1 = min(b0 + P.ew.spi, P.B); }
+            else { b0 = local / P.gx; b1 = b0 + 1; }        // gx = items per sample
+            break;
         default: {
             const int bx = local / P.gy;    // channel group fastest: a sample's items are adjacent
             if (P.NI == 1) { b0 = bx / P.tiles_per_img; b1 = b0 + 1; }
@@ -181,6 +192,36 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void composite_t
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
     composite_tile<ND, K, FIRST>(const_params(p), tile, b, goal, tile_lds());
+}
+static __device__ __noinline__ __attribute__((not_tail_called)) void gates_raw_tile_call(const ConvParams *p, int bx, int by) {
+    conv_lstm_gsplit2_tile<4, const VF_CONST_AS ConvParams, true>(const_params(p), bx, by, tile_lds());
+}
+// the element-wise items of arch 3 (vf_savp3.h), one out-of-line body per operation (own register allocation each)
+#define VF_EW_BODY(NAME_, CALL_)                                                                                        \
+    static __device__ __noinline__ __attribute__((not_tail_called)) void NAME_(const EwParams *p_, int idx, int b0, int b1) { \
+        const VF_CONST_AS EwParams &p = const_params(p_);                                                               \
+        (void)idx; (void)b0; (void)b1;                                                                                  \
+        CALL_;                                                                                                          \
+    }
+VF_EW_BODY(ew_cond3_call, cond3_item(p.cond, b0, b1, tile_lds()))
+VF_EW_BODY(ew_inorm_call, inorm_item(p.norm, b0, idx, tile_lds()))
+VF_EW_BODY(ew_incell_call, incell_item(p.norm, b0, idx, tile_lds()))
+VF_EW_BODY(ew_upsample_call, upsample_item(p.up, b0, idx))
+#undef VF_EW_BODY
+static __device__ __noinline__ __attribute__((not_tail_called)) void ew_sa3_call(const EwParams *p_, int b0, int b1) {
+    const VF_CONST_AS EwParams &p = const_params(p_);
+    const int wave = threadIdx.x >> 6, b = b0 + wave;
+    if (b < b1) sa3_sample(p.sa, b, threadIdx.x & 63, tile_lds() + 128 * wave);
+}
+template <int ND>
+static __device__ __noinline__ __attribute__((not_tail_called)) void ew_transform_call(const EwParams *p_, int idx, int b) {
+    transform_item<ND>(const_params(p_).top, idx, b, tile_lds());
+}
+template <int ND>
+static __device__ __noinline__ __attribute__((not_tail_called)) void ew_compose_call(const EwParams *p_, int idx, int b, int view) {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
+    compose_item<ND>(const_params(p_).top, idx, b, goal, tile_lds());
 }
 static __device__ __noinline__ __attribute__((not_tail_called)) void small_item_call(const PhaseDesc *P, int type, int b0, int b1) {
     float *smem = tile_lds();
@@ -392,6 +433,21 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                     else if (P.comp.first_frame) composite_tile_call<ND, true, 10>(&P.comp, local % P.gx, b0, P.view);
                     else composite_tile_call<ND, false, 10>(&P.comp, local % P.gx, b0, P.view);
                     break;
+                case PH_CONV_RAW3: conv_tile_call<1, EPI_RAW, 1>(&P.conv, bx, by, 0); break;
+                case PH_GATES_RAW: gates_raw_tile_call(&P.conv, bx, by); break;
+                case PH_EW: {
+                    const int idx = P.ew.spi > 0 ? 0 : local - b0 * P.gx;
+                    switch (P.ew.op) {
+                        case EW_SA3: ew_sa3_call(&P.ew, b0, b1); break;
+                        case EW_COND3: ew_cond3_call(&P.ew, idx, b0, b1); break;
+                        case EW_INORM: ew_inorm_call(&P.ew, idx, b0, b1); break;
+                        case EW_INCELL: ew_incell_call(&P.ew, idx, b0, b1); break;
+                        case EW_UPSAMPLE: ew_upsample_call(&P.ew, idx, b0, b1); break;
+                        case EW_TRANSFORM: ew_transform_call<ND>(&P.ew, idx, b0); break;
+                        default: ew_compose_call<ND>(&P.ew, idx, b0, P.view); break;
+                    }
+                    break;
+                }
                 default: small_item_call(&P, P.type, b0, b1); break;
             }
         }
@@ -410,7 +466,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
         if (wave == 0) {
             // write-through items (ConvParams::wt_out: every global store of the tile was an sc1 / atomic store, drained
             // above by every wave) need no L2 write-back in front of their counters - CDNA guide section 6 G16, recipe R1
-            if (lane == 0 && !(P.type <= PH_CONVT_RAW && P.conv.wt_out != 0)) {
+            if (lane == 0 && !(ph_is_conv(P.type) && P.conv.wt_out != 0)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }

@@ -1,0 +1,640 @@
+// vf_savp3.h - the non-GEMM items of arch 3, the published SAVP generator (video_prediction/savp3_arch.py; Lee et al. 2018,
+// arXiv:1804.01523 appendix A; the reference only instantiates the class, visual_mpc/video_prediction/vpred_model_interface.py:52-58).
+//
+// What differs from the CDNA-core networks (arch 0 - 2) and why it needs its own items:
+//   * INSTANCE normalisation - per sample AND channel over H x W - follows every convolution and sits INSIDE the conv-LSTM
+//     cell (over the 4C gate pre-activations and over the new cell state).  A statistic of the whole image stands between a
+//     GEMM tile's accumulators and the values that depend on them, so the gate math cannot live in the GEMM epilogue: the
+//     GEMM tiles of arch 3 store raw outputs (EPI_RAW / the raw gate-split epilogue) and ONE element-wise item per (sample,
+//     channel group) owns all pixels of its channels - it computes the statistics itself (fixed order, float64: the result
+//     does not depend on the GEMM's tiling or on the batch), normalises, runs the cell update, takes the statistics of the
+//     new cell state, normalises again and writes c and h.  No cross-item reduction, no extra dependency hop per statistic.
+//   * conv + 2x2 average pool is ONE stride-2 convolution with the box-filtered kernel (k + 1) x (k + 1) (packed on the
+//     host): 2.8x (5x5) / 2.25x (3x3) fewer MACs than the literal pair, same sums up to fp32 association.
+//   * bilinear 2x up-sampling + 3x3 conv: the up-sampled tensor is materialised by an element-wise item (the 3x3 conv at the
+//     up-sampled resolution has the MAC count of any fused form - 36 (tap, parity) blocks per source pixel - so fusing would
+//     only save the round trip through memory).
+//   * the conditioning vector v = [a, s, rnn_z(z)] is tile-concatenated to the input of every conv and every conv-LSTM: as in
+//     arch 2 it never becomes GEMM rows - a spatially constant input contributes a bias that only depends on the pixel's
+//     border class (5 x 5 classes) - but here the tables follow each layer's geometry (pooled conv: 3 classes per axis,
+//     up-sampled conv: the bilinear kernel attenuates the outermost up-sampled row to 0.75) through a per-layer coefficient
+//     table f[class][tap]:  bias[ry][rx] = sum_ty f[ry][ty] sum_tx f[rx][tx] (W_cond . v)[ty][tx].
+//   * dependent masks: the mask head convolves [h_masks | the seven compositing layers], so the layers (CDNA warps with
+//     SYMMETRIC padding, previous, first, scratch) are materialised (EW_TRANSFORM) before the 3x3 mask conv and composed
+//     after it (EW_COMPOSE).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vf_conv_mfma.h"
+#include "vf_small_kernels.h"
+
+namespace vf {
+
+enum EwOp { EW_SA3 = 0, EW_COND3, EW_INORM, EW_INCELL, EW_UPSAMPLE, EW_TRANSFORM, EW_COMPOSE };
+
+constexpr int kTransCh = 32;        // floats per pixel of the materialised compositing layers (21 used: 4 warps, previous, first, scratch)
+constexpr int kMaskCh = 8;          // floats per pixel of the mask logits (7 used)
+constexpr int kScrCh = 4;           // floats per pixel of the raw scratch image (3 used)
+constexpr int kNumWarp3 = 4;        // CDNA kernels of the published generator
+
+struct Sa3Params {
+    const float *action; long long action_bs;   // [adim] = [a_env | z] per sample (0 stride: shared)
+    const float *state; long long state_bs;     // [sdim]
+    int adim, sdim, zdim;
+    const float *w_state, *b_state;             // [a_env + sdim][sdim], [sdim]
+    const float *w_rnnz, *b_rnnz;               // [2 zdim][4 zdim], [4 zdim]  (BasicLSTMCell: gate order i, j, f, o)
+    float *rnn_state;                           // [B][2 zdim] = (c, h), updated in place
+    int first;                                  // 1: the previous rnn state is zero
+    float *condvec;                             // [B][a_env + sdim + zdim] = [a, s, rnn_z]
+    float *state_out; long long state_out_bs;   // may be null
+};
+
+struct Cond3Params {
+    const float *condvec;       // [B][ncond]
+    int ncond;
+    const float *w;             // [KH * KH][ncond][Ctot]: the conditioning rows of the layer's (effective) kernel
+    int Ctot, KH;
+    float f[5][8];              // f[border class][tap]: weight with which a tap of the constant input reaches a pixel of that class
+    float *out;                 // [B][25][Ctot]
+};
+
+struct NormParams {
+    const float *in; long long in_bs;       // INORM: raw conv output [HW][C]; INCELL: raw gates [HW][4C]
+    const float *cond; long long cond_bs;   // border-class biases [25][C] / [25][4C], or null
+    const float *g0, *b0;                   // INORM: gain / offset [C]; INCELL: of the gate norm [4C]
+    const float *g1, *b1;                   // INCELL: of the cell-state norm [C]
+    const float *cprev; long long cprev_bs; // INCELL: previous cell state [HW][C], null = zero
+    float *out; long long out_bs;           // INORM: normalised (may alias in); INCELL: h
+    float *cout; long long cout_bs;         // INCELL: new cell state (may alias cprev)
+    int H, W, C, cpi, relu;
+    float eps;
+};
+
+struct UpParams {
+    const float *in0; long long in0_bs; int C0;
+    const float *in1; long long in1_bs; int C1;     // second source (skip connection), C1 = 0: none
+    float *out; long long out_bs;                   // [2h][2w][C0 + C1]
+    int h, w, rows;                                 // source size; output rows per item
+};
+
+struct TopParams {
+    int H, W, ND;
+    const float *prev_frame; long long prev_frame_bs;
+    const float *prev_distrib; long long prev_distrib_bs;
+    const double *prev_sums;                // [B][ND][blocks][2] partial sums of prev_distrib, or null (already normalised)
+    const float *first_frame, *first_distrib;
+    const float *kern;                      // [B][25][4]
+    const float *scr_raw;                   // [B][HW][kScrCh]
+    float *trans;                           // [B][HW][kTransCh]
+    float *transd;                          // [B][HW][4 ND]
+    const float *mlog;                      // [B][HW][kMaskCh]
+    float *out_frame; long long out_frame_bs;
+    float *out_distrib; long long out_distrib_bs;
+    double *out_sums;
+    int goal[kMaxDesig][2];                 // per-layer launches only (the persistent kernel takes them from its launch arguments)
+};
+
+struct EwParams {
+    int op, B;
+    int gx;             // items per sample (spi == 0)
+    int spi;            // > 0: an item covers spi consecutive samples (EW_SA3, EW_COND3)
+    union {
+        Sa3Params sa;
+        Cond3Params cond;
+        NormParams norm;
+        UpParams up;
+        TopParams top;
+    };
+};
+
+constexpr int kEwLdsFloats = 20 * 20 * 8 + 25 * 4 + 16 + 2 * 4 * 8 * 32;   // largest: EW_TRANSFORM halo; reductions [4][8][32] doubles
+
+// border class of coordinate y in an image of H rows: 0, 1 | 2 = interior | 3, 4   (H >= 4)
+__device__ __forceinline__ int cls5(const int y, const int H) { return y < 2 ? y : (y >= H - 2 ? y - (H - 5) : 2); }
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void st4(float *p, const f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+// ------------------------------------------------------------------------------------------ state FC + rnn_z + conditioning vector
+// one sample per wave; s = 128 floats of LDS scratch for this wave
+template <class PT>
+__device__ __forceinline__ void sa3_sample(const PT &p, const int b, const int t, float *s) {
+    const int a_env = p.adim - p.zdim, nsa = a_env + p.sdim, nz = p.zdim, ncond = nsa + nz;
+    if (t < a_env) s[t] = p.action[(long long)b * p.action_bs + t];
+    else if (t < nsa) s[t] = p.state[(long long)b * p.state_bs + (t - a_env)];
+    if (t < nz) {
+        s[32 + t] = p.action[(long long)b * p.action_bs + a_env + t];
+        s[32 + nz + t] = p.first ? 0.f : p.rnn_state[(long long)b * 2 * nz + nz + t];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (t < 4 * nz) {
+        float acc = 0.f;
+        for (int k = 0; k < 2 * nz; ++k) acc = fmaf(s[32 + k], p.w_rnnz[k * 4 * nz + t], acc);
+        s[64 + t] = acc + p.b_rnnz[t];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (t < nz) {
+        const float gi = s[64 + t], gj = s[64 + nz + t], gf = s[64 + 2 * nz + t], go = s[64 + 3 * nz + t];
+        const float c_old = p.first ? 0.f : p.rnn_state[(long long)b * 2 * nz + t];
+        float c_new, h_new;
+        lstm_cell(gi, gj, gf, go, c_old, c_new, h_new);
+        p.rnn_state[(long long)b * 2 * nz + t] = c_new;
+        p.rnn_state[(long long)b * 2 * nz + nz + t] = h_new;
+        p.condvec[(long long)b * ncond + nsa + t] = h_new;
+    }
+    if (t < nsa) p.condvec[(long long)b * ncond + t] = s[t];
+    if (p.state_out && t < p.sdim) {
+        float acc = 0.f;
+        for (int k = 0; k < nsa; ++k) acc = fmaf(s[k], p.w_state[k * p.sdim + t], acc);
+        p.state_out[(long long)b * p.state_out_bs + t] = acc + p.b_state[t];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ border-class biases of one layer
+// samples [b0, b1) (at most 4) per call; sv = 128 floats of LDS.  Separable: row sums over the taps a column class sees, then
+// over the rows a row class sees - in a fixed order (deterministic; independent of the batch the sample is rolled in).
+constexpr int kCond3PerItem = 4;
+template <class PT>
+__device__ __forceinline__ void cond3_item(const PT &p, const int b0, const int b1, float *sv) {
+    const int t = threadIdx.x, ns = b1 - b0, nc = p.ncond, KH = p.KH;
+    if (t < kCond3PerItem * 32) {
+        const int s = t >> 5, c = t & 31;
+        sv[t] = (s < ns && c < nc) ? p.condvec[(long long)(b0 + s) * nc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int col = t; col < p.Ctot; col += 256) {
+        for (int s0 = 0; s0 < ns; s0 += 2) {
+            float acc[2][25];
+#pragma unroll
+            for (int i = 0; i < 25; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+            for (int ty = 0; ty < KH; ++ty) {
+                float tt[2][6];
+#pragma unroll
+                for (int tx = 0; tx < 6; ++tx) {
+                    float a0 = 0.f, a1 = 0.f;
+                    if (tx < KH) {
+                        const float *wp = p.w + ((long long)(ty * KH + tx) * nc) * p.Ctot + col;
+                        for (int c = 0; c < nc; ++c) {
+                            const float w = wp[(long long)c * p.Ctot];
+                            a0 = fmaf(sv[s0 * 32 + c], w, a0);
+                            a1 = fmaf(sv[(s0 + 1) * 32 + c], w, a1);
+                        }
+                    }
+                    tt[0][tx] = a0; tt[1][tx] = a1;
+                }
+                float fy[5];
+#pragma unroll
+                for (int ry = 0; ry < 5; ++ry) fy[ry] = p.f[ry][ty];
+#pragma unroll
+                for (int rx = 0; rx < 5; ++rx) {
+                    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+                    for (int tx = 0; tx < 6; ++tx) {
+                        const float fx = p.f[rx][tx];       // (zero beyond the kernel)
+                        r0 = fmaf(fx, tt[0][tx], r0); r1 = fmaf(fx, tt[1][tx], r1);
+                    }
+#pragma unroll
+                    for (int ry = 0; ry < 5; ++ry) {
+                        acc[0][ry * 5 + rx] = fmaf(fy[ry], r0, acc[0][ry * 5 + rx]);
+                        acc[1][ry * 5 + rx] = fmaf(fy[ry], r1, acc[1][ry * 5 + rx]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (s0 + s >= ns) break;
+                float *o = p.out + (long long)(b0 + s0 + s) * 25 * p.Ctot + col;
+#pragma unroll
+                for (int i = 0; i < 25; ++i) o[(long long)i * p.Ctot] = acc[s][i];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ reductions of the norm items
+// v[i] <- sum over all threads of the workgroup that share this thread's index modulo nq (nq = 1, 2, 4, 8): lanes by a
+// fixed xor butterfly, the four waves in order through LDS ([4][8][NV] doubles).  Deterministic.
+template <int NV>
+__device__ __forceinline__ void ew_reduce(double (&v)[NV], const int nq, double *lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        for (int off = 32; off >= nq; off >>= 1) v[i] += __shfl_xor(v[i], off, 64);
+    __syncthreads();                        // (the previous use of lds is over)
+    if (lane < nq)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) lds[(wave * 8 + lane) * NV + i] = v[i];
+    __syncthreads();
+    const int q = lane & (nq - 1);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double a = 0.0;
+        for (int w = 0; w < 4; ++w) a += lds[(w * 8 + q) * NV + i];
+        v[i] = a;
+    }
+}
+
+__device__ __forceinline__ void in_scale_shift(const double su, const double sq, const double inv_n, const float eps,
+                                               const float g, const float b, float &scale, float &shift) {
+    const double m = su * inv_n;
+    double var = sq * inv_n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    const double sc = (double)g / sqrt(var + (double)eps);
+    scale = (float)sc;
+    shift = (float)((double)b - m * sc);
+}
+
+// relu(IN(x + class bias)) of the channels [grp * cpi, (grp + 1) * cpi) of sample b, all pixels
+template <class PT>
+__device__ __forceinline__ void inorm_item(const PT &p, const int b, const int grp, float *smem) {
+    const int tid = threadIdx.x;
+    const int nq = p.cpi >> 2, nq_log2 = 31 - __builtin_clz((unsigned)nq);
+    const int q = tid & (nq - 1), ps = tid >> nq_log2, ppp = kConvThreads >> nq_log2;
+    const int HW = p.H * p.W, C = p.C, c0 = grp * p.cpi + 4 * q;
+    const float *in = p.in + (long long)b * p.in_bs + c0;
+    const float *cond = p.cond ? p.cond + (long long)b * p.cond_bs + c0 : nullptr;
+    float *out = p.out + (long long)b * p.out_bs + c0;
+    const TileDiv div_w(p.W);
+    auto value = [&](const int px) {
+        f32x4 v = ld4(in + (long long)px * C);
+        if (cond) {
+            const int y = div_w.div(px), x = px - y * p.W;
+            const f32x4 cb = ld4(cond + (cls5(y, p.H) * 5 + cls5(x, p.W)) * C);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += cb[j];
+        }
+        return v;
+    };
+    double st[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = 0.0;
+    for (int px = ps; px < HW; px += ppp) {
+        const f32x4 v = value(px);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const double d = (double)v[j]; st[j] += d; st[4 + j] += d * d; }
+    }
+    ew_reduce<8>(st, nq, reinterpret_cast<double *>(smem));
+    float sc[4], sh[4];
+    const double inv_n = 1.0 / (double)HW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) in_scale_shift(st[j], st[4 + j], inv_n, p.eps, p.g0[c0 + j], p.b0[c0 + j], sc[j], sh[j]);
+    for (int px = ps; px < HW; px += ppp) {
+        f32x4 v = value(px);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = fmaf(v[j], sc[j], sh[j]);
+            if (p.relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        st4(out + (long long)px * C, v);
+    }
+}
+
+// The conv-LSTM cell behind its gate GEMM, channels [grp * cpi, ..) of sample b:  g = IN(raw gates + class bias);
+// c_new = c_prev * sigmoid(f + 1) + sigmoid(i) * tanh(j);  c = IN(c_new);  h = tanh(c) * sigmoid(o).
+// Three passes over the item's own elements; c_new and sigmoid(o) rest in the c / h buffers between passes 2 and 3
+// (a thread re-reads only what it wrote itself).
+template <class PT>
+__device__ __forceinline__ void incell_item(const PT &p, const int b, const int grp, float *smem) {
+    const int tid = threadIdx.x;
+    const int nq = p.cpi >> 2, nq_log2 = 31 - __builtin_clz((unsigned)nq);
+    const int q = tid & (nq - 1), ps = tid >> nq_log2, ppp = kConvThreads >> nq_log2;
+    const int HW = p.H * p.W, C = p.C, C4 = 4 * C, c0 = grp * p.cpi + 4 * q;
+    const float *in = p.in + (long long)b * p.in_bs + c0;
+    const float *cond = p.cond ? p.cond + (long long)b * p.cond_bs + c0 : nullptr;
+    const float *cprev = p.cprev ? p.cprev + (long long)b * p.cprev_bs + c0 : nullptr;
+    float *hout = p.out + (long long)b * p.out_bs + c0;
+    float *cout = p.cout + (long long)b * p.cout_bs + c0;
+    const TileDiv div_w(p.W);
+    double *red = reinterpret_cast<double *>(smem);
+    auto gates = [&](const int px, f32x4 (&g)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = ld4(in + (long long)px * C4 + k * C);
+        if (cond) {
+            const int y = div_w.div(px), x = px - y * p.W;
+            const float *cb = cond + (cls5(y, p.H) * 5 + cls5(x, p.W)) * C4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 a = ld4(cb + k * C);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[k][j] += a[j];
+            }
+        }
+    };
+    // ---- pass 1: statistics of the four gate maps of every channel
+    double st[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) st[i] = 0.0;
+    for (int px = ps; px < HW; px += ppp) {
+        f32x4 g[4];
+        gates(px, g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const double d = (double)g[k][j]; st[k * 4 + j] += d; st[16 + k * 4 + j] += d * d; }
+    }
+    ew_reduce<32>(st, nq, red);
+    const double inv_n = 1.0 / (double)HW;
+    float sc[4][4], sh[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            in_scale_shift(st[k * 4 + j], st[16 + k * 4 + j], inv_n, p.eps, p.g0[k * C + c0 + j], p.b0[k * C + c0 + j],
+                           sc[k][j], sh[k][j]);
+    // ---- pass 2: the cell update; statistics of the new cell state
+    double ct[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ct[i] = 0.0;
+    for (int px = ps; px < HW; px += ppp) {
+        f32x4 g[4];
+        gates(px, g);
+        f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+        if (cprev) cp = ld4(cprev + (long long)px * C);
+        f32x4 cn, so;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gi = fmaf(g[0][j], sc[0][j], sh[0][j]), gj = fmaf(g[1][j], sc[1][j], sh[1][j]);
+            const float gf = fmaf(g[2][j], sc[2][j], sh[2][j]), go = fmaf(g[3][j], sc[3][j], sh[3][j]);
+            cn[j] = fmaf(cp[j], sigmoidf_(gf + 1.0f), sigmoidf_(gi) * tanhf_(gj));
+            so[j] = sigmoidf_(go);
+            const double d = (double)cn[j];
+            ct[j] += d; ct[4 + j] += d * d;
+        }
+        st4(cout + (long long)px * C, cn);
+        st4(hout + (long long)px * C, so);
+    }
+    ew_reduce<8>(ct, nq, red);
+    float csc[4], csh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) in_scale_shift(ct[j], ct[4 + j], inv_n, p.eps, p.g1[c0 + j], p.b1[c0 + j], csc[j], csh[j]);
+    // ---- pass 3: normalised cell state, hidden state
+    for (int px = ps; px < HW; px += ppp) {
+        f32x4 cn = ld4(cout + (long long)px * C);
+        const f32x4 so = ld4(hout + (long long)px * C);
+        f32x4 hn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cn[j] = fmaf(cn[j], csc[j], csh[j]);
+            hn[j] = tanhf_(cn[j]) * so[j];
+        }
+        st4(cout + (long long)px * C, cn);
+        st4(hout + (long long)px * C, hn);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bilinear 2x up-sampling of concat[in0, in1]
+// out(2i + a, 2j + b) = sum over the two source rows / columns the transposed convolution with the kernel
+// [.25, .75, .75, .25] (stride 2, SAME) reaches: a = 0: .25 s[i-1] + .75 s[i];  a = 1: .75 s[i] + .25 s[i+1];  zero outside.
+template <class PT>
+__device__ __forceinline__ void upsample_item(const PT &p, const int b, const int band) {
+    const int C = p.C0 + p.C1, Cq = C >> 2, OW = 2 * p.w, OH = 2 * p.h;
+    const int y_begin = band * p.rows, n_rows = min(p.rows, OH - y_begin);
+    const int total = n_rows * OW * Cq;
+    const TileDiv div_cq(Cq), div_ow(OW);
+    float *out = p.out + (long long)b * p.out_bs;
+    for (int e = threadIdx.x; e < total; e += kConvThreads) {
+        const int pq = div_cq.div(e), cq = e - pq * Cq;
+        const int yl = div_ow.div(pq), X = pq - yl * OW, Y = y_begin + yl;
+        const int i = Y >> 1, a = Y & 1, j = X >> 1, bb = X & 1;
+        const int r0 = i - 1 + a, r1 = i + a, q0 = j - 1 + bb, q1 = j + bb;
+        const float wy0 = a ? 0.75f : 0.25f, wy1 = a ? 0.25f : 0.75f, wx0 = bb ? 0.75f : 0.25f, wx1 = bb ? 0.25f : 0.75f;
+        const int c = 4 * cq;
+        const float *src; int Cs;
+        if (c < p.C0) { src = p.in0 + (long long)b * p.in0_bs + c; Cs = p.C0; }
+        else { src = p.in1 + (long long)b * p.in1_bs + (c - p.C0); Cs = p.C1; }
+        auto tap = [&](const int r, const int qq) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)r < (unsigned)p.h && (unsigned)qq < (unsigned)p.w) v = ld4(src + (long long)(r * p.w + qq) * Cs);
+            return v;
+        };
+        const f32x4 v00 = tap(r0, q0), v01 = tap(r0, q1), v10 = tap(r1, q0), v11 = tap(r1, q1);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = fmaf(wy1 * wx1, v11[k], fmaf(wy1 * wx0, v10[k], fmaf(wy0 * wx1, v01[k], (wy0 * wx0) * v00[k])));
+        st4(out + ((long long)Y * OW + X) * C + c, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ the compositing layers
+__device__ __forceinline__ int reflect_sym(int v, const int n) {
+    v = v < 0 ? -v - 1 : (v >= n ? 2 * n - 1 - v : v);
+    return min(max(v, 0), n - 1);
+}
+
+// mass of the previous distributions (they are stored un-normalised with their block sums): s_dscale[d] = 1 / sum
+template <class PT>
+__device__ __forceinline__ void top_dscale(const PT &p, const int b, float *s_dscale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nblocks = sum_blocks(p.H, p.W);
+    for (int d = wave; d < p.ND; d += 4) {
+        float sc = 1.0f;
+        if (p.prev_sums) {
+            double su = 0.0;
+            const double *pp = p.prev_sums + ((long long)b * p.ND + d) * nblocks * 2;
+            for (int k = lane; k < nblocks; k += 64) su += pp[2 * k];
+            su = wave_sum(su);
+            sc = (float)(1.0 / su);
+        }
+        if (lane == 0) s_dscale[d] = sc;
+    }
+}
+
+// one 16 x 16 tile of sample b: [warp_0..3(previous frame), previous, first, sigmoid(scratch)] -> trans, warp_k(previous
+// distributions) -> transd.  The warps read the SYMMETRICALLY padded image (the published apply_cdna_kernels).
+template <int ND, class PT>
+__device__ __forceinline__ void transform_item(const PT &p, const int tile, const int b, float *smem) {
+    constexpr int TS = kCompTile, HS = TS + 4, PS = comp_px_stride(ND);
+    float *s_px = smem;                         // [HS * HS][PS]
+    float *s_kern = s_px + HS * HS * PS;        // [25][4]
+    float *s_dscale = s_kern + kTaps * 4;       // [ND]
+    const int tid = threadIdx.x;
+    const int tilesX = (p.W + TS - 1) / TS;
+    const int ty0 = (tile / tilesX) * TS, tx0 = (tile % tilesX) * TS;
+    top_dscale(p, b, s_dscale);
+    if (tid < kTaps * kNumWarp3) s_kern[tid] = p.kern[(long long)b * kTaps * kNumWarp3 + tid];
+    __syncthreads();
+    const float *pf = p.prev_frame + (long long)b * p.prev_frame_bs;
+    const float *pd = p.prev_distrib + (long long)b * p.prev_distrib_bs;
+    for (int i = tid; i < HS * HS; i += kConvThreads) {
+        const int ly = i / HS, lx = i - ly * HS;
+        const int y = reflect_sym(ty0 + ly - 2, p.H), x = reflect_sym(tx0 + lx - 2, p.W);
+        const long long o = (long long)y * p.W + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s_px[i * PS + c] = pf[o * 3 + c];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) s_px[i * PS + 3 + d] = pd[o * ND + d] * s_dscale[d];
+    }
+    __syncthreads();
+    const int ly = tid / TS, lx = tid - ly * TS;
+    const int y = ty0 + ly, x = tx0 + lx;
+    if (y >= p.H || x >= p.W) return;
+    float wf[kNumWarp3][3], wd[kNumWarp3][ND];
+#pragma unroll
+    for (int k = 0; k < kNumWarp3; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wf[k][c] = 0.f;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) wd[k][d] = 0.f;
+    }
+    // (one kernel row at a time: fully unrolled, the 25 taps' LDS reads are hoisted and the item needs all 256 VGPRs)
+#pragma unroll 1
+    for (int dy = 0; dy < kDnaKern; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < kDnaKern; ++dx) {
+            const f32x4 kr = ld4(s_kern + (dy * kDnaKern + dx) * 4);
+            const int sp = (ly + dy) * HS + (lx + dx);
+            const f32x4 a = ld4(s_px + sp * PS);
+            float di[ND];
+            di[0] = a[3];
+            if constexpr (ND > 1) {
+                const f32x4 c2 = ld4(s_px + sp * PS + 4);
+#pragma unroll
+                for (int d = 1; d < ND; ++d) di[d] = c2[d - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < kNumWarp3; ++k) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) wf[k][c] = fmaf(kr[k], a[c], wf[k][c]);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) wd[k][d] = fmaf(kr[k], di[d], wd[k][d]);
+            }
+        }
+    const long long o = (long long)y * p.W + x;
+    const long long ob = (long long)b * p.H * p.W + o;
+    float t[kTransCh];
+#pragma unroll
+    for (int k = 0; k < kNumWarp3; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[k * 3 + c] = wf[k][c];
+    const f32x4 ctr = ld4(s_px + ((ly + 2) * HS + lx + 2) * PS);
+    const f32x4 scr = ld4(p.scr_raw + ob * kScrCh);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        t[12 + c] = ctr[c];
+        t[15 + c] = p.first_frame[o * 3 + c];
+        t[18 + c] = sigmoidf_(scr[c]);
+    }
+#pragma unroll
+    for (int c = 21; c < kTransCh; ++c) t[c] = 0.f;
+    float *to = p.trans + ob * kTransCh;
+#pragma unroll
+    for (int k = 0; k < kTransCh / 4; ++k) st4(to + 4 * k, f32x4{t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]});
+    float *tdo = p.transd + ob * (kNumWarp3 * ND);
+#pragma unroll
+    for (int k = 0; k < kNumWarp3; ++k)
+#pragma unroll
+        for (int d = 0; d < ND; ++d) tdo[k * ND + d] = wd[k][d];
+}
+
+// one 16 x 16 tile of sample b: softmax of the mask logits, next frame, next (un-normalised) distributions, cost sums per
+// 4 x 16-pixel block (the layout scores_kernel / export_distrib_kernel and the next step's top_dscale read)
+template <int ND, class PT>
+__device__ __forceinline__ void compose_item(const PT &p, const int tile, const int b, const int *goal, float *smem) {
+    constexpr int TS = kCompTile;
+    float *s_dscale = smem;
+    const int tid = threadIdx.x;
+    const int tilesX = (p.W + TS - 1) / TS;
+    const int nblocks = sum_blocks(p.H, p.W);
+    const int ty0 = (tile / tilesX) * TS, tx0 = (tile % tilesX) * TS;
+    top_dscale(p, b, s_dscale);
+    __syncthreads();
+    const int ly = tid / TS, lx = tid - ly * TS;
+    const int y = ty0 + ly, x = tx0 + lx;
+    double cost[2 * ND];
+#pragma unroll
+    for (int i = 0; i < 2 * ND; ++i) cost[i] = 0.0;
+    if (y < p.H && x < p.W) {
+        const long long o = (long long)y * p.W + x;
+        const long long ob = (long long)b * p.H * p.W + o;
+        const f32x4 l0 = ld4(p.mlog + ob * kMaskCh), l1 = ld4(p.mlog + ob * kMaskCh + 4);
+        float m[7] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2]};
+        float mx = m[0];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) mx = fmaxf(mx, m[j]);
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { m[j] = __expf(m[j] - mx); den += m[j]; }
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) m[j] *= inv;
+        float t[24];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const f32x4 v = ld4(p.trans + ob * kTransCh + 4 * k);
+            t[4 * k] = v[0]; t[4 * k + 1] = v[1]; t[4 * k + 2] = v[2]; t[4 * k + 3] = v[3];
+        }
+        float *fo = p.out_frame + (long long)b * p.out_frame_bs + o * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a = m[0] * t[c];
+#pragma unroll
+            for (int j = 1; j < 7; ++j) a = fmaf(m[j], t[3 * j + c], a);
+            fo[c] = a;
+        }
+        const float *wd = p.transd + ob * (kNumWarp3 * ND);
+        const float *pd = p.prev_distrib + (long long)b * p.prev_distrib_bs + o * ND;
+        float *dout = p.out_distrib + (long long)b * p.out_distrib_bs + o * ND;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const float prev = pd[d] * s_dscale[d];
+            float a = m[0] * wd[d];
+#pragma unroll
+            for (int k = 1; k < kNumWarp3; ++k) a = fmaf(m[k], wd[k * ND + d], a);
+            a = fmaf(m[4], prev, a);
+            a = fmaf(m[5], p.first_distrib[o * ND + d], a);
+            a = fmaf(m[6], prev, a);            // the scratch layer's slot carries the previous distribution
+            dout[d] = a;
+            const float ry = (float)(y - goal[2 * d]), rx = (float)(x - goal[2 * d + 1]);
+            const float dist = sqrtf(fmaf(ry, ry, rx * rx));
+            cost[2 * d] = (double)a;
+            cost[2 * d + 1] = (double)a * (double)dist;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * ND; ++i) cost[i] = wave_sum(cost[i]);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int by = ty0 / kSumBlockH + wave, bxk = tx0 / kSumBlockW;
+    if (lane == 0 && by * kSumBlockH < p.H && tx0 < p.W) {
+        const int blk = by * sum_blocks_x(p.W) + bxk;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            double *dst = p.out_sums + (((long long)b * ND + d) * nblocks + blk) * 2;
+            dst[0] = cost[2 * d]; dst[1] = cost[2 * d + 1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dispatch of one item
+// `idx` = item index within its sample (spi == 0) / ignored (spi > 0: the item covers samples [b0, b1)); goal = this view's
+// goal pixels (EW_COMPOSE)
+template <int ND, class PT>
+__device__ __forceinline__ void ew_item(const PT &p, const int idx, const int b0, const int b1, const int *goal, float *smem) {
+    switch (p.op) {
+        case EW_SA3: {
+            const int wave = threadIdx.x >> 6, b = b0 + wave;
+            if (b < b1) sa3_sample(p.sa, b, threadIdx.x & 63, smem + 128 * wave);
+            break;
+        }
+        case EW_COND3: cond3_item(p.cond, b0, b1, smem); break;
+        case EW_INORM: inorm_item(p.norm, b0, idx, smem); break;
+        case EW_INCELL: incell_item(p.norm, b0, idx, smem); break;
+        case EW_UPSAMPLE: upsample_item(p.up, b0, idx); break;
+        case EW_TRANSFORM: transform_item<ND>(p.top, idx, b0, smem); break;
+        default: compose_item<ND>(p.top, idx, b0, goal, smem); break;
+    }
+}
+
+// per-layer launch: one workgroup per item
+template <int ND>
+VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads) void ew_kernel(const EwParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[kEwLdsFloats];
+    const int item = blockIdx.x;
+    int b0, b1, idx = 0;
+    if (p.spi > 0) { b0 = item * p.spi; b1 = min(b0 + p.spi, p.B); }
+    else { b0 = item / p.gx; b1 = b0 + 1; idx = item - b0 * p.gx; }
+    ew_item<ND>(p, idx, b0, b1, &p.top.goal[0][0], smem);
+}
+
+}  // namespace vf

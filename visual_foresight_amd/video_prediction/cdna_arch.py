@@ -223,13 +223,16 @@ class CdnaWeights(object):
         elif arch in ('savp', 'savp2'):
             from visual_foresight_amd.video_prediction.savp_arch import SavpConfig, Savp2Config
             file_cfg = (SavpConfig if arch == 'savp' else Savp2Config)(**manifest['config'])
+        elif arch == 'savp3':
+            from visual_foresight_amd.video_prediction.savp3_arch import Savp3Config
+            file_cfg = Savp3Config(**manifest['config'])
         else:
             raise ValueError('unknown architecture %r in %s' % (arch, model_dir))
         if cfg is not None and cfg.arch != arch:
             raise ValueError('checkpoint architecture %r does not match requested %r' % (arch, cfg.arch))
         if cfg is not None:
             mine, theirs = cfg.as_dict(), file_cfg.as_dict()
-            for k in ('height', 'width', 'adim', 'sdim', 'num_masks'):
+            for k in ('height', 'width', 'adim', 'sdim', 'num_masks') + (('zdim', 'layer_spec') if arch == 'savp3' else ()):
                 if mine[k] != theirs[k]:
                     raise ValueError('checkpoint %s=%r does not match requested %r' % (k, theirs[k], mine[k]))
             file_cfg = cfg      # ndesig / sequence_length are run-time choices, not weights

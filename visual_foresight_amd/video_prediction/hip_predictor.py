@@ -42,6 +42,7 @@ import numpy as np
 from visual_foresight_amd import _lib
 from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights
 from visual_foresight_amd.video_prediction.savp_arch import SavpConfig, Savp2Config
+from visual_foresight_amd.video_prediction.savp3_arch import Savp3Config
 from visual_foresight_amd.video_prediction.sharding import dist_info as _dist_info, shard_bounds, all_gather_rows
 
 
@@ -65,16 +66,18 @@ class HipVPredEvaluation(object):
         self.n_draws = int(hp.get('n_draws', 1))        # latent draws per action (stochastic_predictor.py)
         self.run_batch_size = int(hp.get('run_batch_size', 200)) * self.n_draws
         self.seed = int(hp.get('seed', 0))
-        # 'arch': 'cdna' (cdna_arch.py, default), 'savp' (savp_arch.py: four scales, first-frame compositing) or 'savp2'
-        # (savp + the conditioning vector in every conv-LSTM + the published seven-layer compositing)
+        # 'arch': 'cdna' (cdna_arch.py, default), 'savp' (savp_arch.py: four scales, first-frame compositing), 'savp2'
+        # (savp + the conditioning vector in every conv-LSTM + the published seven-layer compositing) or 'savp3' (savp3_arch.py:
+        # the published SAVP generator; 'zdim' of the 'adim' channels are the latent, 'layer_spec' overrides the size rule)
         self.arch = str(hp.get('arch', 'cdna'))
-        if self.arch not in ('cdna', 'savp', 'savp2'):
-            raise ValueError("arch must be 'cdna', 'savp' or 'savp2', got %r" % (self.arch,))
-        cfg_cls = {'cdna': CdnaConfig, 'savp': SavpConfig, 'savp2': Savp2Config}[self.arch]
+        if self.arch not in ('cdna', 'savp', 'savp2', 'savp3'):
+            raise ValueError("arch must be 'cdna', 'savp', 'savp2' or 'savp3', got %r" % (self.arch,))
+        cfg_cls = {'cdna': CdnaConfig, 'savp': SavpConfig, 'savp2': Savp2Config, 'savp3': Savp3Config}[self.arch]
+        extra = dict(zdim=int(hp.get('zdim', 8)), layer_spec=int(hp.get('layer_spec', 0))) if self.arch == 'savp3' else {}
         self.cfg = cfg_cls(height=hp.get('image_height', 64), width=hp.get('image_width', 64),
                            adim=hp.get('adim', 4), sdim=hp.get('sdim', 5),
                            ndesig=hp.get('designated_pixel_count', 1), n_context=self.n_context,
-                           sequence_length=self.sequence_length)
+                           sequence_length=self.sequence_length, **extra)
         if not torch.cuda.is_available():
             raise _lib.VfError('HipVPredEvaluation needs a ROCm GPU (no CPU fallback)')
         world = _dist_info()[1]
@@ -120,7 +123,8 @@ class HipVPredEvaluation(object):
         self.precision = {'fp32': 0, '0': 0, 0: 0, 'bf16x6': 1, '1': 1, 1: 1}[precision]
         self._c_cfg = _lib.VfConfig(c.height, c.width, c.adim, c.sdim, c.ndesig, c.n_context,
                                     c.sequence_length, c.num_masks, self.run_batch_size,
-                                    self.device_index, self.precision, self.n_cam, self.n_draws, c.arch_id)
+                                    self.device_index, self.precision, self.n_cam, self.n_draws, c.arch_id,
+                                    getattr(c, 'zdim', 0), getattr(c, 'layer_spec', 0))
         self._handle = ctypes.c_void_p()
         _lib.check(self._libh.vf_create(ctypes.byref(self._c_cfg), ctypes.byref(self._handle)))
         self.set_dedup(int(hp.get('dedup', os.environ.get('VF_DEDUP', 1))))

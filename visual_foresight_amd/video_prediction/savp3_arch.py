@@ -1,0 +1,174 @@
+"""Architecture table of ``arch = 'savp3'`` (``vf_config.arch = 3``): the PUBLISHED SAVP generator.
+
+BASELINE config 5 / SURVEY 8f rank 3.  The reference only instantiates ``SAVPVideoPredictionModel`` from the absent
+``video_prediction`` package (``visual_mpc/video_prediction/vpred_model_interface.py:52-58``), so - as for every network
+here - this module is the normative description of what the engine implements, **parity unpinned**.  It follows the
+generator cell of Lee et al. 2018 (arXiv:1804.01523, appendix A; the public implementation's ``SAVPCell`` with its
+default hyper-parameters) layer for layer; ``savp_arch.py`` (``arch = 1 / 2``) lists its departures from that network,
+this table has none left that it knows of.  Per time step (NHWC, float32, TensorFlow "SAME" padding)::
+
+    v    = [a_t, s_t, rnn_z(z_t)]                 conditioning vector; rnn_z = a dense LSTM cell with nz units on z_t
+    x    = concat[frame_t, frame_0]               current frame (ground truth while t < n_context) and FIRST context frame
+    for i, (C, rnn) in enumerate(encoder):        # conv + 2x2 average pool
+        x = relu(IN(avgpool2(conv k x k (tile_concat[x, v], ->C) + b)))      k = 5 for i = 0, else 3
+        if rnn: x = convlstm_i(tile_concat[x, v])
+        layer[i] = x
+    for j, (C, rnn) in enumerate(decoder):        # bilinear 2x upsampling + conv
+        x = x if j == 0 else concat[x, layer[n_enc - j - 1]]
+        x = relu(IN(conv3x3(upsample2(tile_concat[x, v]), ->C) + b))
+        if rnn: x = convlstm(tile_concat[x, v])
+    top  = x                                       full resolution
+    convlstm(u): g = IN(conv5x5(concat[u, h_prev], ->4C))            (no bias; instance norm over the 4C gate maps)
+                 i, j, f, o = split(g);  c = IN(c_prev * sigmoid(f + 1) + sigmoid(i) * tanh(j));  h = tanh(c) * sigmoid(o)
+    kern    = normalise_taps(relu(FC(flatten(layer[n_enc - 1]), ->5*5*4) - 1e-12) + 1e-12)          four CDNA kernels
+    scratch = sigmoid(conv3x3(relu(IN(conv3x3(top, ->32))), ->3))
+    layers  = [warp_0..3(frame_t), frame_t, frame_0, scratch]        warp = 5x5 depthwise, SYMMETRIC padding
+    masks   = softmax_c(conv3x3(concat[relu(IN(conv3x3(top, ->32))), layers], ->7))       ("dependent" masks)
+    frame'  = sum_i masks_i * layers_i
+    distr'  = normalise_hw(sum_i masks_i * [warp_0..3(distr_t), distr_t, distr_0, distr_t]_i)
+    state'  = FC([a_t, s_t], ->sdim)
+
+``IN`` = instance normalisation (per sample and channel over H x W, biased variance, eps 1e-6, learned gain / offset).
+Encoder / decoder tables by ``min(H, W)`` as in the public code: >= 128: ``[(32, -), (64, R), (128, R), (256, R)]`` /
+``[(256, R), (128, R), (64, R), (32, -)]``; >= 64 (the paper's network, five conv-LSTMs of 32 / 64 / 128 / 64 / 32
+channels): ``[(32, R), (64, R), (128, R)]`` / ``[(64, R), (32, R), (16, -)]``; >= 32: ``[(32, R), (64, R)]`` /
+``[(32, R), (16, -)]``.  ``layer_spec`` overrides the size rule (64 on 128 x 128 frames = the paper's table at twice the
+resolution).
+
+Canonical tensors (float32, C order; conv ``[kh, kw, cin, cout]`` with input channels in concatenation order -
+``[x | v]`` for the convs, ``[x | v | h_prev]`` for the conv-LSTMs): ``h{i}c/w,b`` conv of layer i (encoder layers first,
+then the decoder's), ``h{i}n/g,b`` its instance norm, ``h{i}l/w`` the conv-LSTM kernel, ``h{i}lg/g,b`` the gate norm
+(4C), ``h{i}lc/g,b`` the cell-state norm; ``hm*`` / ``hs*`` the hidden layers of the mask / scratch heads, ``scratch``,
+``masks``, ``cdna``, ``state``, ``rnnz/w [zdim + nz, 4 nz]``, ``rnnz/b``.
+
+The engine's ``adim`` INCLUDES the latent channels (``StochasticHipPredictor`` appends ``z_t`` to every action); ``zdim`` says
+how many of them there are.
+"""
+from collections import OrderedDict
+
+from visual_foresight_amd.video_prediction.cdna_arch import CdnaConfig, CdnaWeights  # noqa: F401
+
+NGF = 32
+N_WARP = 4          # num_transformed_images
+DNA_KERN = 5
+IN_EPS = 1e-6
+
+
+def layer_specs(height, width, layer_spec=0):
+    scale = int(layer_spec) if layer_spec else min(height, width)
+    if scale >= 128:
+        return ([(NGF, False), (NGF * 2, True), (NGF * 4, True), (NGF * 8, True)],
+                [(NGF * 8, True), (NGF * 4, True), (NGF * 2, True), (NGF, False)])
+    if scale >= 64:
+        return ([(NGF, True), (NGF * 2, True), (NGF * 4, True)],
+                [(NGF * 2, True), (NGF, True), (NGF // 2, False)])
+    if scale >= 32:
+        return ([(NGF, True), (NGF * 2, True)], [(NGF, True), (NGF // 2, False)])
+    raise ValueError('savp3 needs images of at least 32 x 32')
+
+
+class Savp3Config(CdnaConfig):
+    arch = 'savp3'
+    arch_id = 3
+
+    def __init__(self, height=64, width=64, adim=12, sdim=5, ndesig=1, n_context=2, sequence_length=15,
+                 num_masks=N_WARP, ncam=1, zdim=8, layer_spec=0):
+        if num_masks != N_WARP:
+            raise ValueError('savp3 composes %d CDNA warps (num_masks = %d)' % (N_WARP, N_WARP))
+        self.zdim, self.layer_spec = int(zdim), int(layer_spec)
+        if not 0 < self.zdim < adim:
+            raise ValueError('adim (%d) includes the zdim (%d) latent channels' % (adim, zdim))
+        self.enc, self.dec = layer_specs(height, width, layer_spec)
+        f = 1 << len(self.enc)
+        if height % f or width % f or height // f < 4 or width // f < 4:
+            raise ValueError('savp3 with %d scales needs sizes that are multiples of %d and at least %d' % (len(self.enc), f, 4 * f))
+        super(Savp3Config, self).__init__(height, width, adim, sdim, ndesig, n_context, sequence_length, num_masks, ncam)
+
+    def as_dict(self):
+        return dict(super(Savp3Config, self).as_dict(), zdim=self.zdim, layer_spec=self.layer_spec)
+
+    @property
+    def ncond(self):
+        return (self.adim - self.zdim) + self.sdim + self.zdim      # [a, s, rnn_z]
+
+    def layer_table(self):
+        """[(index, kind 'enc' / 'dec', conv kernel, input channels (without the conditioning), Cout, rnn, input size,
+        output size)] of every layer, in execution order."""
+        H, W = self.height, self.width
+        rows, outs = [], []
+        cin, h, w = 6, H, W
+        for i, (C, rnn) in enumerate(self.enc):
+            rows.append((i, 'enc', 5 if i == 0 else 3, cin, C, rnn, (h, w), (h // 2, w // 2)))
+            h, w, cin = h // 2, w // 2, C
+            outs.append(C)
+        n_enc = len(self.enc)
+        for j, (C, rnn) in enumerate(self.dec):
+            if j > 0:
+                cin += outs[n_enc - j - 1]
+            rows.append((n_enc + j, 'dec', 3, cin, C, rnn, (h, w), (2 * h, 2 * w)))
+            h, w, cin = 2 * h, 2 * w, C
+        return rows
+
+    def tensor_shapes(self):
+        nc, nz = self.ncond, self.zdim
+        t = OrderedDict()
+        for i, kind, k, cin, C, rnn, _, _ in self.layer_table():
+            t['h%dc/w' % i] = (k, k, cin + nc, C); t['h%dc/b' % i] = (C,)
+            t['h%dn/g' % i] = (C,); t['h%dn/b' % i] = (C,)
+            if rnn:
+                t['h%dl/w' % i] = (5, 5, C + nc + C, 4 * C)
+                t['h%dlg/g' % i] = (4 * C,); t['h%dlg/b' % i] = (4 * C,)
+                t['h%dlc/g' % i] = (C,); t['h%dlc/b' % i] = (C,)
+        top = self.dec[-1][0]
+        for name in ('hm', 'hs'):
+            t[name + '/w'] = (3, 3, top, NGF); t[name + '/b'] = (NGF,)
+            t[name + 'n/g'] = (NGF,); t[name + 'n/b'] = (NGF,)
+        t['scratch/w'] = (3, 3, NGF, 3); t['scratch/b'] = (3,)
+        t['masks/w'] = (3, 3, NGF + 3 * (N_WARP + 3), N_WARP + 3); t['masks/b'] = (N_WARP + 3,)
+        f = 1 << len(self.enc)
+        fc_in = (self.height // f) * (self.width // f) * self.enc[-1][0]
+        t['cdna/w'] = (fc_in, DNA_KERN * DNA_KERN * N_WARP); t['cdna/b'] = (DNA_KERN * DNA_KERN * N_WARP,)
+        t['state/w'] = ((self.adim - self.zdim) + self.sdim, self.sdim); t['state/b'] = (self.sdim,)
+        t['rnnz/w'] = (self.zdim + nz, 4 * nz); t['rnnz/b'] = (4 * nz,)
+        return t
+
+    def macs_per_sample_step(self):
+        """Algorithmic MACs of the network AS THE CHECKPOINT DESCRIBES IT: stride-1 convolutions at the input resolution in
+        front of the pools, 3 x 3 convolutions at the up-sampled resolution, the conditioning channels as convolution
+        rows.  (The engine executes fewer: conv + pool as one stride-2 convolution, the conditioning as bias tables -
+        ``executed_macs_per_sample_step``.)"""
+        H, W, nc = self.height, self.width, self.ncond
+        out = OrderedDict()
+        for i, kind, k, cin, C, rnn, (hi, wi), (ho, wo) in self.layer_table():
+            r = (hi, wi) if kind == 'enc' else (ho, wo)
+            out['h%dc' % i] = r[0] * r[1] * k * k * (cin + nc) * C
+            if rnn:
+                out['h%dl' % i] = ho * wo * 25 * (2 * C + nc) * 4 * C
+        top = self.dec[-1][0]
+        out['hm'] = out['hs'] = H * W * 9 * top * NGF
+        out['scratch'] = H * W * 9 * NGF * 3
+        out['masks'] = H * W * 9 * (NGF + 3 * (N_WARP + 3)) * (N_WARP + 3)
+        shp = self.tensor_shapes()
+        out['cdna_fc'] = shp['cdna/w'][0] * shp['cdna/w'][1]
+        out['warp_frame'] = H * W * 25 * 3 * N_WARP
+        out['warp_distrib'] = H * W * 25 * self.ndesig * N_WARP
+        out['state_fc'] = shp['state/w'][0] * shp['state/w'][1]
+        out['rnnz'] = shp['rnnz/w'][0] * shp['rnnz/w'][1]
+        return out
+
+    def executed_macs_per_sample_step(self):
+        """What the engine's matrix pipe executes per sample-step: conv + pool as one (k + 1) x (k + 1) stride-2 convolution,
+        no conditioning rows (they are border-class bias tables computed with scalar FMAs), channel padding not counted."""
+        H, W = self.height, self.width
+        out = OrderedDict()
+        for i, kind, k, cin, C, rnn, (hi, wi), (ho, wo) in self.layer_table():
+            out['h%dc' % i] = ho * wo * ((k + 1) ** 2 if kind == 'enc' else 9) * cin * C
+            if rnn:
+                out['h%dl' % i] = ho * wo * 25 * 2 * C * 4 * C
+        top = self.dec[-1][0]
+        out['hm'] = out['hs'] = H * W * 9 * top * NGF
+        out['scratch'] = H * W * 9 * NGF * 3
+        out['masks'] = H * W * 9 * (NGF + 3 * (N_WARP + 3)) * (N_WARP + 3)
+        shp = self.tensor_shapes()
+        out['cdna_fc'] = shp['cdna/w'][0] * shp['cdna/w'][1]
+        return out

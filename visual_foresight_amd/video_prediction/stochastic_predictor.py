@@ -41,7 +41,7 @@ class StochasticHipPredictor(HipVPredEvaluation):
         self.adim = int(hp.get('adim', 4))
         self._calls = 0
         self._z = None
-        inner = dict(hp, adim=self.adim + self.zdim, n_draws=self.n_latent, arch=hp.get('arch', 'savp'))
+        inner = dict(hp, adim=self.adim + self.zdim, n_draws=self.n_latent, arch=hp.get('arch', 'savp'), zdim=self.zdim)
         super(StochasticHipPredictor, self).__init__(model_path, inner, n_gpus=n_gpus, first_gpu=first_gpu)
 
     def draw_latents(self, T):
