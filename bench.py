@@ -82,9 +82,13 @@ def parse():
                          'pixel_cost_controller.py:57)')
     ap.add_argument('--precision', choices=('fp32', 'bf16x6'), default=os.environ.get('VF_PRECISION', 'fp32'),
                     help='primary precision mode (the other one is reported as alt_precision)')
-    ap.add_argument('--network', choices=('savp', 'savp2'), default='savp',
-                    help='generator of the c5 workload: savp (vf_config.arch 1) or savp2 (arch 2: the conditioning vector in '
-                         'every conv-LSTM, published seven-layer compositing; exact fp32 only)')
+    ap.add_argument('--network', choices=('savp', 'savp2', 'savp3'), default='savp',
+                    help='generator of the c5 workload: savp (vf_config.arch 1), savp2 (arch 2: the conditioning vector in '
+                         'every conv-LSTM, published seven-layer compositing; exact fp32 only) or savp3 (arch 3: the published '
+                         'SAVP generator - instance norm, conv + pool / up-sampling + conv, dependent masks; exact fp32 only)')
+    ap.add_argument('--layer-spec', type=int, default=0, choices=(0, 32, 64, 128),
+                    help='savp3: 0 = the layer table the public code selects by image size (128 x 128: six conv-LSTMs up to '
+                         '256 channels); 64 = the paper\'s five-cell table')
     ap.add_argument('--no-alt', action='store_true', help='skip the alt_precision measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
@@ -364,7 +368,10 @@ class Bench(object):
             policy.update(registration_warper=smooth_flow_warper, register_region=True)
         if self.draws:
             from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
-            policy['predictor_class'] = StochasticHipPredictor.with_options(n_latent=self.draws, arch=self.args.network)
+            opts = dict(n_latent=self.draws, arch=self.args.network)
+            if self.args.network == 'savp3' and self.args.layer_spec:
+                opts['layer_spec'] = self.args.layer_spec
+            policy['predictor_class'] = StochasticHipPredictor.with_options(**opts)
         if self.per_rank != 200:
             policy['vpred_batch_size'] = self.per_rank      # engine buffers sized for one rank's shard
         if self.ndesig != 1:
@@ -492,11 +499,22 @@ class Bench(object):
             return None
         rollouts_per_launch = m['rollouts'] / m['launches']
         macs = float(sum(pred.cfg.macs_per_sample_step().values()))
-        flops = 2.0 * macs * steps * rollouts_per_launch
+        # networks whose checkpoint describes more MACs than the matrix pipe runs (savp2 / savp3: the conditioning channels are
+        # border-class bias tables; savp3: conv + pool is one stride-2 convolution) are priced on the EXECUTED count; the
+        # checkpoint's own count is reported beside it and kept away from the MFMA peak
+        executed = getattr(pred.cfg, 'executed_macs_per_sample_step', None)
+        priced = float(sum(executed().values())) if executed else macs
+        flops = 2.0 * priced * steps * rollouts_per_launch
         tf = flops / (1e-3 * m['kernel_ms'] / m['launches']) / 1e12
-        return {'flops_per_launch': flops, 'tflops': tf, 'frac_of_fp32_mfma_peak': tf / PEAK_FP32_MFMA_TFLOPS,
-                'what': '2 x %.3f GMAC per sample-step x %d steps x %d single-view rollouts per launch / avg launch '
-                        'duration' % (macs / 1e9, steps, rollouts_per_launch)}
+        out = {'flops_per_launch': flops, 'tflops': tf, 'frac_of_fp32_mfma_peak': tf / PEAK_FP32_MFMA_TFLOPS,
+               'what': '2 x %.3f GMAC per sample-step x %d steps x %d single-view rollouts per launch / avg launch '
+                       'duration' % (priced / 1e9, steps, rollouts_per_launch)}
+        if executed:
+            out['what'] += ' (MACs the matrix pipe executes; the checkpoint describes %.3f GMAC per sample-step: conditioning ' \
+                           'channels as convolution rows%s - those run as scalar-FMA bias tables / one fused stride-2 conv)' % (
+                               macs / 1e9, ', stride-1 convs in front of the pools' if pred.cfg.arch == 'savp3' else '')
+            out['checkpoint_gmacs_per_sample_step'] = macs / 1e9
+        return out
 
     def roofline(self, m, precision):
         tf = m['flops'] / (m['kernel_ms'] * 1e-3) / 1e12 if m['kernel_ms'] > 0 else None
@@ -599,7 +617,7 @@ class Bench(object):
         }
         self.attach_traffic(result['roofline'], primary)
 
-        if not a.no_alt and not (self.draws and a.network == 'savp2'):       # (arch 2 is built for exact fp32 only)
+        if not a.no_alt and not (self.draws and a.network in ('savp2', 'savp3')):   # (arch 2 / 3 are built for exact fp32 only)
             other = 'bf16x6' if primary == 'fp32' else 'fp32'
             am = self.measure(other)
             result['alt_precision'] = {

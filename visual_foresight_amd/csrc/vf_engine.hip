@@ -2321,7 +2321,10 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
         for (int q = 0; q < kQueues; ++q) sc_host.total_q[q] = bs.total_q[q];
         sc_host.phases = (int)bs.phases.size();
         sc_host.types.clear(); sc_host.nitems.clear();
-        for (const PhaseDesc &P : bs.phases) { sc_host.types.push_back(P.type); sc_host.nitems.push_back(P.n_items); }
+        for (const PhaseDesc &P : bs.phases) {      // (element-wise phases of arch 3 report 100 + their operation)
+            sc_host.types.push_back(P.type == PH_EW ? 100 + P.ew.op : P.type);
+            sc_host.nitems.push_back(P.n_items);
+        }
         sc_host.flops = bs.flops;
         sc_host.lds = bs.lds;
     }

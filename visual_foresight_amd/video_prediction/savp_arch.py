@@ -129,10 +129,12 @@ class Savp2Config(SavpConfig):
       convolution up to fp32 association, at +0 matrix work instead of one more 32-channel chunk per cell;
     * **the published compositing**: FOUR CDNA kernels (``cdna/w`` is ``[fc_in, 5 * 5 * 4]``), and seven compositing
       layers in the published order - ``[warp_0 .. warp_3, previous frame, first frame, scratch image]`` - under one
-      channel softmax (``masks/w`` is ``[1, 1, 32, 7]``); designated-pixel distributions follow the same masks, the
-      scratch layer carrying no mass.
+      channel softmax (``masks/w`` is ``[1, 1, 32, 7]``); designated-pixel distributions follow the same masks, with the
+      PREVIOUS distribution standing in for the scratch entry (the scratch image has no distribution of its own; as the
+      public code, ``composite_pixel`` and ``OracleSavp2`` do).
 
-    Still departing from the published network (none of it pinned by the reference): layer normalisation where SAVP
+    ``arch = 'savp3'`` (``savp3_arch.py``) is the published network without these departures.  Still departing here
+    (none of it pinned by the reference): layer normalisation where SAVP
     normalises per instance and channel (inside the conv-LSTM cells too: gates and cell state), strided / transposed
     convolutions for conv + average-pool / bilinear-upsample + conv, the channel widths and the seven-cell depth of
     the CDNA core (SAVP at 64 x 64: five cells of 32 / 64 / 128 / 64 / 32 channels), 1 x 1 heads where SAVP has 3 x 3
@@ -182,5 +184,18 @@ class Savp2Config(SavpConfig):
         out['cdna_fc'] = shp['cdna/w'][0] * shp['cdna/w'][1]
         out['warp_frame'] = H * W * DNA_KERN * DNA_KERN * 3 * N_WARP2
         out['warp_distrib'] = H * W * DNA_KERN * DNA_KERN * self.ndesig * N_WARP2
+        return out
+
+    def executed_macs_per_sample_step(self):
+        """What the matrix pipe runs: the conditioning channels of every conv-LSTM are border-class bias tables (scalar FMAs
+        in ``PH_COND`` items), not GEMM rows - so this, not the checkpoint's count above, is priced against the MFMA peak."""
+        out = self.macs_per_sample_step()
+        H, W = self.height, self.width
+        nsa = self.adim + self.sdim
+        shp = self.tensor_shapes()
+        res = {'lstm1': 4, 'lstm2': 4, 'lstm3': 8, 'lstm4': 8, 'lstm5': 16, 'lstm6': 8, 'lstm7': 4}
+        for name, div in res.items():
+            kh, kw, cin, cout = shp[name + '/w']
+            out[name] = (H // div) * (W // div) * kh * kw * (cin - nsa) * cout
         return out
 
