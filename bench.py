@@ -473,7 +473,28 @@ class Bench(object):
         ranks = [None] * self.world
         dist.all_gather_object(ranks, mine)
         means = [r['allgather_mean_ms'] for r in ranks if r['allgather_mean_ms'] is not None]
+        # proof of transport that needs no NCCL_DEBUG log: a device all-gather of the rank ids through the SAME process group
+        # the score rows travel on must come back as 0 .. N-1 on every rank; the RCCL version and the peer-access matrix of
+        # the devices say what the ranks could have talked over
+        on_gpu = dist.get_backend() == 'nccl'
+        ids = torch.full((1,), self.rank, dtype=torch.int64, device=self.dev if on_gpu else 'cpu')
+        got = [torch.empty_like(ids) for _ in range(self.world)]
+        dist.all_gather(got, ids)
+        ids_ok = [int(t.item()) for t in got] == list(range(self.world))
+        all_ok = [None] * self.world
+        dist.all_gather_object(all_ok, bool(ids_ok))
+        try:
+            rccl_version = '.'.join(str(v) for v in torch.cuda.nccl.version()) if on_gpu else None
+        except Exception as e:       # (informational only)
+            rccl_version = 'unavailable: %r' % (e,)
+        devs = sorted({r['device'] for r in ranks})
+        peer = None
+        if on_gpu and len(devs) > 1:
+            peer = {'%d->%d' % (i, j): bool(torch.cuda.can_device_access_peer(i, j)) for i in devs for j in devs if i != j}
         return {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                'rccl_version': rccl_version,
+                'rank_id_allgather_verified_on_every_rank': bool(all(all_ok)),
+                'peer_access': peer,
                 'devices': [r['device'] for r in ranks],
                 'distinct_gpus': len({(r['uuid'] or r['device']) for r in ranks}),
                 'allgather_ms_per_cem_iter': {'mean_over_ranks': float(np.mean(means)) if means else None,
@@ -613,6 +634,13 @@ class Bench(object):
             # line's string - the sharded job planned bit for bit what one GPU plans
             'elites_identical_across_ranks': m['elites_identical_across_ranks'],
             'scores_sha': m['scores_sha'],
+            # what the digest was taken over: two lines are only comparable when these agree (the frame history and the
+            # position in the candidate stream depend on --steps / --warmup) - see compare_lines()
+            'scores_sha_over': {'workload': a.workload, 'samples': self.M, 'horizon': T, 'iterations': iters,
+                                'steps': a.steps, 'warmup': a.warmup, 'seed': 0, 'precision': primary,
+                                'network': getattr(m['pred'], 'arch', 'cdna'), 'layer_spec': a.layer_spec,
+                                'views': self.ncam, 'designated_pixels_per_view': self.ndesig,
+                                'latent_draws_per_action': self.draws},
             'scores_sha_per_rank': m['scores_sha_per_rank'] if self.world > 1 else None,
         }
         self.attach_traffic(result['roofline'], primary)
@@ -641,6 +669,16 @@ class Bench(object):
             print(json.dumps(result), flush=True)
         if self.world > 1:
             self.dist.destroy_process_group()
+
+
+def compare_lines(a, b):
+    """Do two bench lines (dicts) show the same plans?  'equal' / 'mismatch' when both hashed the same job (``scores_sha_over``
+    agrees: same workload, candidates, --steps, --warmup, seed, precision, network), else 'not comparable' - a different
+    warm-up moves the frame history and the position in the candidate stream, so different strings then prove nothing."""
+    oa, ob = a.get('scores_sha_over'), b.get('scores_sha_over')
+    if not oa or not ob or oa != ob:
+        return 'not comparable'
+    return 'equal' if a.get('scores_sha') == b.get('scores_sha') else 'mismatch'
 
 
 if __name__ == '__main__':

@@ -80,9 +80,26 @@ def test_two_rank_line_and_collective_evidence(single, launcher):
     assert r['elites_identical_across_ranks'] is True
     assert r['scores_sha_per_rank'] == [r['scores_sha']] * 2
     assert r['scores_sha'] == single['scores_sha'], 'the 2-rank job planned something else than one GPU'
+    import bench
+    assert r['scores_sha_over'] == single['scores_sha_over'] and bench.compare_lines(r, single) == 'equal'
+    assert c['rank_id_allgather_verified_on_every_rank'] is True
+    assert (c['rccl_version'] is not None) == (c['backend'] == 'nccl')
     assert all(x['avg_launch_us'] > 0 for x in c['ranks'])
     lo, hi = c['avg_launch_us_min_max_over_ranks']
     assert 0 < lo <= hi
+
+
+def test_lines_with_different_warmups_are_not_comparable(single):
+    """``scores_sha`` is one string per (workload, candidates, --steps, --warmup, seed): a line run with another warm-up
+    hashes other planning calls - the comparison says 'not comparable', never 'mismatch'."""
+    import bench
+    other = _line([sys.executable, 'bench.py', '--gpus', '1', '--samples', '24', '--steps', '2', '--warmup', '2', '--no-alt',
+                   '--no-cpu-baseline'])
+    assert other['scores_sha_over']['warmup'] == 2 and single['scores_sha_over']['warmup'] == 1
+    assert other['scores_sha'] != single['scores_sha']
+    assert bench.compare_lines(other, single) == 'not comparable'
+    assert bench.compare_lines(single, dict(single)) == 'equal'
+    assert bench.compare_lines(single, dict(single, scores_sha='0' * 16)) == 'mismatch'
 
 
 def test_build_then_smoke_in_one_process():

@@ -21,3 +21,8 @@ def test_host_side_is_clean_under_asan_ubsan():
     assert 'runtime error' not in proc.stdout and 'AddressSanitizer' not in proc.stdout
     # the 2-view 600-sample schedule (BASELINE configs[2]) was built and verified
     assert 'ncam 2 prec 0  B=600  full' in proc.stdout
+    # include/vf_hip.h: "No exception crosses this boundary" - injected std::bad_alloc / std::exception / foreign throws in
+    # vf_create, vf_load_weights and the schedule builder come back as status codes, nothing leaks, the handle stays usable
+    assert 'status codes returned, handle reusable' in proc.stdout
+    # arch 3 (the published SAVP generator): its schedules - every layer table - were built and verified too
+    assert '128x128 adim 12 nd 1 ncam 1 prec 0  B=125  full: 2450163 items' in proc.stdout

@@ -12,11 +12,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "../../include/vf_hip.h"
 
 extern "C" int vf_set_fuse_top(vf_handle *h, int32_t enable);
+extern "C" int vf_selftest_inject(int32_t where, int32_t kind);
 extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared, int64_t *out_items,
                                     uint64_t *out_upload_checksum);
 
@@ -102,6 +104,46 @@ int main() {
     if (vf_create(&bad7, &h) == 0) { std::fprintf(stderr, "zdim with arch 0 accepted\n"); rc = 1; }
     vf_config bad8 = {72, 64, 12, 5, 1, 2, 15, 4, 8, 0, 0, 1, 1, 3, 8, 128};   // four scales need multiples of 16
     if (vf_create(&bad8, &h) == 0) { std::fprintf(stderr, "arch 3 / four scales at 72x64 accepted\n"); rc = 1; }
+    // "No exception crosses this boundary" (include/vf_hip.h): a std::bad_alloc / std::exception / foreign throw inside the
+    // schedule builder, the weight packer or vf_create comes back as a status code with vf_last_error() set, leaks nothing
+    // (ASan's leak check runs at exit) and leaves the handle usable and destroyable
+    {
+        vf_config cfg = {64, 64, 4, 5, 1, 2, 5, 10, 16, 0, 0, 1, 1, 0, 0, 0};
+        const size_t n = vf_weight_count(&cfg);
+        std::vector<float> blob(n, 0.01f);
+        vf_handle *hh = nullptr;
+        const int want_code[3] = {VF_ERR_NOMEM, VF_ERR_INVALID, VF_ERR_INVALID};
+        const char *want_msg[3] = {"out of memory", "exception: injected failure", "unknown exception"};
+        for (int kind = 0; kind < 3; ++kind) {
+            vf_selftest_inject(3, kind);
+            hh = reinterpret_cast<vf_handle *>(1);
+            const int r = vf_create(&cfg, &hh);
+            if (r != want_code[kind] || hh != nullptr || std::string(vf_last_error()) != want_msg[kind]) {
+                std::fprintf(stderr, "vf_create under injected failure %d: rc %d, '%s'\n", kind, r, vf_last_error()); rc = 1;
+            }
+        }
+        if (vf_create(&cfg, &hh)) { std::fprintf(stderr, "vf_create after the injected failures: %s\n", vf_last_error()); rc = 1; }
+        for (int kind = 0; kind < 3 && hh; ++kind) {
+            vf_selftest_inject(2, kind);
+            int r = vf_load_weights(hh, blob.data(), blob.size());
+            if (r != want_code[kind] || std::string(vf_last_error()) != want_msg[kind]) {
+                std::fprintf(stderr, "vf_load_weights under injected failure %d: rc %d, '%s'\n", kind, r, vf_last_error()); rc = 1;
+            }
+            if (vf_load_weights(hh, blob.data(), blob.size())) { std::fprintf(stderr, "reload after failure: %s\n", vf_last_error()); rc = 1; }
+            vf_selftest_inject(1, kind);
+            int64_t items = 0; uint64_t sum = 0;
+            r = vf_selftest_schedule(hh, 7, 0, &items, &sum);
+            if (r != want_code[kind] || std::string(vf_last_error()) != want_msg[kind]) {
+                std::fprintf(stderr, "build_schedule under injected failure %d: rc %d, '%s'\n", kind, r, vf_last_error()); rc = 1;
+            }
+            if (vf_selftest_schedule(hh, 7, 0, &items, &sum) || items <= 0) {
+                std::fprintf(stderr, "schedule after failure: %s\n", vf_last_error()); rc = 1;
+            }
+        }
+        if (hh && vf_destroy(hh)) { std::fprintf(stderr, "vf_destroy after the injected failures failed\n"); rc = 1; }
+        std::printf("  injected failures (bad_alloc, std::exception, foreign) in vf_create / vf_load_weights / build_schedule: %s\n",
+                    rc ? "FAILED" : "status codes returned, handle reusable");
+    }
     std::printf(rc ? "HOST SELFTEST FAILED\n" : "HOST SELFTEST OK\n");
     return rc;
 }

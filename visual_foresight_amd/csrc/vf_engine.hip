@@ -51,6 +51,47 @@ static int fail(int code, const std::string &msg) {
     return code;
 }
 
+// "No exception crosses this boundary" (include/vf_hip.h): every extern "C" body runs inside VF_API_TRY / VF_API_CATCH.  The
+// out-of-memory handler must not allocate: its message fits the small-string buffer of g_last_error.
+template <class R> static R api_error(int code);
+template <> int api_error<int>(int code) { return code; }
+template <> size_t api_error<size_t>(int) { return 0; }
+template <> double api_error<double>(int) { return 0.0; }
+#define VF_API_TRY try {
+#define VF_API_CATCH_CLEANUP(RET_, CLEANUP_)                                                               \
+    } catch (const std::bad_alloc &) {                                                                     \
+        CLEANUP_                                                                                           \
+        g_last_error.assign("out of memory");                                                              \
+        return api_error<RET_>(VF_ERR_NOMEM);                                                              \
+    } catch (const std::exception &e_) {                                                                   \
+        CLEANUP_                                                                                           \
+        try { g_last_error = std::string("exception: ") + e_.what(); } catch (...) { g_last_error.assign("exception"); } \
+        return api_error<RET_>(VF_ERR_INVALID);                                                            \
+    } catch (...) {                                                                                        \
+        CLEANUP_                                                                                           \
+        g_last_error.assign("unknown exception");                                                          \
+        return api_error<RET_>(VF_ERR_INVALID);                                                            \
+    }
+#define VF_API_CATCH(RET_) VF_API_CATCH_CLEANUP(RET_, {})
+
+// Failure injection of the ASan / UBSan host build (tools/sanitize/host_selftest.cc): the next pass through injection point
+// `where` throws - 0: std::bad_alloc, 1: std::runtime_error, 2: an int - so the tests can show that the status code and
+// vf_last_error() come back, nothing leaks and the handle stays usable.
+#ifdef VF_HOST_SELFTEST
+#include <stdexcept>
+static int g_inject_where = 0, g_inject_kind = 0;
+static void inject_point(int where) {
+    if (g_inject_where != where) return;
+    g_inject_where = 0;
+    if (g_inject_kind == 0) throw std::bad_alloc();
+    if (g_inject_kind == 1) throw std::runtime_error("injected failure");
+    throw 42;
+}
+#define VF_INJECT(W_) inject_point(W_)
+#else
+#define VF_INJECT(W_) do { } while (0)
+#endif
+
 #define VF_HIP_CHECK(expr)                                                                  \
     do {                                                                                    \
         hipError_t err_ = (expr);                                                           \
@@ -783,12 +824,15 @@ int vf_abi_version(void) { return VF_ABI_VERSION; }
 const char *vf_last_error(void) { return g_last_error.c_str(); }
 
 size_t vf_weight_count(const vf_config *cfg) {
+    VF_API_TRY
     if (validate(cfg)) return 0;
     auto t = tensor_table(*cfg);
     return t.back().offset + t.back().size();
+    VF_API_CATCH(size_t)
 }
 
 double vf_macs_per_sample_step(const vf_config *cfg) {
+    VF_API_TRY
     if (validate(cfg)) return 0.0;
     if (cfg->arch == 3) return s3_macs(*cfg);
     const bool savp = cfg->arch >= 1;
@@ -811,6 +855,7 @@ double vf_macs_per_sample_step(const vf_config *cfg) {
     macs += (double)fc->shape[0] * fc->shape[1] + (double)sw->shape[0] * sw->shape[1];
     macs += (double)HF * WF * kTaps * (3 + cfg->ndesig) * (cfg->arch == 2 ? cfg->num_masks - 2 : cfg->num_masks);
     return macs;
+    VF_API_CATCH(double)
 }
 
 }  // extern "C"
@@ -1046,6 +1091,8 @@ static int cdna_create(vf_handle *h) {
 extern "C" {
 
 int vf_create(const vf_config *cfg, vf_handle **out) {
+    vf_handle *made = nullptr;     // (released if anything below throws)
+    VF_API_TRY
     if (!out) return fail(VF_ERR_INVALID, "null out pointer");
     *out = nullptr;
     int rc = validate(cfg);
@@ -1054,6 +1101,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
     VF_HIP_CHECK(hipSetDevice(cfg->device));
 #endif
     vf_handle *h = new vf_handle();
+    made = h;
     h->cfg = *cfg;
     h->ncam = std::max(1, cfg->ncam);
     h->n_draws = std::max(1, cfg->n_draws);
@@ -1078,6 +1126,7 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
 
     rc = cfg->arch == 3 ? s3_create(h) : cdna_create(h);
     if (rc) { vf_destroy(h); return rc; }
+    VF_INJECT(3);
 #ifndef VF_HOST_SELFTEST
     if (hipMemset(h->d_sync, 0, kSyncHead * sizeof(int)) != hipSuccess || hipMemset(h->d_status, 0, sizeof(int)) != hipSuccess) {
         vf_destroy(h);
@@ -1101,9 +1150,11 @@ int vf_create(const vf_config *cfg, vf_handle **out) {
 #endif
     *out = h;
     return VF_OK;
+    VF_API_CATCH_CLEANUP(int, { if (made) vf_destroy(made); if (out) *out = nullptr; })
 }
 
 int vf_destroy(vf_handle *h) {
+    VF_API_TRY
     if (!h) return VF_OK;
 #ifdef VF_HOST_SELFTEST
     if (h->fake_base) munmap(h->fake_base, h->fake_size);
@@ -1120,10 +1171,13 @@ int vf_destroy(vf_handle *h) {
     s3_free(h);
     delete h;
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_load_weights(vf_handle *h, const float *blob_all, size_t n_floats) {
+    VF_API_TRY
     if (!h || !blob_all) return fail(VF_ERR_INVALID, "null handle or blob");
+    VF_INJECT(2);
     const size_t want = h->blob_floats * h->ncam;
     if (n_floats != want)
         return fail(VF_ERR_INVALID, "weight blob has " + std::to_string(n_floats) + " floats, expected " +
@@ -1244,11 +1298,13 @@ int vf_load_weights(vf_handle *h, const float *blob_all, size_t n_floats) {
     h->have_weights = true;
     h->shared_valid = false;
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 #ifndef VF_HOST_SELFTEST
 int vf_set_context(vf_handle *h, const uint8_t *d_frames, const float *d_states, const float *d_ctx_actions,
                    const float *d_ctx_distrib, void *stream) {
+    VF_API_TRY
     if (!h || !d_frames || !d_states || !d_ctx_distrib) return fail(VF_ERR_INVALID, "null argument");
     const int nc = h->cfg.n_context;
     if (nc > 1 && !d_ctx_actions) return fail(VF_ERR_INVALID, "context actions required when n_context > 1");
@@ -1265,6 +1321,7 @@ int vf_set_context(vf_handle *h, const uint8_t *d_frames, const float *d_states,
     h->have_context = true;
     h->shared_valid = false;        // the shared units are functions of the context
     return VF_OK;
+    VF_API_CATCH(int)
 }
 #endif
 
@@ -1920,6 +1977,7 @@ struct BuiltSchedule {
 // the views advance together and a phase's items of both views are neighbours in ticket order.
 static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &out) {
     std::vector<ScheduleSink> sinks(h->ncam);
+    VF_INJECT(1);
     int counters = 0, rc;
     out.flops = 0.0;
     size_t max_lds = 0;
@@ -2011,6 +2069,7 @@ static bool in_allocs(const vf_handle *h, const void *p, size_t bytes) {
 
 extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared, int64_t *out_items,
                                     uint64_t *out_upload_checksum) {
+    VF_API_TRY
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     BuiltSchedule bs;
     int rc = build_schedule(h, B, skip_shared != 0, bs);
@@ -2168,12 +2227,19 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
     if (out_items) *out_items = bs.items;
     if (out_upload_checksum) *out_upload_checksum = h->upload_checksum;
     return VF_OK;
+    VF_API_CATCH(int)
+}
+extern "C" int vf_selftest_inject(int32_t where, int32_t kind) {
+    g_inject_where = where; g_inject_kind = kind;
+    return VF_OK;
 }
 extern "C" int vf_set_fuse_top(vf_handle *h, int32_t enable) {      // (the device build defines it further down)
+    VF_API_TRY
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->fuse_top = enable != 0;
     h->fuse_pair = enable != 0;
     return VF_OK;
+    VF_API_CATCH(int)
 }
 #else   // ------------------------------------------------------------------ device execution
 
@@ -2386,6 +2452,7 @@ extern "C" {
 
 int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *goal_pix, float finalweight,
                const float *task_weights, double *d_scores, double *d_scores_per_task, void *stream) {
+    VF_API_TRY
     if (!h || !d_actions || !goal_pix || !d_scores) return fail(VF_ERR_INVALID, "null argument");
     if (!h->have_weights) return fail(VF_ERR_NOWEIGHTS, "vf_load_weights has not been called");
     if (!h->have_context) return fail(VF_ERR_NOCONTEXT, "vf_set_context has not been called");
@@ -2423,9 +2490,11 @@ int vf_rollout(vf_handle *h, const float *d_actions, int32_t B, const int32_t *g
     VF_HIP_CHECK(hipGetLastError());
     h->last_B = B;
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_set_persistent(vf_handle *h, int32_t enable) {
+    VF_API_TRY
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->persistent = enable != 0;
 #ifdef VF_DEBUG_KNOBS
@@ -2433,16 +2502,20 @@ int vf_set_persistent(vf_handle *h, int32_t enable) {
     if (const char *e = getenv("VF_EARLY_START")) h->early_start = atoi(e) != 0;
 #endif
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_set_fuse_top(vf_handle *h, int32_t enable) {
+    VF_API_TRY
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->fuse_top = enable != 0;
     h->fuse_pair = enable != 0 && h->pair_allowed;
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_set_sched_option(vf_handle *h, int32_t option, int32_t value) {
+    VF_API_TRY
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     switch (option) {
         case VF_OPT_YIELD_BUDGET:
@@ -2455,15 +2528,19 @@ int vf_set_sched_option(vf_handle *h, int32_t option, int32_t value) {
         default:
             return fail(VF_ERR_INVALID, "unknown scheduling option " + std::to_string(option));
     }
+    VF_API_CATCH(int)
 }
 
 int vf_set_xcd_queues(vf_handle *h, int32_t enable) {
+    VF_API_TRY
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->xcd_queues = enable ? kQueues : 1;
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_device_status(vf_handle *h, int32_t *status) {
+    VF_API_TRY
     if (!h || !status) return fail(VF_ERR_INVALID, "null argument");
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
     VF_HIP_CHECK(hipDeviceSynchronize());
@@ -2473,27 +2550,33 @@ int vf_device_status(vf_handle *h, int32_t *status) {
         h->shared_valid = false;
     }
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 // debugging aid: make the next rollouts fail as if a producer never arrived (tests of the in-band
 // failure path); the word is cleared again by vf_device_status
 int vf_debug_poison_status(vf_handle *h) {
+    VF_API_TRY
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
     VF_HIP_CHECK(hipDeviceSynchronize());
     const int one = 1;
     VF_HIP_CHECK(hipMemcpy(h->d_status, &one, sizeof(int), hipMemcpyHostToDevice));
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 // debugging aid: per-phase (type, items, wait ticks, run ticks) of the last persistent rollout
 int vf_set_phase_stats(vf_handle *h, int32_t enable) {
+    VF_API_TRY
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->phase_stats = enable != 0;
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_debug_phase_stats(vf_handle *h, int32_t max_phases, int32_t *types, int32_t *items, uint64_t *wait_run) {
+    VF_API_TRY
     if (!h || !h->phase_stats) return fail(VF_ERR_INVALID, "no phase statistics (vf_set_phase_stats)");
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
     VF_HIP_CHECK(hipDeviceSynchronize());
@@ -2502,10 +2585,12 @@ int vf_debug_phase_stats(vf_handle *h, int32_t max_phases, int32_t *types, int32
     for (int i = 0; i < n; ++i) { types[i] = sc.types[i]; items[i] = sc.nitems[i]; }
     VF_HIP_CHECK(hipMemcpy(wait_run, h->d_stats, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return n;
+    VF_API_CATCH(int)
 }
 
 #ifdef VF_TILE_STATS
 int vf_debug_tile_clocks(uint64_t *out /*[32][8]*/, int32_t reset) {
+    VF_API_TRY
     if (hipDeviceSynchronize() != hipSuccess) return fail(VF_ERR_HIP, "sync failed");
     VF_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(vf::g_tile_clk), sizeof(uint64_t) * 256));
     if (reset) {
@@ -2513,28 +2598,34 @@ int vf_debug_tile_clocks(uint64_t *out /*[32][8]*/, int32_t reset) {
         VF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(vf::g_tile_clk), zeros, sizeof(zeros)));
     }
     return VF_OK;
+    VF_API_CATCH(int)
 }
 #endif
 
 #ifdef VF_TRACE
 // diagnostic build: the event log of the last persistent launch, [512 workgroups][8192] words + the event counts
 extern "C" int vf_debug_trace(uint64_t *events, uint32_t *counts) {
+    VF_API_TRY
     if (hipDeviceSynchronize() != hipSuccess) return fail(VF_ERR_HIP, "sync failed");
     VF_HIP_CHECK(hipMemcpyFromSymbol(events, HIP_SYMBOL(vf::g_trace), sizeof(uint64_t) * vf::kTraceWgs * vf::kTraceMax));
     VF_HIP_CHECK(hipMemcpyFromSymbol(counts, HIP_SYMBOL(vf::g_trace_n), sizeof(uint32_t) * vf::kTraceWgs));
     return VF_OK;
+    VF_API_CATCH(int)
 }
 #endif
 
 int vf_set_dedup(vf_handle *h, int32_t enable) {
+    VF_API_TRY
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->dedup = enable != 0 && h->cfg.arch != 3;     // (arch 3 has no context de-duplication)
     h->shared_valid = false;
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_export(vf_handle *h, int32_t first, int32_t count, float *d_frames, float *d_distrib, float *d_states,
               void *stream) {
+    VF_API_TRY
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     if (first < 0 || count < 1 || first + count > h->last_B)
         return fail(VF_ERR_INVALID, "sample range outside the last rollout");
@@ -2566,11 +2657,13 @@ int vf_export(vf_handle *h, int32_t first, int32_t count, float *d_frames, float
         VF_HIP_CHECK(hipGetLastError());
     }
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_register(vf_handle *h, const float *d_current, const float *d_reference, const float *d_flow,
                 const int32_t *d_pix, int32_t ntask, int32_t region, int32_t clip_sub, float *d_warped,
                 float *d_warp_pts, float *d_desig, float *d_err, void *stream) {
+    VF_API_TRY
     if (!h || !d_current || !d_reference || !d_flow || !d_pix || !d_desig || !d_err)
         return fail(VF_ERR_INVALID, "null argument");
     if (ntask < 1 || region < 0 || (2 * region + 1) * (2 * region + 1) > kRegMaxWin || (clip_sub != 0 && clip_sub != 1))
@@ -2587,6 +2680,7 @@ int vf_register(vf_handle *h, const float *d_current, const float *d_reference, 
                        d_pix, h->ncam, ntask, h->H, h->W, region, clip_sub, d_desig, d_err);
     VF_HIP_CHECK(hipGetLastError());
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 // RCCL is bound at first use (dlopen of the library the process already carries - PyTorch ships
@@ -2627,6 +2721,7 @@ static const int kNcclFloat64 = 8;      // ncclFloat64 in nccl.h
 
 int vf_allgather_scores(vf_handle *h, void *nccl_comm, const double *d_local, int32_t n_local, double *d_all,
                         void *stream) {
+    VF_API_TRY
     if (!h || !nccl_comm || !d_local || !d_all || n_local < 1) return fail(VF_ERR_INVALID, "null or empty argument");
     int rc = bind_rccl();
     if (rc) return rc;
@@ -2634,9 +2729,11 @@ int vf_allgather_scores(vf_handle *h, void *nccl_comm, const double *d_local, in
     rc = g_rccl.all_gather(d_local, d_all, (size_t)n_local, kNcclFloat64, nccl_comm, stream);
     if (rc != 0) return fail(VF_ERR_HIP, "ncclAllGather failed with ncclResult_t " + std::to_string(rc));
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_comm_init_all(int32_t n, const int32_t *devices, void **comms) {
+    VF_API_TRY
     if (n < 1 || !devices || !comms) return fail(VF_ERR_INVALID, "null or empty argument");
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < i; ++j)
@@ -2649,19 +2746,23 @@ int vf_comm_init_all(int32_t n, const int32_t *devices, void **comms) {
     rc = g_rccl.comm_init_all(comms, n, devs.data());
     if (rc != 0) return fail(VF_ERR_HIP, "ncclCommInitAll failed with ncclResult_t " + std::to_string(rc));
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_comm_destroy(void *comm) {
+    VF_API_TRY
     if (!comm) return VF_OK;
     int rc = bind_rccl();
     if (rc) return rc;
     rc = g_rccl.comm_destroy(comm);
     if (rc != 0) return fail(VF_ERR_HIP, "ncclCommDestroy failed with ncclResult_t " + std::to_string(rc));
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_allgather_scores_group(int32_t n, vf_handle *const *hs, void *const *comms, const double *const *d_local,
                               int32_t n_local, double *const *d_all, void *const *streams) {
+    VF_API_TRY
     if (n < 1 || !hs || !comms || !d_local || !d_all || n_local < 1) return fail(VF_ERR_INVALID, "null or empty argument");
     for (int i = 0; i < n; ++i)
         if (!hs[i] || !comms[i] || !d_local[i] || !d_all[i]) return fail(VF_ERR_INVALID, "null entry " + std::to_string(i));
@@ -2681,17 +2782,21 @@ int vf_allgather_scores_group(int32_t n, vf_handle *const *hs, void *const *comm
     if (first_bad) return fail(VF_ERR_HIP, "grouped ncclAllGather failed (" + std::to_string(first_bad) + ")");
     if (rc != 0) return fail(VF_ERR_HIP, "ncclGroupEnd failed with ncclResult_t " + std::to_string(rc));
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_set_profiling(vf_handle *h, int32_t enable) {
+    VF_API_TRY
     if (!h) return fail(VF_ERR_INVALID, "null handle");
     h->profiling = enable != 0;
     h->ev_used = 0;
     h->prof_flops = 0.0;
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 int vf_get_profile(vf_handle *h, double *kernel_ms, int64_t *launches, double *flops, double *busy_ms) {
+    VF_API_TRY
     if (!h || !kernel_ms || !launches || !flops || !busy_ms) return fail(VF_ERR_INVALID, "null argument");
     VF_HIP_CHECK(hipSetDevice(h->cfg.device));
     double ms = 0.0;
@@ -2723,6 +2828,7 @@ int vf_get_profile(vf_handle *h, double *kernel_ms, int64_t *launches, double *f
     h->ev_used = 0;
     h->prof_flops = 0.0;
     return VF_OK;
+    VF_API_CATCH(int)
 }
 
 }  // extern "C"
