@@ -78,6 +78,52 @@ def test_experiment_policy_dicts_drop_in(golden_dir):
         assert ctrl._hp.start_planning == case['start_planning_after_ctor']
 
 
+def test_every_experiment_file_of_the_reference_drops_in(golden_dir):
+    """ALL experiment files of the reference that configure a ``PixelCostController`` / ``Register_Gtruth_Controller`` (18),
+    loaded from the reference's own sources by tools/make_golden.py - nothing hand-typed: the product's controllers give the
+    same hyper-parameter values where the reference's constructor succeeds and raise the same exception type where the
+    reference itself refuses its own file (keys that are no hyper-parameters, a list-valued ``num_samples``).  Two of the
+    files do not even import in the reference (a syntax error; a sampler module that is gone): pinned as such.
+    Reference: policy.py:51-63, cem_base_controller.py:66-76."""
+    from visual_foresight_amd.policy.cem_controllers import RegisterGtruthController
+    want = _meta(golden_dir, 'experiment_files')['files']
+    assert len(want) == 18
+    classes = {'PixelCostController': PixelCostController, 'Register_Gtruth_Controller': RegisterGtruthController}
+    named = {'class:CorrelatedNoiseSampler': CorrelatedNoiseSampler, 'class:GaussianCEMSampler': GaussianCEMSampler}
+    product_only = {'trade_off_reg', 'registration_warper', 'registration_on_device'}      # RegisterGtruthController's plug-in keys
+    seen = {'ok': 0, 'raises': 0, 'unloadable': 0}
+    for rel, case in sorted(want.items()):
+        if 'unloadable' in case:
+            assert case['unloadable'] in ('SyntaxError', 'ImportError'), rel
+            seen['unloadable'] += 1
+            continue
+        pdict = {k: named.get(v, v) if isinstance(v, str) else v for k, v in case['policy'].items()}
+        assert not any(isinstance(v, str) and v.startswith('class:') for v in pdict.values()), (rel, pdict)
+        fake = make_fake_predictor_class(5, case['ag_params']['image_height'], case['ag_params']['image_width'])
+        cls = classes[case['controller']]
+        pdict['predictor_class'] = fake
+        if 'raises' in case:
+            with pytest.raises(Exception) as e:
+                with quiet():
+                    cls(dict(case['ag_params']), pdict, 0, 1)
+            assert type(e.value).__name__ == case['raises'], (rel, type(e.value).__name__, case['raises'])
+            seen['raises'] += 1
+            continue
+        with quiet():
+            ctrl = cls(dict(case['ag_params']), pdict, 0, 1)
+        vals = ctrl._hp.values()
+        vals.pop('predictor_class')
+        for k, v in case['values'].items():
+            if k == 'sampler':
+                assert 'class:' + vals[k].__name__ == v, rel
+            else:
+                assert vals[k] == v, (rel, k, vals[k], v)
+        assert set(vals.keys()) - product_only == set(case['values'].keys()), rel
+        assert ctrl._hp.start_planning == case['start_planning_after_ctor'], rel
+        seen['ok'] += 1
+    assert seen == {'ok': 6, 'raises': 10, 'unloadable': 2}
+
+
 def test_override_errors(golden_dir):
     want = _meta(golden_dir, 'hparams')['errors']
     fake = make_fake_predictor_class(5, 16, 16)

@@ -23,6 +23,7 @@ product class instead of pinning the product class against itself.
 import io
 import json
 import os
+import re
 import sys
 import types
 import contextlib
@@ -132,25 +133,92 @@ def golden_policy_args(ref):
 AG = {'adim': 4, 'sdim': 5, 'image_height': 16, 'image_width': 16}
 
 
+# the reference's OWN experiment files: import stubs and loader
+class _Anything(object):
+    """Stands in for every class / function an experiment file imports from the parts of the reference that are out of
+    scope (environments, agents, ROS topics): constructible with any arguments, any attribute is another one."""
+    def __init__(self, *a, **k):
+        pass
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return _Anything()
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+
+class _StubModule(types.ModuleType):
+    __path__ = []
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return type(name, (_Anything,), {})
+
+
+class _StubFinder(object):
+    """Catch-all import stub.  `front`: intercepts the reference's environment / agent / robot packages before their real
+    modules (which need MuJoCo, ROS, ...) are found; otherwise: the last resort for anything the image lacks."""
+    FRONT = ('visual_mpc.envs', 'visual_mpc.agent', 'visual_mpc.utils', 'visual_mpc.sim', 'visual_mpc.foresight_rospkg')
+
+    def __init__(self, front):
+        self.front = front
+
+    def find_spec(self, name, path=None, target=None):
+        import importlib.machinery
+        if self.front and not any(name == p or name.startswith(p + '.') for p in self.FRONT):
+            return None
+        return importlib.machinery.ModuleSpec(name, self)
+
+    def create_module(self, spec):
+        return _StubModule(spec.name)
+
+    def exec_module(self, module):
+        pass
+
+
+
+@contextlib.contextmanager
+def experiment_import_stubs():
+    """While active, the environment / agent / robot imports of the reference's experiment files resolve to catch-all stubs."""
+    front, back = _StubFinder(True), _StubFinder(False)
+    for k in ('VMPC_DATA_DIR', 'VMPC_EXP_DIR'):     # (experiment files build paths from them)
+        os.environ.setdefault(k, '/nonexistent/' + k.lower())
+    sys.meta_path.insert(0, front)
+    sys.meta_path.append(back)
+    try:
+        yield
+    finally:
+        sys.meta_path.remove(front)
+        sys.meta_path.remove(back)
+
+
+def load_experiment_file(rel):
+    import importlib.machinery
+    import importlib.util
+    path = os.path.join(REFERENCE, rel)
+    name = 'vf_exp_' + re.sub(r'\W', '_', rel)
+    loader = importlib.machinery.SourceFileLoader(name, path)
+    mod = importlib.util.module_from_spec(importlib.util.spec_from_loader(name, loader))
+    with quiet():
+        loader.exec_module(mod)
+    return mod
+
+
+
 def policy_dicts():
-    """The `policy` dicts of three experiment files, minus 'type' (values copied as data)."""
-    return {
-        # experiments/sim/cartgripper_2d_grasping/pixel_cost/hparams.py:31-39
-        'sim_cartgripper': {'action_order': ['x', 'z', 'grasp'], 'initial_std_lift': 0.5,
-                            'rejection_sampling': False, 'replan_interval': 10, 'num_samples': 800},
-        # experiments/robonet/pixel_cost/hparams.py:31-42
-        'robonet_pixel_cost': {'replan_interval': 13, 'num_samples': 600, 'selection_frac': 0.05,
-                               'predictor_propagation': True, 'initial_std_lift': 0.2,
-                               'initial_std_rot': np.pi / 10, 'rejection_sampling': False,
-                               'nactions': 13, 'repeat': 1},
-        # experiments/robonet/robotiq/zero_shot.py:24-38
-        'robotiq_zero_shot': {'replan_interval': 13, 'zeros_for_start_frames': False,
-                              'num_samples': 600, 'selection_frac': 0.05,
-                              'predictor_propagation': True, 'initial_std_lift': 0.2,
-                              'initial_std_rot': np.pi / 10, 'rejection_sampling': False,
-                              'nactions': 13, 'repeat': 1,
-                              'model_path': '~/models/sawyer_only/checkpoint_210000'},
-    }
+    """The `policy` dicts of three experiment files, minus 'type' - read from the reference's own files (no hand-typed copy)."""
+    files = {'sim_cartgripper': 'experiments/sim/cartgripper_2d_grasping/pixel_cost/hparams.py',
+             'robonet_pixel_cost': 'experiments/robonet/pixel_cost/hparams.py',
+             'robotiq_zero_shot': 'experiments/robonet/robotiq/zero_shot.py'}
+    out = {}
+    with experiment_import_stubs():
+        for name, rel in files.items():
+            mod = load_experiment_file(rel)
+            out[name] = {k: v for k, v in mod.config['policy'].items() if k != 'type'}
+    return out
 
 
 def golden_hparams(ref):
@@ -175,6 +243,63 @@ def golden_hparams(ref):
         except Exception as e:      # noqa
             errs[label] = type(e).__name__
     out['errors'] = errs
+    return out
+
+
+# ----------------------------------------------------------------------------- a2, every experiment file
+def golden_experiment_files():
+    """Load EVERY ``experiments/**`` file of the reference whose ``policy['type']`` is ``PixelCostController`` or
+    ``Register_Gtruth_Controller`` from the reference itself (``SourceFileLoader``; the environment / agent / robot imports of
+    those files resolve to catch-all stubs), run the reference's constructor on each ``policy`` dict with the fake predictor,
+    and record per file either ``_hp.values()`` or the exception the REFERENCE raises (several of its own files do not load:
+    keys that are no hyper-parameters, a list-valued ``num_samples``).  The product classes must reproduce all of it
+    (tests/test_host_golden.py) - no hand-typed dict can skip a key.  Reference: policy.py:51-63, cem_base_controller.py:66-76."""
+    import glob
+    install_registration_stubs()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        from visual_mpc.policy.cem_controllers.register_gtruth_controller import Register_Gtruth_Controller
+    from visual_mpc.policy.cem_controllers import PixelCostController
+    out = {'files': {}, 'skipped': {}}
+    with experiment_import_stubs():
+        for path in sorted(glob.glob(os.path.join(REFERENCE, 'experiments', '**', '*.py'), recursive=True)):
+            rel = os.path.relpath(path, REFERENCE)
+            with open(path) as f:
+                ours = re.search(r"'type'\s*:\s*(PixelCostController|Register_Gtruth_Controller)\b", f.read()) is not None
+            try:
+                mod = load_experiment_file(rel)
+            except Exception as e:      # noqa  (files of other sub-systems are not ours to load; one of OURS that does not
+                if ours:                # even import in the reference - a syntax error, a sampler module that is gone - is pinned as such)
+                    out['files'][rel] = {'unloadable': type(e).__name__}
+                else:
+                    out['skipped'][rel] = type(e).__name__
+                continue
+            cfg = getattr(mod, 'config', None)
+            policy = cfg.get('policy') if isinstance(cfg, dict) else getattr(mod, 'policy', None)
+            agent = cfg.get('agent') if isinstance(cfg, dict) else getattr(mod, 'agent', None)
+            if not isinstance(policy, dict) or policy.get('type') not in (PixelCostController, Register_Gtruth_Controller):
+                continue
+            cls = policy['type']
+            agent = agent if isinstance(agent, dict) else {}
+            ag = {'adim': 4, 'sdim': 5, 'image_height': int(agent.get('image_height', 48)),
+                  'image_width': int(agent.get('image_width', 64))}
+            for k in ('register_gtruth', 'current_dir'):
+                if k in agent:
+                    ag[k] = agent[k]
+            pdict = {k: v for k, v in policy.items() if k != 'type'}
+            entry = {'controller': cls.__name__, 'ag_params': {k: v for k, v in ag.items() if k != 'current_dir'},
+                     'policy': jsonable(pdict)}
+            try:
+                with quiet():
+                    ctrl = cls(dict(ag), dict(policy), 0, 1)
+                vals = ctrl._hp.values()
+                vals.pop('predictor_class')
+                entry['values'] = jsonable(vals)
+                entry['start_planning_after_ctor'] = ctrl._hp.start_planning
+            except Exception as e:      # noqa
+                entry['raises'] = type(e).__name__
+            out['files'][rel] = entry
     return out
 
 
@@ -599,6 +724,7 @@ def main():
     dump('pred_util', *golden_pred_util(ref))
     dump('traj_layout', *golden_traj_layout())
     dump('registration', *golden_registration())
+    dump('experiment_files', None, golden_experiment_files())
     print('wrote fixtures to', OUT, 'with numpy', np.__version__)
     for fn in sorted(os.listdir(OUT)):
         print('  %-20s %8d B' % (fn, os.path.getsize(os.path.join(OUT, fn))))
