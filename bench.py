@@ -83,7 +83,7 @@ def parse():
     ap.add_argument('--precision', choices=('fp32', 'bf16x6'), default=os.environ.get('VF_PRECISION', 'fp32'),
                     help='primary precision mode (the other one is reported as alt_precision)')
     ap.add_argument('--network', choices=('savp', 'savp2', 'savp3'), default='savp',
-                    help='generator of the c5 workload: savp (vf_config.arch 1), savp2 (arch 2: the conditioning vector in '
+                    help='generator of the c5 workload (savp3: of any workload): savp (vf_config.arch 1), savp2 (arch 2: the conditioning vector in '
                          'every conv-LSTM, published seven-layer compositing; exact fp32 only) or savp3 (arch 3: the published '
                          'SAVP generator - instance norm, conv + pool / up-sampling + conv, dependent masks; exact fp32 only)')
     ap.add_argument('--layer-spec', type=int, default=0, choices=(0, 32, 64, 128),
@@ -366,9 +366,11 @@ class Bench(object):
                   'predictor_class': HipVPredEvaluation}
         if self.args.workload == 'c3':
             policy.update(registration_warper=smooth_flow_warper, register_region=True)
-        if self.draws:
+        if self.draws or self.args.network == 'savp3':
+            # (savp3 on a deterministic workload - the shape the reference's RoboNet-era configs run their SAVP-architecture
+            # models at: 64 x 64, a few hundred candidates - is the stochastic predictor with ONE latent draw per action)
             from visual_foresight_amd.video_prediction.stochastic_predictor import StochasticHipPredictor
-            opts = dict(n_latent=self.draws, arch=self.args.network)
+            opts = dict(n_latent=max(self.draws, 1), arch=self.args.network)
             if self.args.network == 'savp3' and self.args.layer_spec:
                 opts['layer_spec'] = self.args.layer_spec
             policy['predictor_class'] = StochasticHipPredictor.with_options(**opts)
@@ -645,7 +647,7 @@ class Bench(object):
         }
         self.attach_traffic(result['roofline'], primary)
 
-        if not a.no_alt and not (self.draws and a.network in ('savp2', 'savp3')):   # (arch 2 / 3 are built for exact fp32 only)
+        if not a.no_alt and not ((self.draws and a.network == 'savp2') or a.network == 'savp3'):   # (arch 2 / 3 are built for exact fp32 only)
             other = 'bf16x6' if primary == 'fp32' else 'fp32'
             am = self.measure(other)
             result['alt_precision'] = {

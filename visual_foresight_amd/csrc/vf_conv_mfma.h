@@ -524,7 +524,9 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
         constexpr bool kStats = EPI == EPI_RAW_STATS || EPI == EPI_CONVT_RAW_STATS;
         const bool ni1 = p.NI == 1;
         const int n_here = ni1 ? (bimg0 < p.B ? 1 : 0) : min(p.NI, p.B - bimg0);
-        const long long out_elems = (long long)(kT ? 4 : 1) * p.Hout * p.Wout * p.Cout;
+        // (EPI_RAW with G > 1, arch 3's two heads as one item: gate g = output channels [g Cout, (g + 1) Cout) of every pixel)
+        constexpr int kGS = (EPI == EPI_RAW) ? G : 1;
+        const long long out_elems = (long long)(kT ? 4 : kGS) * p.Hout * p.Wout * p.Cout;
         const unsigned out_bytes = (unsigned)out_elems * 4u;
         const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
             p.out + (long long)bimg0 * out_elems, 0, n_here > 0 ? (int)((unsigned)n_here * out_bytes) : 0, 0x00020000);
@@ -562,7 +564,7 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
             const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
             const bool ok = img < n_here && rem < px_per_img && y < p.Hout && x < p.Wout && cg * 32 + 4 * cq < p.Cout;
             const unsigned in_img = kT ? (unsigned)(((2 * y) * (2 * p.Wout) + 2 * x) * p.Cout + cg * 32 + 4 * cq) * 4u
-                                       : (unsigned)((y * p.Wout + x) * p.Cout + cg * 32 + 4 * cq) * 4u;
+                                       : (unsigned)((y * p.Wout + x) * (kGS * p.Cout) + cg * 32 + 4 * cq) * 4u;
             off_o[k] = ok ? (unsigned)img * out_bytes + in_img : 0xFFFFFFFFu;
         }
         __syncthreads();                    // every wave is done reading the operand tile: its LDS becomes the slabs
@@ -574,7 +576,8 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const unsigned par = kT ? (unsigned)(((g >> 1) * (2 * p.Wout) + (g & 1)) * p.Cout) * 4u : 0u;
+            const unsigned par = kT ? (unsigned)(((g >> 1) * (2 * p.Wout) + (g & 1)) * p.Cout) * 4u
+                                    : (kGS > 1 ? (unsigned)(g * p.Cout) * 4u : 0u);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const f32x4 q = *reinterpret_cast<const f32x4 *>(T + (pl + 8 * k) * 36 + 4 * cq);

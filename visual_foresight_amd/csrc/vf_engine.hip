@@ -710,6 +710,7 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_lstm_split_kernel<1>, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_RAW, 1>, n))) return rc;
     if ((rc = allow_lds(&conv_gates_raw_kernel, n))) return rc;
+    if ((rc = allow_lds(&conv_mfma_kernel<2, EPI_RAW, 1>, n))) return rc;
     const size_t np = n + kCtlWords * sizeof(int);
     if ((rc = allow_lds(&rollout_persistent_kernel<1>, np))) return rc;
     if ((rc = allow_lds(&rollout_persistent_kernel<2>, np))) return rc;
@@ -1407,6 +1408,7 @@ struct LaunchSink {
             case PH_CONVT_RELU: return launch_conv_t<4, EPI_CONVT_RELU>(l, p, st);
             case PH_CONVT_RAW: return launch_conv_t<4, EPI_CONVT_RAW_STATS>(l, p, st);
             case PH_CONV_RAW3: return launch_conv_t<1, EPI_RAW>(l, p, st);
+            case PH_CONV_RAW3G2: return launch_conv_m<2, EPI_RAW, 1>(l, p, st);
             case PH_GATES_RAW: {
                 const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
                 hipLaunchKernelGGL(conv_gates_raw_kernel, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
@@ -1562,7 +1564,7 @@ struct ScheduleSink {
         const double rows = (double)p.B * l.Hout * l.Wout;
         const double taps = l.mode == PACK_CONVT ? 9.0 / 4.0 * 4.0 : (double)l.KH * l.KW;   // real taps
         flops += 2.0 * rows * taps * (l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0)) *
-                 (l.mode == PACK_LSTM ? 4.0 : 1.0) * l.Cout;
+                 (l.mode == PACK_LSTM ? 4.0 : (l.mode == PACK_PLAIN ? (double)l.G : 1.0)) * l.Cout;
         return add(P, P.gx * P.gy * l.nsplit, P.whole ? 1 : p.B, deps);
     }
     int sa(const SaParams &p, std::initializer_list<int> deps) {
@@ -2123,7 +2125,9 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
                 const NormParams &q = e.norm;
                 const size_t hw = (size_t)q.H * q.W, ctot = (size_t)(e.op == EW_INCELL ? 4 : 1) * q.C;
                 ok = ok && in_allocs(h, q.in, ((size_t)(P.B - 1) * q.in_bs + hw * ctot) * 4);
-                ok = ok && in_allocs(h, q.out, ((size_t)(P.B - 1) * q.out_bs + hw * q.C) * 4);
+                const size_t co = q.split > 0 ? (size_t)q.split : (size_t)q.C;
+                ok = ok && in_allocs(h, q.out, ((size_t)(P.B - 1) * q.out_bs + hw * co) * 4);
+                ok = ok && (q.split == 0 || (in_allocs(h, q.out2, ((size_t)(P.B - 1) * q.out_bs + hw * co) * 4) && q.C == 2 * q.split));
                 ok = ok && in_allocs(h, q.cond, q.cond ? ((size_t)(P.B - 1) * q.cond_bs + 25 * ctot) * 4 : 0);
                 ok = ok && in_allocs(h, q.g0, ctot * 4) && in_allocs(h, q.b0, ctot * 4) && q.C % q.cpi == 0 && e.gx == q.C / q.cpi;
                 if (e.op == EW_INCELL)
@@ -2364,7 +2368,8 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
             // ... and so do the light layers (conv_epilogue's vectorised form: every conv / transposed-conv tile)
             if (P.type >= PH_CONV_RELU && P.type <= PH_CONVT_RAW && h->wt_publish && (VF_WT_DEFAULT & 2)) P.conv.wt_out = 1;
             // arch 3: the raw epilogues store 16 bytes per lane (EPI_RAW needs whole channel quads; gates_raw_epilogue always)
-            if (P.type == PH_CONV_RAW3 && h->wt_publish && (VF_WT_DEFAULT & 2) && P.conv.Cout % 4 == 0) P.conv.wt_out = 1;
+            if ((P.type == PH_CONV_RAW3 || P.type == PH_CONV_RAW3G2) && h->wt_publish && (VF_WT_DEFAULT & 2) && P.conv.Cout % 4 == 0)
+                P.conv.wt_out = 1;
             if (P.type == PH_GATES_RAW && h->wt_publish) P.conv.wt_out = 1;
             if (P.type == PH_CONV_PAIR) P.conv.fuse_next = &sc_host.d_phases[i].conv2;
             if (P.type != PH_TOP_FUSED) continue;

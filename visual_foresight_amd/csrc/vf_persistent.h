@@ -36,9 +36,13 @@ enum PhaseType {
     // arch 3 (the published SAVP generator, vf_savp3.h): GEMM tiles that store raw outputs, element-wise items
     PH_CONV_RAW3,           // conv, acc + bias (EPI_RAW)
     PH_GATES_RAW,           // conv-LSTM gate GEMM on the gate-split 128-row tile, raw gate pre-activations (gates_raw_epilogue)
-    PH_EW                   // state FC / class biases / instance norm / cell / up-sampling / compositing layers (EwParams::op)
+    PH_EW,                  // state FC / class biases / instance norm / cell / up-sampling / compositing layers (EwParams::op)
+    PH_CONV_RAW3G2          // two 32-channel convs of the same input as the two "gates" of one item (the hidden layers of the
+                            // mask and scratch heads): conv_tile<2, EPI_RAW>, output [pixel][2 x 32]
 };
-__host__ __device__ constexpr bool ph_is_conv(const int t) { return t <= PH_CONVT_RAW || t == PH_CONV_RAW3 || t == PH_GATES_RAW; }
+__host__ __device__ constexpr bool ph_is_conv(const int t) {
+    return t <= PH_CONVT_RAW || t == PH_CONV_RAW3 || t == PH_GATES_RAW || t == PH_CONV_RAW3G2;
+}
 
 constexpr int kMaxDeps = 3;
 constexpr int kQueues = 8;                  // one ticket queue per XCD
@@ -434,6 +438,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                     else composite_tile_call<ND, false, 10>(&P.comp, local % P.gx, b0, P.view);
                     break;
                 case PH_CONV_RAW3: conv_tile_call<1, EPI_RAW, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONV_RAW3G2: conv_tile_call<2, EPI_RAW, 1>(&P.conv, bx, by, 0); break;
                 case PH_GATES_RAW: gates_raw_tile_call(&P.conv, bx, by); break;
                 case PH_EW: {
                     const int idx = P.ew.spi > 0 ? 0 : local - b0 * P.gx;

@@ -64,6 +64,8 @@ struct NormParams {
     const float *g1, *b1;                   // INCELL: of the cell-state norm [C]
     const float *cprev; long long cprev_bs; // INCELL: previous cell state [HW][C], null = zero
     float *out; long long out_bs;           // INORM: normalised (may alias in); INCELL: h
+    float *out2; int split;                 // INORM, split > 0: channels >= split go to out2 (both outputs `split` channels
+                                            // per pixel: the two heads' hidden layers leave one fused conv)
     float *cout; long long cout_bs;         // INCELL: new cell state (may alias cprev)
     int H, W, C, cpi, relu;
     float eps;
@@ -106,6 +108,7 @@ struct EwParams {
     };
 };
 
+constexpr int kEwBatch = 4;         // pixels whose loads an element-wise item keeps in flight per thread
 constexpr int kEwLdsFloats = 20 * 20 * 8 + 25 * 4 + 16 + 2 * 4 * 8 * 32;   // largest: EW_TRANSFORM halo; reductions [4][8][32] doubles
 
 // border class of coordinate y in an image of H rows: 0, 1 | 2 = interior | 3, 4   (H >= 4)
@@ -254,7 +257,9 @@ __device__ __forceinline__ void inorm_item(const PT &p, const int b, const int g
     const int HW = p.H * p.W, C = p.C, c0 = grp * p.cpi + 4 * q;
     const float *in = p.in + (long long)b * p.in_bs + c0;
     const float *cond = p.cond ? p.cond + (long long)b * p.cond_bs + c0 : nullptr;
-    float *out = p.out + (long long)b * p.out_bs + c0;
+    const int Co = p.split > 0 ? p.split : C;       // channels per pixel of the output tensor(s)
+    float *out = (p.split > 0 && c0 >= p.split) ? p.out2 + (long long)b * p.out_bs + (c0 - p.split)
+                                                : p.out + (long long)b * p.out_bs + c0;
     const TileDiv div_w(p.W);
     auto value = [&](const int px) {
         f32x4 v = ld4(in + (long long)px * C);
@@ -269,24 +274,38 @@ __device__ __forceinline__ void inorm_item(const PT &p, const int b, const int g
     double st[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) st[i] = 0.0;
-    for (int px = ps; px < HW; px += ppp) {
-        const f32x4 v = value(px);
+    // (the items are latency chains: kEwBatch pixels' loads are issued back to back before anything is computed on them)
+    for (int px0 = ps; px0 < HW; px0 += kEwBatch * ppp) {
+        f32x4 v[kEwBatch];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const double d = (double)v[j]; st[j] += d; st[4 + j] += d * d; }
+        for (int u = 0; u < kEwBatch; ++u) { const int px = px0 + u * ppp; v[u] = px < HW ? value(px) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int u = 0; u < kEwBatch; ++u) {
+            if (px0 + u * ppp >= HW) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const double d = (double)v[u][j]; st[j] += d; st[4 + j] += d * d; }
+        }
     }
     ew_reduce<8>(st, nq, reinterpret_cast<double *>(smem));
     float sc[4], sh[4];
     const double inv_n = 1.0 / (double)HW;
 #pragma unroll
     for (int j = 0; j < 4; ++j) in_scale_shift(st[j], st[4 + j], inv_n, p.eps, p.g0[c0 + j], p.b0[c0 + j], sc[j], sh[j]);
-    for (int px = ps; px < HW; px += ppp) {
-        f32x4 v = value(px);
+    for (int px0 = ps; px0 < HW; px0 += kEwBatch * ppp) {
+        f32x4 v[kEwBatch];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = fmaf(v[j], sc[j], sh[j]);
-            if (p.relu) v[j] = fmaxf(v[j], 0.f);
+        for (int u = 0; u < kEwBatch; ++u) { const int px = px0 + u * ppp; v[u] = px < HW ? value(px) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int u = 0; u < kEwBatch; ++u) {
+            const int px = px0 + u * ppp;
+            if (px >= HW) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[u][j] = fmaf(v[u][j], sc[j], sh[j]);
+                if (p.relu) v[u][j] = fmaxf(v[u][j], 0.f);
+            }
+            st4(out + (long long)px * Co, v[u]);
         }
-        st4(out + (long long)px * C, v);
     }
 }
 
@@ -325,13 +344,19 @@ __device__ __forceinline__ void incell_item(const PT &p, const int b, const int 
     double st[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) st[i] = 0.0;
-    for (int px = ps; px < HW; px += ppp) {
-        f32x4 g[4];
-        gates(px, g);
+    for (int px0 = ps; px0 < HW; px0 += 2 * ppp) {      // (two pixels = eight + eight 16-byte loads in flight)
+        f32x4 g[2][4];
+        const bool two = px0 + ppp < HW;
+        gates(px0, g[0]);
+        gates(two ? px0 + ppp : px0, g[1]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const double d = (double)g[k][j]; st[k * 4 + j] += d; st[16 + k * 4 + j] += d * d; }
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const double d = (double)g[u][k][j]; st[k * 4 + j] += d; st[16 + k * 4 + j] += d * d; }
+        }
     }
     ew_reduce<32>(st, nq, red);
     const double inv_n = 1.0 / (double)HW;
@@ -346,40 +371,60 @@ __device__ __forceinline__ void incell_item(const PT &p, const int b, const int 
     double ct[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) ct[i] = 0.0;
-    for (int px = ps; px < HW; px += ppp) {
-        f32x4 g[4];
-        gates(px, g);
-        f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-        if (cprev) cp = ld4(cprev + (long long)px * C);
-        f32x4 cn, so;
+    for (int px0 = ps; px0 < HW; px0 += 2 * ppp) {
+        f32x4 g[2][4], cp[2];
+        const bool two = px0 + ppp < HW;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float gi = fmaf(g[0][j], sc[0][j], sh[0][j]), gj = fmaf(g[1][j], sc[1][j], sh[1][j]);
-            const float gf = fmaf(g[2][j], sc[2][j], sh[2][j]), go = fmaf(g[3][j], sc[3][j], sh[3][j]);
-            cn[j] = fmaf(cp[j], sigmoidf_(gf + 1.0f), sigmoidf_(gi) * tanhf_(gj));
-            so[j] = sigmoidf_(go);
-            const double d = (double)cn[j];
-            ct[j] += d; ct[4 + j] += d * d;
+        for (int u = 0; u < 2; ++u) {
+            const int px = (u == 1 && two) ? px0 + ppp : px0;
+            gates(px, g[u]);
+            cp[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (cprev) cp[u] = ld4(cprev + (long long)px * C);
         }
-        st4(cout + (long long)px * C, cn);
-        st4(hout + (long long)px * C, so);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const int px = px0 + u * ppp;
+            f32x4 cn, so;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gi = fmaf(g[u][0][j], sc[0][j], sh[0][j]), gj = fmaf(g[u][1][j], sc[1][j], sh[1][j]);
+                const float gf = fmaf(g[u][2][j], sc[2][j], sh[2][j]), go = fmaf(g[u][3][j], sc[3][j], sh[3][j]);
+                cn[j] = fmaf(cp[u][j], sigmoidf_(gf + 1.0f), sigmoidf_(gi) * tanhf_(gj));
+                so[j] = sigmoidf_(go);
+                const double d = (double)cn[j];
+                ct[j] += d; ct[4 + j] += d * d;
+            }
+            st4(cout + (long long)px * C, cn);
+            st4(hout + (long long)px * C, so);
+        }
     }
     ew_reduce<8>(ct, nq, red);
     float csc[4], csh[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) in_scale_shift(ct[j], ct[4 + j], inv_n, p.eps, p.g1[c0 + j], p.b1[c0 + j], csc[j], csh[j]);
     // ---- pass 3: normalised cell state, hidden state
-    for (int px = ps; px < HW; px += ppp) {
-        f32x4 cn = ld4(cout + (long long)px * C);
-        const f32x4 so = ld4(hout + (long long)px * C);
-        f32x4 hn;
+    for (int px0 = ps; px0 < HW; px0 += kEwBatch * ppp) {
+        f32x4 cn[kEwBatch], so[kEwBatch];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            cn[j] = fmaf(cn[j], csc[j], csh[j]);
-            hn[j] = tanhf_(cn[j]) * so[j];
+        for (int u = 0; u < kEwBatch; ++u) {
+            const int px = px0 + u * ppp < HW ? px0 + u * ppp : px0;
+            cn[u] = ld4(cout + (long long)px * C);
+            so[u] = ld4(hout + (long long)px * C);
         }
-        st4(cout + (long long)px * C, cn);
-        st4(hout + (long long)px * C, hn);
+#pragma unroll
+        for (int u = 0; u < kEwBatch; ++u) {
+            const int px = px0 + u * ppp;
+            if (px >= HW) break;
+            f32x4 hn;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cn[u][j] = fmaf(cn[u][j], csc[j], csh[j]);
+                hn[j] = tanhf_(cn[u][j]) * so[u][j];
+            }
+            st4(cout + (long long)px * C, cn[u]);
+            st4(hout + (long long)px * C, hn);
+        }
     }
 }
 
@@ -393,27 +438,45 @@ __device__ __forceinline__ void upsample_item(const PT &p, const int b, const in
     const int total = n_rows * OW * Cq;
     const TileDiv div_cq(Cq), div_ow(OW);
     float *out = p.out + (long long)b * p.out_bs;
-    for (int e = threadIdx.x; e < total; e += kConvThreads) {
-        const int pq = div_cq.div(e), cq = e - pq * Cq;
-        const int yl = div_ow.div(pq), X = pq - yl * OW, Y = y_begin + yl;
-        const int i = Y >> 1, a = Y & 1, j = X >> 1, bb = X & 1;
-        const int r0 = i - 1 + a, r1 = i + a, q0 = j - 1 + bb, q1 = j + bb;
-        const float wy0 = a ? 0.75f : 0.25f, wy1 = a ? 0.25f : 0.75f, wx0 = bb ? 0.75f : 0.25f, wx1 = bb ? 0.25f : 0.75f;
-        const int c = 4 * cq;
-        const float *src; int Cs;
-        if (c < p.C0) { src = p.in0 + (long long)b * p.in0_bs + c; Cs = p.C0; }
-        else { src = p.in1 + (long long)b * p.in1_bs + (c - p.C0); Cs = p.C1; }
-        auto tap = [&](const int r, const int qq) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)r < (unsigned)p.h && (unsigned)qq < (unsigned)p.w) v = ld4(src + (long long)(r * p.w + qq) * Cs);
-            return v;
-        };
-        const f32x4 v00 = tap(r0, q0), v01 = tap(r0, q1), v10 = tap(r1, q0), v11 = tap(r1, q1);
-        f32x4 o;
+    // two output elements per thread and pass: their eight source loads are issued back to back (clamped addresses, zeros
+    // by select: no branch between the loads)
+    for (int e0 = threadIdx.x; e0 < total; e0 += 2 * kConvThreads) {
+        f32x4 v[2][4];
+        float wgt[2][4];
+        long long dst[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            o[k] = fmaf(wy1 * wx1, v11[k], fmaf(wy1 * wx0, v10[k], fmaf(wy0 * wx1, v01[k], (wy0 * wx0) * v00[k])));
-        st4(out + ((long long)Y * OW + X) * C + c, o);
+        for (int u = 0; u < 2; ++u) {
+            const int e = min(e0 + u * kConvThreads, total - 1);
+            const int pq = div_cq.div(e), cq = e - pq * Cq;
+            const int yl = div_ow.div(pq), X = pq - yl * OW, Y = y_begin + yl;
+            const int i = Y >> 1, a = Y & 1, j = X >> 1, bb = X & 1;
+            const int r0 = i - 1 + a, r1 = i + a, q0 = j - 1 + bb, q1 = j + bb;
+            const float wy0 = a ? 0.75f : 0.25f, wy1 = a ? 0.25f : 0.75f, wx0 = bb ? 0.75f : 0.25f, wx1 = bb ? 0.25f : 0.75f;
+            const int c = 4 * cq;
+            const float *src; int Cs;
+            if (c < p.C0) { src = p.in0 + (long long)b * p.in0_bs + c; Cs = p.C0; }
+            else { src = p.in1 + (long long)b * p.in1_bs + (c - p.C0); Cs = p.C1; }
+            const bool r0ok = r0 >= 0, r1ok = r1 < p.h, q0ok = q0 >= 0, q1ok = q1 < p.w;
+            const int r0c = max(r0, 0), r1c = min(r1, p.h - 1), q0c = max(q0, 0), q1c = min(q1, p.w - 1);
+            v[u][0] = ld4(src + (long long)(r0c * p.w + q0c) * Cs);
+            v[u][1] = ld4(src + (long long)(r0c * p.w + q1c) * Cs);
+            v[u][2] = ld4(src + (long long)(r1c * p.w + q0c) * Cs);
+            v[u][3] = ld4(src + (long long)(r1c * p.w + q1c) * Cs);
+            wgt[u][0] = (r0ok && q0ok) ? wy0 * wx0 : 0.f;
+            wgt[u][1] = (r0ok && q1ok) ? wy0 * wx1 : 0.f;
+            wgt[u][2] = (r1ok && q0ok) ? wy1 * wx0 : 0.f;
+            wgt[u][3] = (r1ok && q1ok) ? wy1 * wx1 : 0.f;
+            dst[u] = ((long long)Y * OW + X) * C + c;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (e0 + u * kConvThreads >= total) break;
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[k] = fmaf(wgt[u][3], v[u][3][k], fmaf(wgt[u][2], v[u][2][k], fmaf(wgt[u][1], v[u][1][k], wgt[u][0] * v[u][0][k])));
+            st4(out + dst[u], o);
+        }
     }
 }
 
