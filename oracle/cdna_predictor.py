@@ -43,6 +43,8 @@ def expected_shapes(cfg):
     table (cdna_arch.py) cannot hide behind weights generated from that same table."""
     a, K = cfg.adim + cfg.sdim, cfg.num_masks
     h8, w8 = cfg.height // 8, cfg.width // 8
+    if getattr(cfg, 'decoder', 'survey') == 'public':
+        return _expected_shapes_public(a, K, h8, w8, cfg.sdim)
     t = {'enc0/w': (5, 5, 3, 32), 'lstm1/w': (5, 5, 64, 128), 'lstm2/w': (5, 5, 64, 128), 'enc1/w': (3, 3, 32, 32),
          'lstm3/w': (5, 5, 96, 256), 'lstm4/w': (5, 5, 128, 256), 'enc2/w': (3, 3, 64, 64), 'enc3/w': (1, 1, 64 + a, 64),
          'lstm5/w': (5, 5, 192, 512), 'convt1/w': (3, 3, 128, 128), 'lstm6/w': (5, 5, 192, 256),
@@ -51,6 +53,22 @@ def expected_shapes(cfg):
     for name in list(t):
         t[name[:-2] + '/b'] = (t[name][-1],)
     for i, c in enumerate((32, 32, 32, 64, 64, 128, 64, 32, 32)):
+        t['ln%d/g' % (i + 1)] = t['ln%d/b' % (i + 1)] = (c,)
+    return t
+
+
+def _expected_shapes_public(a, K, h8, w8, sdim):
+    """The decoder as the PUBLIC ``prediction_model.py`` of arXiv:1605.07157 builds it: every ``conv2d_transpose`` keeps the
+    channel count of its input - ``enc4 = convT(hidden5, 128)``, ``enc5 = convT(concat[hidden6, enc1] = 96, 96)``, ``enc6 =
+    convT(concat[hidden7, enc0] = 64, 64)`` - so ``lstm7`` convolves 96 + 32 channels and the two 1 x 1 heads read 64."""
+    t = {'enc0/w': (5, 5, 3, 32), 'lstm1/w': (5, 5, 64, 128), 'lstm2/w': (5, 5, 64, 128), 'enc1/w': (3, 3, 32, 32),
+         'lstm3/w': (5, 5, 96, 256), 'lstm4/w': (5, 5, 128, 256), 'enc2/w': (3, 3, 64, 64), 'enc3/w': (1, 1, 64 + a, 64),
+         'lstm5/w': (5, 5, 192, 512), 'convt1/w': (3, 3, 128, 128), 'lstm6/w': (5, 5, 192, 256),
+         'convt2/w': (3, 3, 96, 96), 'lstm7/w': (5, 5, 128, 128), 'convt3/w': (3, 3, 64, 64), 'rgb/w': (1, 1, 64, 3),
+         'masks/w': (1, 1, 64, K + 1), 'cdna/w': (h8 * w8 * 128, 25 * K), 'state/w': (a, sdim)}
+    for name in list(t):
+        t[name[:-2] + '/b'] = (t[name][-1],)
+    for i, c in enumerate((32, 32, 32, 64, 64, 128, 64, 32, 64)):
         t['ln%d/g' % (i + 1)] = t['ln%d/b' % (i + 1)] = (c,)
     return t
 

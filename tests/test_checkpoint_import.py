@@ -76,3 +76,25 @@ def test_missing_bias_of_a_normalised_conv_becomes_zeros_and_savp_is_refused():
         import_named_arrays(dump, cfg, log=said.append)
     with pytest.raises(ValueError, match='cdna'):
         import_named_arrays(arrays, SavpConfig(height=64, width=64))
+
+
+def test_public_decoder_checkpoint_roundtrip(tmp_path):
+    """The TensorFlow variable names are the same for both decoder tables; the shapes decide.  A dump of the public code's
+    widths (convt2 96 -> 96, convt3 64 -> 64) imports into ``CdnaConfig(decoder='public')`` and is refused by the default."""
+    cfg = CdnaConfig(height=32, width=32, decoder='public')
+    w = CdnaWeights.random(cfg, seed=5, bias_scale=0.1, ln_jitter=0.1)
+    named = ci.export_named_arrays(w, scope='model')
+    assert named['model/convt2/weights'].shape == (3, 3, 96, 96) and named['model/convt3/weights'].shape == (3, 3, 64, 64)
+    assert named['model/state7/Gates/weights'].shape == (5, 5, 128, 128) and named['model/convt4/weights'].shape == (1, 1, 3, 64)
+    npz = os.path.join(str(tmp_path), 'ckpt.npz')
+    np.savez(npz, **named)
+    back = ci.convert_npz(npz, os.path.join(str(tmp_path), 'model'), cfg)
+    loaded = CdnaWeights.load(os.path.join(str(tmp_path), 'model'), cfg)
+    assert loaded.cfg.decoder == 'public'
+    for k in w.tensors:
+        np.testing.assert_array_equal(back.tensors[k], w.tensors[k])
+        np.testing.assert_array_equal(loaded.tensors[k], w.tensors[k])
+    with pytest.raises(ValueError, match='shape'):
+        ci.import_named_arrays(named, CdnaConfig(height=32, width=32))
+    with pytest.raises(ValueError, match='decoder'):
+        CdnaWeights.load(os.path.join(str(tmp_path), 'model'), CdnaConfig(height=32, width=32))

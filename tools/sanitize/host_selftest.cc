@@ -79,6 +79,9 @@ int main() {
     rc |= run_case(128, 128, 12, 5, 1, 2, 15, 125, 0, 1, 5, b_c2 + 1, 2, 2);
     rc |= run_case(64, 80, 6, 3, 2, 2, 2, 37, 0, 2, 1, b_small, 4, 2);
     rc |= run_case(64, 64, 12, 5, 3, 1, 2, 16, 0, 1, 1, b_small, 3, 2);
+    // arch 0 on the decoder widths of the public CDNA code (layer_spec 1: convt2 96 -> 96, convt3 64 -> 64, unfused top)
+    rc |= run_case(64, 64, 4, 5, 2, 2, 3, 37, 0, 1, 1, b_small, 4, 0, 0, 1);
+    rc |= run_case(48, 64, 3, 3, 1, 2, 13, 200, 0, 2, 1, b_c2, 3, 0, 0, 1);
     // arch 3: the published SAVP generator - every layer table (32 / 64 / 128 pixels, the paper's table forced on 128 x 128),
     // a config-5 shard, two views, an odd shape
     rc |= run_case(32, 32, 12, 5, 1, 2, 3, 37, 0, 1, 1, b_small, 4, 3, 8);

@@ -516,8 +516,9 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
     // of four pixels: 4 memory instructions and 4 pixel geometries per gate instead of 16 - and, with ConvParams::wt_out, as
     // sc1 (write-through) stores, which is what lets the item publish without a release fence (16-byte sc1 stores cost what
     // plain ones do, 4-byte ones six times as much per byte: CDNA guide, section 6 G16).  Same values, same statistics.
-    constexpr bool kVec = MREP == 1 && (EPI == EPI_BIAS_RELU || EPI == EPI_RAW_STATS || EPI == EPI_CONVT_RELU ||
-                                         EPI == EPI_CONVT_RAW_STATS || EPI == EPI_RAW);
+    // (EPI_RAW also with two row blocks per wave - the 256-row plan of arch 3's full-resolution layers: the same per block)
+    constexpr bool kVec = (MREP == 1 && (EPI == EPI_BIAS_RELU || EPI == EPI_RAW_STATS || EPI == EPI_CONVT_RELU ||
+                                          EPI == EPI_CONVT_RAW_STATS)) || EPI == EPI_RAW;
     if constexpr (kVec) {
         constexpr bool kT = EPI == EPI_CONVT_RELU || EPI == EPI_CONVT_RAW_STATS;
         constexpr bool kRelu = EPI == EPI_BIAS_RELU || EPI == EPI_CONVT_RELU;
@@ -534,8 +535,10 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
         // ---- values (bias, per-sample bias, relu) and the exact statistics, lane = channel
         const bool ch_ok = ch < p.Cout;
 #pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int row = wave * WROWS + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             int img = 0, rem = row;
             if (!ni1) { img = div_rpi.div(row); rem = row - img * p.RPI; }
             const int yy = div_tw.div(rem);
@@ -545,19 +548,21 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
             if (p.sbias && ok) sb = p.sbias[(long long)(bimg0 + img) * p.sbias_ld + ch];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                float v = acc[0][g][r] + bias_g[g];
+                float v = acc[m][g][r] + bias_g[g];
                 if (p.sbias) v += sb;
                 if (kRelu) v = fmaxf(v, 0.f);
-                acc[0][g][r] = v;
+                acc[m][g][r] = v;
                 if constexpr (kStats) { if (ok) { ssum += stat_q(v); ssq += stat_q2(v); } }
             }
         }
         // ---- where this lane's four pixels (rows lane / 8 + 8 k of the wave's block) go: channels 4 (lane % 8) ..
         const int pl = lane >> 3, cq = lane & 7;
-        unsigned off_o[4];
+        unsigned off_o[MREP][4];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int row = wave * 32 + pl + 8 * k;
+            const int row = wave * WROWS + m * 32 + pl + 8 * k;
             int img = 0, rem = row;
             if (!ni1) { img = div_rpi.div(row); rem = row - img * p.RPI; }
             const int yy = div_tw.div(rem);
@@ -565,14 +570,16 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
             const bool ok = img < n_here && rem < px_per_img && y < p.Hout && x < p.Wout && cg * 32 + 4 * cq < p.Cout;
             const unsigned in_img = kT ? (unsigned)(((2 * y) * (2 * p.Wout) + 2 * x) * p.Cout + cg * 32 + 4 * cq) * 4u
                                        : (unsigned)((y * p.Wout + x) * (kGS * p.Cout) + cg * 32 + 4 * cq) * 4u;
-            off_o[k] = ok ? (unsigned)img * out_bytes + in_img : 0xFFFFFFFFu;
+            off_o[m][k] = ok ? (unsigned)img * out_bytes + in_img : 0xFFFFFFFFu;
         }
         __syncthreads();                    // every wave is done reading the operand tile: its LDS becomes the slabs
         float *T = smem + wave * (32 * 36);
 #pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * kh) * 36 + n] = acc[0][g][r];
+            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * kh) * 36 + n] = acc[m][g][r];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -581,7 +588,7 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const f32x4 q = *reinterpret_cast<const f32x4 *>(T + (pl + 8 * k) * 36 + 4 * cq);
-                const unsigned off = off_o[k] == 0xFFFFFFFFu ? off_o[k] : off_o[k] + par;
+                const unsigned off = off_o[m][k] == 0xFFFFFFFFu ? off_o[m][k] : off_o[m][k] + par;
                 if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, q), r_out, off, 0, 16);
                 else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, q), r_out, off, 0, 0);
             }

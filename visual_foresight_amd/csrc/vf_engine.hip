@@ -158,6 +158,11 @@ static std::vector<TensorDesc> tensor_table(const vf_config &c) {
     const int cc = c.arch == 2 ? a_of(c) : 0;
     const int Hc = savp ? c.height / 2 : c.height, Wc = savp ? c.width / 2 : c.width;
     const int fc_in = (Hc / 8) * (Wc / 8) * L[4];
+    // arch 0 with layer_spec = 1: the decoder widths of the PUBLIC CDNA prediction_model (arXiv:1605.07157's code keeps the
+    // concatenated width through its transposed convs: convt2 96 -> 96, convt3 64 -> 64, so lstm7 reads 96 + 32 channels and
+    // the heads 64); layer_spec = 0: the widths of SURVEY row a14 (convt2 96 -> 64, convt3 64 -> 32)
+    const bool pub = c.arch == 0 && c.layer_spec == 1;
+    const int c_t2 = pub ? L[5] + L[1] : L[5], c_top = pub ? L[6] + 32 : 32;
     if (savp) { conv("enc00", 5, 5, 3, kEnc00Ch); ln("lna", kEnc00Ch); }
     conv("enc0", 5, 5, savp ? kEnc00Ch : 3, 32); ln("ln1", 32);
     conv("lstm1", 5, 5, 32 + cc + L[0], 4 * L[0]);  ln("ln2", L[0]);
@@ -170,12 +175,12 @@ static std::vector<TensorDesc> tensor_table(const vf_config &c) {
     conv("lstm5", 5, 5, L[3] + cc + L[4], 4 * L[4]); ln("ln6", L[4]);
     conv("convt1", 3, 3, L[4], L[4]);
     conv("lstm6", 5, 5, L[4] + cc + L[5], 4 * L[5]); ln("ln7", L[5]);
-    conv("convt2", 3, 3, L[5] + L[1], L[5]);
-    conv("lstm7", 5, 5, L[5] + cc + L[6], 4 * L[6]); ln("ln8", L[6]);
-    conv("convt3", 3, 3, L[6] + 32, 32);        ln("ln9", 32);
+    conv("convt2", 3, 3, L[5] + L[1], c_t2);
+    conv("lstm7", 5, 5, c_t2 + cc + L[6], 4 * L[6]); ln("ln8", L[6]);
+    conv("convt3", 3, 3, L[6] + 32, c_top);     ln("ln9", c_top);
     if (savp) { conv("convt4", 3, 3, 32 + kEnc00Ch, 32); ln("lnb", 32); }
-    conv("rgb", 1, 1, 32, 3);
-    conv("masks", 1, 1, 32, K + 1);
+    conv("rgb", 1, 1, c_top, 3);
+    conv("masks", 1, 1, c_top, K + 1);
     // arch 2: the FOUR CDNA kernels of the published generator (the engine pads them to its num_masks = 6 slots at load)
     const int KF = c.arch == 2 ? K - 2 : K;
     add("cdna/w", {fc_in, kTaps * KF});
@@ -473,6 +478,7 @@ struct vf_handle {
     bool cond = false;                  // vf_config.arch == 2: [action, latent, state] conditions every conv-LSTM
     float *cond_bias[7] = {nullptr};    // ... through per-sample border-class biases [2 step parities][ncam][max_batch][25][4C]
     int Hc, Wc;                         // input size of the three-scale conv-LSTM core (H, W; arch 1: H/2, W/2)
+    int c_t2 = 64, c_top = 32;          // output channels of convt2 / convt3 (arch 0, layer_spec 1 - the public table: 96 / 64)
     int ncam = 1, n_draws = 1;
     int ntiles;                         // composite tiles per image
     int nblocks;                        // cost-sum blocks per image (4 x 16 pixels, vf_small_kernels.h)
@@ -633,8 +639,11 @@ static int validate(const vf_config *c) {
         if (c->n_draws > 1 && c->max_batch % c->n_draws) return fail(VF_ERR_INVALID, "max_batch must be a multiple of n_draws");
         return s3_validate(c);
     }
-    if (c->zdim != 0 || c->layer_spec != 0)
-        return fail(VF_ERR_INVALID, "zdim / layer_spec belong to arch 3 (must be 0 otherwise)");
+    if (c->zdim != 0) return fail(VF_ERR_INVALID, "zdim belongs to arch 3 (must be 0 otherwise)");
+    if (c->layer_spec != 0 && !(c->arch == 0 && c->layer_spec == 1))
+        return fail(VF_ERR_INVALID, "layer_spec: arch 3's layer table, or 1 with arch 0 (the public CDNA decoder widths); 0 otherwise");
+    if (c->arch == 0 && c->layer_spec == 1 && c->precision != 0)
+        return fail(VF_ERR_INVALID, "the public decoder table (arch 0, layer_spec 1) is built for precision 0 (exact fp32) only");
     if (c->arch == 2 ? c->num_masks != 6 : c->num_masks != 10)
         return fail(VF_ERR_INVALID, "num_masks must be 10 (arch 0 / 1), 6 (arch 2: four CDNA warps + previous + first + scratch) or 4 (arch 3)");
     if (c->max_batch < 1) return fail(VF_ERR_INVALID, "max_batch must be >= 1");
@@ -711,6 +720,8 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_RAW, 1>, n))) return rc;
     if ((rc = allow_lds(&conv_gates_raw_kernel, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<2, EPI_RAW, 1>, n))) return rc;
+    if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_RAW, 2>, n))) return rc;
+    if ((rc = allow_lds(&conv_mfma_kernel<2, EPI_RAW, 2>, n))) return rc;
     const size_t np = n + kCtlWords * sizeof(int);
     if ((rc = allow_lds(&rollout_persistent_kernel<1>, np))) return rc;
     if ((rc = allow_lds(&rollout_persistent_kernel<2>, np))) return rc;
@@ -909,9 +920,12 @@ static int cdna_create(vf_handle *h) {
     init_layer(h->enc3_one, "enc3", PACK_PLAIN, H8, W8, H8, W8, 1, 1, 1, 0, L[3], 0, L[3], false);
     init_layer(h->convt1_one, "convt1", PACK_CONVT, H8, W8, H8, W8, 2, 2, 1, 1, L[4], 0, L[4], false);
     init_layer(h->lstm[5], "lstm6", PACK_LSTM, H4, W4, H4, W4, 5, 5, 1, 2, L[4], L[5], L[5], true, false, lstm_mrep[5], cfg->precision, false, ccond);
-    init_layer(h->convt2, "convt2", PACK_CONVT, H4, W4, H4, W4, 2, 2, 1, 1, L[5], L[1], L[5], false, false, 1, 0, true);
-    init_layer(h->lstm[6], "lstm7", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, L[5], L[6], L[6], true, false, lstm_mrep[6], cfg->precision, false, ccond);
-    init_layer(h->convt3, "convt3", PACK_CONVT, H2, W2, H2, W2, 2, 2, 1, 1, L[6], 32, 32, true, false, 1, 0, true);
+    const bool pub = cfg->arch == 0 && cfg->layer_spec == 1;
+    h->c_t2 = pub ? L[5] + L[1] : L[5];
+    h->c_top = pub ? L[6] + 32 : 32;
+    init_layer(h->convt2, "convt2", PACK_CONVT, H4, W4, H4, W4, 2, 2, 1, 1, L[5], L[1], h->c_t2, false, false, 1, 0, true);
+    init_layer(h->lstm[6], "lstm7", PACK_LSTM, H2, W2, H2, W2, 5, 5, 1, 2, h->c_t2, L[6], L[6], true, false, lstm_mrep[6], cfg->precision, false, ccond);
+    init_layer(h->convt3, "convt3", PACK_CONVT, H2, W2, H2, W2, 2, 2, 1, 1, L[6], 32, h->c_top, true, false, 1, 0, true);
     // CDNA FC as a K-split GEMM over 1x1 "images"
     init_layer(h->fc, "cdna", PACK_PLAIN, 1, 1, 1, 1, 1, 1, 1, 0, H8 * W8 * L[4], 0, kTaps * h->K, false, true, 2);
     {
@@ -998,8 +1012,8 @@ static int cdna_create(vf_handle *h) {
             VF_ALLOC(vd.ln_g[i], g->size());
             VF_ALLOC(vd.ln_b[i], g->size());
         }
-        VF_ALLOC(vd.w_rgb, 32 * 3); VF_ALLOC(vd.b_rgb, 3);
-        VF_ALLOC(vd.w_mask, 32 * (h->K + 1)); VF_ALLOC(vd.b_mask, h->K + 1);
+        VF_ALLOC(vd.w_rgb, h->c_top * 3); VF_ALLOC(vd.b_rgb, 3);
+        VF_ALLOC(vd.w_mask, h->c_top * (h->K + 1)); VF_ALLOC(vd.b_mask, h->K + 1);
         VF_ALLOC(vd.w_state, (size_t)nsa * cfg->sdim); VF_ALLOC(vd.b_state, cfg->sdim);
         VF_ALLOC(vd.w_sa, (size_t)nsa * L[3]); VF_ALLOC(vd.b_fc, kTaps * h->K);
         if (h->cond)
@@ -1019,8 +1033,8 @@ static int cdna_create(vf_handle *h) {
     VF_ALLOC(h->enc2_o, BV * H8 * W8 * L[3]);
     VF_ALLOC(h->enc3_o, BV * H8 * W8 * L[3]);
     VF_ALLOC(h->enc4_o, BV * H4 * W4 * L[4]);
-    VF_ALLOC(h->enc5_o, BV * H2 * W2 * L[5]);
-    VF_ALLOC(h->enc6_o, BV * Hc * Wc * 32);
+    VF_ALLOC(h->enc5_o, BV * H2 * W2 * h->c_t2);
+    VF_ALLOC(h->enc6_o, BV * Hc * Wc * h->c_top);
     if (h->savp) {
         VF_ALLOC(h->enc00_o, BV * Hc * Wc * kEnc00Ch);
         VF_ALLOC(h->enc7_o, BV * H * W * 32);
@@ -1064,7 +1078,7 @@ static int cdna_create(vf_handle *h) {
         VF_ALLOC(sv.enc2_o, (size_t)H8 * W8 * L[3]);
         VF_ALLOC(sv.enc3_o, (size_t)H8 * W8 * L[3]);
         VF_ALLOC(sv.enc4_o, (size_t)H4 * W4 * L[4]);
-        VF_ALLOC(sv.enc5_o, (size_t)H2 * W2 * L[5]);
+        VF_ALLOC(sv.enc5_o, (size_t)H2 * W2 * h->c_t2);
         for (int k = 0; k < 7; ++k) {
             const size_t per = (size_t)lh[k] * lw[k] * L[k];
             VF_ALLOC(sv.c_state[k], per);
@@ -1257,7 +1271,7 @@ int vf_load_weights(vf_handle *h, const float *blob_all, size_t n_floats) {
             std::vector<float> w(mw->size()), bb(mb->size());
             for (int j = 0; j < NM; ++j) {
                 const int src = !h->cond ? j : (j == 0 ? NM - 3 : (j == 1 ? NM - 1 : (j == 2 ? NM - 2 : j - 3)));
-                for (int c = 0; c < 32; ++c) w[(size_t)c * NM + j] = (blob + mw->offset)[(size_t)c * NM + src];
+                for (int c = 0; c < h->c_top; ++c) w[(size_t)c * NM + j] = (blob + mw->offset)[(size_t)c * NM + src];
                 bb[j] = (blob + mb->offset)[src];
             }
             if ((rc = dev_write(h, vd.w_mask, w.data(), w.size() * sizeof(float)))) return rc;
@@ -1348,8 +1362,8 @@ static BatchView make_view(vf_handle *h, int view, const float *d_actions, int b
     v.enc2_o = h->enc2_o + b * H8 * W8 * L[3];
     v.enc3_o = h->enc3_o + b * H8 * W8 * L[3];
     v.enc4_o = h->enc4_o + b * H4 * W4 * L[4];
-    v.enc5_o = h->enc5_o + b * H2 * W2 * L[5];
-    v.enc6_o = h->enc6_o + b * Hc * Wc * 32;
+    v.enc5_o = h->enc5_o + b * H2 * W2 * h->c_t2;
+    v.enc6_o = h->enc6_o + b * Hc * Wc * h->c_top;
     for (int k = 0; k < 7; ++k) {
         const size_t per = (size_t)lh[k] * lw[k] * L[k];
         v.c_state[k] = h->c_state[k] + b * per;
@@ -1407,8 +1421,8 @@ struct LaunchSink {
             case PH_CONV_RAW: return launch_conv_t<1, EPI_RAW_STATS>(l, p, st);
             case PH_CONVT_RELU: return launch_conv_t<4, EPI_CONVT_RELU>(l, p, st);
             case PH_CONVT_RAW: return launch_conv_t<4, EPI_CONVT_RAW_STATS>(l, p, st);
-            case PH_CONV_RAW3: return launch_conv_t<1, EPI_RAW>(l, p, st);
-            case PH_CONV_RAW3G2: return launch_conv_m<2, EPI_RAW, 1>(l, p, st);
+            case PH_CONV_RAW3: return l.mrep == 2 ? launch_conv_m<1, EPI_RAW, 2>(l, p, st) : launch_conv_m<1, EPI_RAW, 1>(l, p, st);
+            case PH_CONV_RAW3G2: return l.mrep == 2 ? launch_conv_m<2, EPI_RAW, 2>(l, p, st) : launch_conv_m<2, EPI_RAW, 1>(l, p, st);
             case PH_GATES_RAW: {
                 const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
                 hipLaunchKernelGGL(conv_gates_raw_kernel, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
@@ -1897,7 +1911,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         p.out = D.enc5_o;
         VF_EMIT_SH(u_t2, all_sh, sink.conv_late(PH_CONVT_RELU, h->convt2, p, u_enc1, u_l6))
         VF_EMIT_SH(u_l7, lstm_shared(6, s), sink.lstm(lstm_plan(6, lstm_shared(6, s) ? 1 : B),
-                                lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * L[5]))), u_prev[6], u_t2, u_cond[6]))
+                                lstm_params(6, plain(D.enc5_o, bs(all_sh, (long long)H2 * W2 * h->c_t2))), u_prev[6], u_t2, u_cond[6]))
         last = u_l7;
         {
             const int now[7] = {u_l1, u_l2, u_l3, u_l4, u_l5, u_l6, u_l7};
@@ -1922,7 +1936,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
             if (h->savp) {  // extra decoder scale: enc7 = convT(concat[relu(LN9(enc6)), relu(LNa(enc00))]), LNb on use
                 // (an encoder-shared enc00 of a context step is read with batch stride 0)
                 SegArg enc6_n = normed(v.enc6_o, (long long)Hc * Wc * 32, v.st_enc6, h->convt3.stats_nparts,
-                                       h->convt3.stats_nparts, false, (long long)Hc * Wc * 32, vd.ln_g[8], vd.ln_b[8], 32, 1);
+                                       h->convt3.stats_nparts, false, (long long)Hc * Wc * 32, vd.ln_g[8], vd.ln_b[8], 32, 1);   // (arch 1 / 2: c_top = 32)
                 VF_EMIT(u_t3, sink.conv_late(PH_CONVT_RAW, h->convt3, p, u_enc0, u_l7))
                 p = params(h->convt4, B, enc00_n, &enc6_n);
                 p.out = v.enc7_o; p.stats = v.st_enc7;
@@ -1939,7 +1953,8 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
                 cp.enc6 = v.enc6_o; cp.ln_part = v.st_enc6; cp.ln_nparts = h->convt3.stats_nparts;
                 cp.gamma = vd.ln_g[8]; cp.beta = vd.ln_b[8];
             }
-            cp.ln_inv_n = (float)(1.0 / ((double)H * W * 32));
+            cp.ln_inv_n = (float)(1.0 / ((double)H * W * h->c_top));
+            cp.CF = h->c_top;
             cp.w_rgb = vd.w_rgb; cp.b_rgb = vd.b_rgb; cp.w_mask = vd.w_mask; cp.b_mask = vd.b_mask;
             cp.kern = v.kern;
             cp.prev_frame = frame_in; cp.prev_frame_bstride = frame_bs;
@@ -2164,7 +2179,7 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
         } else if (P.type == PH_COMPOSITE || P.type == PH_TOP_FUSED) {
             const CompositeParams &c = P.comp;
             const size_t hw = (size_t)c.H * c.W;
-            if (P.type == PH_COMPOSITE) ok = ok && in_allocs(h, c.enc6, (size_t)P.B * hw * 32 * 4);
+            if (P.type == PH_COMPOSITE) ok = ok && in_allocs(h, c.enc6, (size_t)P.B * hw * (c.CF > 32 ? c.CF : 32) * 4);
             ok = ok && in_allocs(h, c.prev_frame, ((size_t)(P.B - 1) * c.prev_frame_bstride + hw * 3) * 4);
             ok = ok && in_allocs(h, c.prev_distrib, ((size_t)(P.B - 1) * c.prev_distrib_bstride + hw * c.ND) * 4);
             ok = ok && in_allocs(h, c.out_frame, ((size_t)(P.B - 1) * c.out_frame_bstride + hw * 3) * 4);

@@ -191,11 +191,11 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void lstm_bf16x6
 static __device__ __noinline__ __attribute__((not_tail_called)) void fc_wide_tile_call(const ConvParams *p, int bx, int bz) {
     fc_wide_tile(const_params(p), bx, bz, tile_lds());
 }
-template <int ND, bool FIRST, int K>
+template <int ND, bool FIRST, int K, int CF = 32>
 static __device__ __noinline__ __attribute__((not_tail_called)) void composite_tile_call(const CompositeParams *p, int tile, int b, int view) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
-    composite_tile<ND, K, FIRST>(const_params(p), tile, b, goal, tile_lds());
+    composite_tile<ND, K, FIRST, const VF_CONST_AS CompositeParams, CF>(const_params(p), tile, b, goal, tile_lds());
 }
 static __device__ __noinline__ __attribute__((not_tail_called)) void gates_raw_tile_call(const ConvParams *p, int bx, int by) {
     conv_lstm_gsplit2_tile<4, const VF_CONST_AS ConvParams, true>(const_params(p), bx, by, tile_lds());
@@ -435,10 +435,18 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                 case PH_COMPOSITE:
                     if (P.comp.K == 6) composite_tile_call<ND, true, 6>(&P.comp, local % P.gx, b0, P.view);
                     else if (P.comp.first_frame) composite_tile_call<ND, true, 10>(&P.comp, local % P.gx, b0, P.view);
+                    else if (P.comp.CF > 32) composite_tile_call<ND, false, 10, 64>(&P.comp, local % P.gx, b0, P.view);  // (public decoder)
                     else composite_tile_call<ND, false, 10>(&P.comp, local % P.gx, b0, P.view);
                     break;
-                case PH_CONV_RAW3: conv_tile_call<1, EPI_RAW, 1>(&P.conv, bx, by, 0); break;
-                case PH_CONV_RAW3G2: conv_tile_call<2, EPI_RAW, 1>(&P.conv, bx, by, 0); break;
+                // (mrep 2: the 256-row plan of arch 3's full-resolution layers - half the items, each twice the GEMM rows)
+                case PH_CONV_RAW3:
+                    if (P.mrep == 2) conv_tile_call<1, EPI_RAW, 2>(&P.conv, bx, by, 0);
+                    else conv_tile_call<1, EPI_RAW, 1>(&P.conv, bx, by, 0);
+                    break;
+                case PH_CONV_RAW3G2:
+                    if (P.mrep == 2) conv_tile_call<2, EPI_RAW, 2>(&P.conv, bx, by, 0);
+                    else conv_tile_call<2, EPI_RAW, 1>(&P.conv, bx, by, 0);
+                    break;
                 case PH_GATES_RAW: gates_raw_tile_call(&P.conv, bx, by); break;
                 case PH_EW: {
                     const int idx = P.ew.spi > 0 ? 0 : local - b0 * P.gx;

@@ -228,6 +228,8 @@ struct CompositeParams {
     int goal[kMaxDesig][2];             // (row, col); read by the per-layer kernel only - the persistent
                                         // kernel takes the goals from its launch arguments, so a schedule
                                         // does not depend on them
+    int CF;                             // feature channels of enc6: 0 / 32, or 64 (the public CDNA decoder table, cdna_arch.py
+                                        // decoder='public': the stand-alone compositing tile only, two 32-channel rounds)
 };
 
 // LDS floats needed by composite_tile<ND, K>
@@ -246,43 +248,28 @@ __host__ __device__ constexpr int composite_lds_floats() {
     return ((composite_small_floats<ND, K>() + 3) & ~3) + kCompTile * kCompTile * kCompEncPad;
 }
 
-// One output pixel (y, x) of sample b: LN + relu of its 32 features (a row of the LDS feature tile), the two 1x1
-// heads, softmax, the effective 5x5 flow kernel over the haloed previous frame / distributions in LDS
-// (halo_w = pixels per halo row, (hy, hx) = the pixel's position inside the halo tile, halo 2), outputs and cost terms.
-// Shared by the stand-alone compositing tile and the fused transposed-conv + compositing tile: same expressions,
-// same bits.
-template <int ND, int K, bool FIRST, class PT>
-__device__ __forceinline__ void composite_pixel(const PT &p, const int b, const int y, const int x, const float *feat,
-                                                const float mean, const float rstd, const float *s_px,
-                                                const float *s_kern, const int halo_w,
-                                                const int hy, const int hx, const int *goal, double (&cost)[2 * ND]) {
-    constexpr int NM = K + 1;
-    constexpr int PS = comp_px_stride(ND);
-    static_assert(K <= 10 && ND <= 4, "LDS record layouts");
-    // one halo pixel: frame[3], distributions[ND]
-    auto load_px = [&](const int sp, float (&fr)[3], float (&di)[ND]) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(s_px + sp * PS);
-        fr[0] = a[0]; fr[1] = a[1]; fr[2] = a[2]; di[0] = a[3];
-        if constexpr (ND > 1) {
-            const f32x4 c2 = *reinterpret_cast<const f32x4 *>(s_px + sp * PS + 4);
-#pragma unroll
-            for (int d = 1; d < ND; ++d) di[d] = c2[d - 1];
-        }
-    };
-    // ---- LN9 + relu of this pixel's 32 features, then the two 1x1 heads.  The 512 head / LayerNorm weights are the
-    // same for every lane: read through the CONSTANT address space they are scalar loads feeding the VALU as SGPR
-    // operands - as plain global pointers the compiler issued 132 vector loads (and as many waits) per pixel, which was
-    // half of the compositing time.
+// The two 1x1 heads of one pixel, accumulated over 32 feature channels [c_off, c_off + 32) of the LDS feature row `feat`
+// (LN + relu applied on the way).  The 512 head / LayerNorm weights are the same for every lane: read through the CONSTANT
+// address space they are scalar loads feeding the VALU as SGPR operands - as plain global pointers the compiler issued 132
+// vector loads (and as many waits) per pixel, which was half of the compositing time.
+template <int K, class PT>
+__device__ __forceinline__ void composite_head_bias(const PT &p, float (&o_rgb)[3], float (&o_m)[K + 1]) {
     typedef const __attribute__((address_space(4))) float cfloat;
-    auto as_const = [](const float *q) { return (cfloat *)(unsigned long long)q; };
-    cfloat *gam_ = as_const(p.gamma), *bet_ = as_const(p.beta), *wrgb_ = as_const(p.w_rgb), *wmask_ = as_const(p.w_mask);
-    cfloat *brgb_ = as_const(p.b_rgb), *bmask_ = as_const(p.b_mask);
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(feat);
-    float o_rgb[3], o_m[NM];
+    cfloat *brgb_ = (cfloat *)(unsigned long long)p.b_rgb, *bmask_ = (cfloat *)(unsigned long long)p.b_mask;
 #pragma unroll
     for (int j = 0; j < 3; ++j) o_rgb[j] = brgb_[j];
 #pragma unroll
-    for (int j = 0; j < NM; ++j) o_m[j] = bmask_[j];
+    for (int j = 0; j < K + 1; ++j) o_m[j] = bmask_[j];
+}
+template <int K, class PT>
+__device__ __forceinline__ void composite_heads(const PT &p, const float *feat, const float mean, const float rstd,
+                                                const int c_off, float (&o_rgb)[3], float (&o_m)[K + 1]) {
+    constexpr int NM = K + 1;
+    typedef const __attribute__((address_space(4))) float cfloat;
+    auto as_const = [](const float *q) { return (cfloat *)(unsigned long long)q; };
+    cfloat *gam_ = as_const(p.gamma) + c_off, *bet_ = as_const(p.beta) + c_off;
+    cfloat *wrgb_ = as_const(p.w_rgb) + c_off * 3, *wmask_ = as_const(p.w_mask) + c_off * NM;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(feat);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const f32x4 raw = src[q];
@@ -296,6 +283,46 @@ __device__ __forceinline__ void composite_pixel(const PT &p, const int b, const 
             for (int j = 0; j < NM; ++j) o_m[j] = fmaf(f, wmask_[c * NM + j], o_m[j]);
         }
     }
+}
+template <int ND, int K, bool FIRST, class PT>
+__device__ __forceinline__ void composite_finish(const PT &p, const int b, const int y, const int x, float (&o_rgb)[3],
+                                                 float (&o_m)[K + 1], const float *s_px, const float *s_kern, const int halo_w,
+                                                 const int hy, const int hx, const int *goal, double (&cost)[2 * ND]);
+
+// One output pixel (y, x) of sample b: LN + relu of its 32 features (a row of the LDS feature tile), the two 1x1
+// heads, softmax, the effective 5x5 flow kernel over the haloed previous frame / distributions in LDS
+// (halo_w = pixels per halo row, (hy, hx) = the pixel's position inside the halo tile, halo 2), outputs and cost terms.
+// Shared by the stand-alone compositing tile and the fused transposed-conv + compositing tile: same expressions,
+// same bits.
+template <int ND, int K, bool FIRST, class PT>
+__device__ __forceinline__ void composite_pixel(const PT &p, const int b, const int y, const int x, const float *feat,
+                                                const float mean, const float rstd, const float *s_px,
+                                                const float *s_kern, const int halo_w,
+                                                const int hy, const int hx, const int *goal, double (&cost)[2 * ND]) {
+    constexpr int NM = K + 1;
+    static_assert(K <= 10 && ND <= 4, "LDS record layouts");
+    float o_rgb[3], o_m[NM];
+    composite_head_bias<K>(p, o_rgb, o_m);
+    composite_heads<K>(p, feat, mean, rstd, 0, o_rgb, o_m);
+    composite_finish<ND, K, FIRST>(p, b, y, x, o_rgb, o_m, s_px, s_kern, halo_w, hy, hx, goal, cost);
+}
+
+// the part of a pixel behind its head outputs: softmax, effective flow kernel, next frame / distributions, cost terms
+template <int ND, int K, bool FIRST, class PT>
+__device__ __forceinline__ void composite_finish(const PT &p, const int b, const int y, const int x, float (&o_rgb)[3],
+                                                 float (&o_m)[K + 1], const float *s_px, const float *s_kern, const int halo_w,
+                                                 const int hy, const int hx, const int *goal, double (&cost)[2 * ND]) {
+    constexpr int NM = K + 1;
+    constexpr int PS = comp_px_stride(ND);
+    auto load_px = [&](const int sp, float (&fr)[3], float (&di)[ND]) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(s_px + sp * PS);
+        fr[0] = a[0]; fr[1] = a[1]; fr[2] = a[2]; di[0] = a[3];
+        if constexpr (ND > 1) {
+            const f32x4 c2 = *reinterpret_cast<const f32x4 *>(s_px + sp * PS + 4);
+#pragma unroll
+            for (int d = 1; d < ND; ++d) di[d] = c2[d - 1];
+        }
+    };
     float mx = o_m[0];
 #pragma unroll
     for (int j = 1; j < NM; ++j) mx = fmaxf(mx, o_m[j]);
@@ -374,7 +401,7 @@ __device__ __forceinline__ void composite_pixel(const PT &p, const int b, const 
 // one 16x16 pixel tile of one sample.  FIRST (arch 1, savp_arch.py): the first context frame is one more compositing
 // layer - a template parameter, because a run-time branch around the mask bookkeeping costs the CDNA path 3.5 us per
 // tile (measured).
-template <int ND, int K, bool FIRST, class PT>
+template <int ND, int K, bool FIRST, class PT, int CFT = 32>
 __device__ __forceinline__ void composite_tile(const PT &p, const int tile, const int b, const int *goal,
                                                float *smem) {
     constexpr int TS = kCompTile, HS = TS + 4;
@@ -390,6 +417,7 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
     const int tilesX = (p.W + TS - 1) / TS;
     const int nblocks = sum_blocks(p.H, p.W);
     const int ty0 = (tile / tilesX) * TS, tx0 = (tile % tilesX) * TS;
+    constexpr int CF = CFT;                     // feature channels per pixel (64: the public decoder table, two rounds below)
 
     // The tile's 32-channel features are fetched cooperatively - a wave instruction reads 1 KiB of consecutive
     // pixels - and transposed through LDS; one thread reading the 128 bytes of "its" pixel straight from memory
@@ -401,7 +429,7 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
         const int yy = ty0 + (px >> 4), xx = tx0 + (px & 15);
         ev[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (yy < p.H && xx < p.W)
-            ev[k] = *reinterpret_cast<const f32x4 *>(p.enc6 + (((long long)b * p.H + yy) * p.W + xx) * 32 + q * 4);
+            ev[k] = *reinterpret_cast<const f32x4 *>(p.enc6 + (((long long)b * p.H + yy) * p.W + xx) * CF + q * 4);
     }
 
     // prologue reductions, lanes over the partials (32 LayerNorm partials and 64 tiles per sample at 128x128):
@@ -457,9 +485,33 @@ __device__ __forceinline__ void composite_tile(const PT &p, const int tile, cons
 #pragma unroll
     for (int i = 0; i < 2 * ND; ++i) cost[i] = 0.0;
 
-    if (valid)
-        composite_pixel<ND, K, FIRST>(p, b, y, x, &s_enc[tid * kCompEncPad], s_ln[0], s_ln[1], s_px, s_kern, HS,
-                                      ly, lx, goal, cost);
+    if constexpr (CF == 32) {
+        if (valid)
+            composite_pixel<ND, K, FIRST>(p, b, y, x, &s_enc[tid * kCompEncPad], s_ln[0], s_ln[1], s_px, s_kern, HS,
+                                          ly, lx, goal, cost);
+    } else {
+        // 64 feature channels (cdna_arch.py decoder='public'): the heads accumulate over two 32-channel rounds through the
+        // same LDS feature tile - channel order 0 .. 63, i.e. the fma chain of the one-round form continued
+        float o_rgb[3], o_m[NM];
+        composite_head_bias<K>(p, o_rgb, o_m);
+        composite_heads<K>(p, &s_enc[tid * kCompEncPad], s_ln[0], s_ln[1], 0, o_rgb, o_m);     // (a pixel outside the image reads zeros)
+#pragma unroll
+        for (int c_off = 32; c_off < CF; c_off += 32) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = tid + 256 * k, px = i >> 3, q = i & 7;
+                const int yy = ty0 + (px >> 4), xx = tx0 + (px & 15);
+                f32x4 e = {0.f, 0.f, 0.f, 0.f};
+                if (yy < p.H && xx < p.W)
+                    e = *reinterpret_cast<const f32x4 *>(p.enc6 + (((long long)b * p.H + yy) * p.W + xx) * CF + c_off + q * 4);
+                *reinterpret_cast<f32x4 *>(&s_enc[(i >> 3) * kCompEncPad + (i & 7) * 4]) = e;
+            }
+            __syncthreads();
+            composite_heads<K>(p, &s_enc[tid * kCompEncPad], s_ln[0], s_ln[1], c_off, o_rgb, o_m);
+        }
+        if (valid) composite_finish<ND, K, FIRST>(p, b, y, x, o_rgb, o_m, s_px, s_kern, HS, ly, lx, goal, cost);
+    }
     // ---- cost sums of this wave's block (4 rows x 16 columns): lanes in a fixed butterfly, one entry per block
 #pragma unroll
     for (int i = 0; i < 2 * ND; ++i) cost[i] = wave_sum(cost[i]);
@@ -479,7 +531,10 @@ template <int ND, int K>
 VF_GLOBAL VF_LAUNCH_BOUNDS(256) void composite_kernel(const CompositeParams p) {
     __shared__ __attribute__((aligned(16))) float smem[composite_lds_floats<ND, K>()];
     if (K == 6 || p.first_frame) composite_tile<ND, K, true>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
-    else if constexpr (K != 6) composite_tile<ND, K, false>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
+    else if constexpr (K != 6) {
+        if (p.CF > 32) composite_tile<ND, K, false, CompositeParams, 64>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
+        else composite_tile<ND, K, false>(p, blockIdx.x, blockIdx.y, &p.goal[0][0], smem);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -59,7 +59,10 @@ class CdnaConfig(object):
     """Static shape of one predictor instance."""
 
     def __init__(self, height=64, width=64, adim=4, sdim=5, ndesig=1, n_context=2,
-                 sequence_length=15, num_masks=10, ncam=1):
+                 sequence_length=15, num_masks=10, ncam=1, decoder='survey'):
+        if decoder not in ('survey', 'public'):
+            raise ValueError("decoder must be 'survey' or 'public', got %r" % (decoder,))
+        self.decoder = decoder
         if height % 8 or width % 8:
             raise ValueError('image size must be a multiple of 8, got %dx%d' % (height, width))
         if ncam != 1:
@@ -78,10 +81,18 @@ class CdnaConfig(object):
     arch = 'cdna'           # architecture tag (manifest, vf_config.arch): 'cdna' here, 'savp' in savp_arch.py
     arch_id = 0
 
+    @property
+    def layer_spec(self):
+        """``vf_config.layer_spec`` of this table: 1 = the public decoder widths (arch 'cdna' only)."""
+        return 1 if self.decoder == 'public' else 0
+
     def as_dict(self):
-        return dict(height=self.height, width=self.width, adim=self.adim, sdim=self.sdim,
-                    ndesig=self.ndesig, n_context=self.n_context,
-                    sequence_length=self.sequence_length, num_masks=self.num_masks)
+        d = dict(height=self.height, width=self.width, adim=self.adim, sdim=self.sdim,
+                 ndesig=self.ndesig, n_context=self.n_context,
+                 sequence_length=self.sequence_length, num_masks=self.num_masks)
+        if self.decoder != 'survey':
+            d['decoder'] = self.decoder
+        return d
 
     def tensor_shapes(self):
         """Ordered name -> shape table of every learned tensor of this architecture."""
@@ -118,11 +129,17 @@ def tensor_shapes(cfg):
     conv('lstm5', 5, 5, L[3] + L[4], 4 * L[4]); ln('ln6', L[4])
     conv('convt1', 3, 3, L[4], L[4])
     conv('lstm6', 5, 5, L[4] + L[5], 4 * L[5]); ln('ln7', L[5])
-    conv('convt2', 3, 3, L[5] + L[1], L[5])
-    conv('lstm7', 5, 5, L[5] + L[6], 4 * L[6]); ln('ln8', L[6])
-    conv('convt3', 3, 3, L[6] + 32, 32);     ln('ln9', 32)
-    conv('rgb', 1, 1, 32, 3)
-    conv('masks', 1, 1, 32, K + 1)
+    # decoder widths: 'survey' = SURVEY.md row a14 (convt2 96 -> 64, convt3 64 -> 32); 'public' = the public
+    # ``prediction_model.py`` of arXiv:1605.07157, whose transposed convs keep the width of their (concatenated) input
+    # (``conv2d_transpose(hidden6, hidden6.get_shape()[3], ...)``): convt2 96 -> 96, convt3 64 -> 64, so lstm7 convolves
+    # 96 + 32 channels and the 1 x 1 heads read 64.  A checkpoint has one or the other.
+    pub = getattr(cfg, 'decoder', 'survey') == 'public'
+    c_t2, c_top = (L[5] + L[1], L[6] + 32) if pub else (L[5], 32)
+    conv('convt2', 3, 3, L[5] + L[1], c_t2)
+    conv('lstm7', 5, 5, c_t2 + L[6], 4 * L[6]); ln('ln8', L[6])
+    conv('convt3', 3, 3, L[6] + 32, c_top);  ln('ln9', c_top)
+    conv('rgb', 1, 1, c_top, 3)
+    conv('masks', 1, 1, c_top, K + 1)
     t['cdna/w'] = (fc_in, DNA_KERN * DNA_KERN * K)
     t['cdna/b'] = (DNA_KERN * DNA_KERN * K,)
     t['state/w'] = (a, cfg.sdim)
@@ -232,7 +249,9 @@ class CdnaWeights(object):
             raise ValueError('checkpoint architecture %r does not match requested %r' % (arch, cfg.arch))
         if cfg is not None:
             mine, theirs = cfg.as_dict(), file_cfg.as_dict()
-            for k in ('height', 'width', 'adim', 'sdim', 'num_masks') + (('zdim', 'layer_spec') if arch == 'savp3' else ()):
+            for k in ('height', 'width', 'adim', 'sdim', 'num_masks') + (('zdim', 'layer_spec') if arch == 'savp3' else ()) + \
+                    (('decoder',) if 'decoder' in mine or 'decoder' in theirs else ()):
+                mine.setdefault('decoder', 'survey'); theirs.setdefault('decoder', 'survey')
                 if mine[k] != theirs[k]:
                     raise ValueError('checkpoint %s=%r does not match requested %r' % (k, theirs[k], mine[k]))
             file_cfg = cfg      # ndesig / sequence_length are run-time choices, not weights

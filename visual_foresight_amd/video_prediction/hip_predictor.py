@@ -74,6 +74,8 @@ class HipVPredEvaluation(object):
             raise ValueError("arch must be 'cdna', 'savp', 'savp2' or 'savp3', got %r" % (self.arch,))
         cfg_cls = {'cdna': CdnaConfig, 'savp': SavpConfig, 'savp2': Savp2Config, 'savp3': Savp3Config}[self.arch]
         extra = dict(zdim=int(hp.get('zdim', 8)), layer_spec=int(hp.get('layer_spec', 0))) if self.arch == 'savp3' else {}
+        if self.arch == 'cdna' and hp.get('decoder', 'survey') != 'survey':
+            extra = dict(decoder=hp['decoder'])     # 'public': the decoder widths of the public CDNA code (cdna_arch.py)
         self.cfg = cfg_cls(height=hp.get('image_height', 64), width=hp.get('image_width', 64),
                            adim=hp.get('adim', 4), sdim=hp.get('sdim', 5),
                            ndesig=hp.get('designated_pixel_count', 1), n_context=self.n_context,

@@ -75,7 +75,7 @@ class Savp3Config(CdnaConfig):
                  num_masks=N_WARP, ncam=1, zdim=8, layer_spec=0):
         if num_masks != N_WARP:
             raise ValueError('savp3 composes %d CDNA warps (num_masks = %d)' % (N_WARP, N_WARP))
-        self.zdim, self.layer_spec = int(zdim), int(layer_spec)
+        self.zdim, self._layer_spec = int(zdim), int(layer_spec)
         if not 0 < self.zdim < adim:
             raise ValueError('adim (%d) includes the zdim (%d) latent channels' % (adim, zdim))
         self.enc, self.dec = layer_specs(height, width, layer_spec)
@@ -83,6 +83,10 @@ class Savp3Config(CdnaConfig):
         if height % f or width % f or height // f < 4 or width // f < 4:
             raise ValueError('savp3 with %d scales needs sizes that are multiples of %d and at least %d' % (len(self.enc), f, 4 * f))
         super(Savp3Config, self).__init__(height, width, adim, sdim, ndesig, n_context, sequence_length, num_masks, ncam)
+
+    @property
+    def layer_spec(self):
+        return self._layer_spec
 
     def as_dict(self):
         return dict(super(Savp3Config, self).as_dict(), zdim=self.zdim, layer_spec=self.layer_spec)
