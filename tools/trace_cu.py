@@ -23,21 +23,33 @@ from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluati
 
 M, T = int(sys.argv[1]) if len(sys.argv) > 1 else 200, 13
 prec = sys.argv[2] if len(sys.argv) > 2 else 'fp32'
-WGS, MAXE = 512, 8192
+# optional: network, image size, horizon, layer_spec, events per workgroup of the trace build (-DVF_TRACE_MAX)
+#   VF_LIBRARY=build/ab/trace64k.so python tools/trace_cu.py 625 fp32 savp3 128 2 0 65536
+ARCH = sys.argv[3] if len(sys.argv) > 3 else 'cdna'
+HH = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+T = int(sys.argv[5]) if len(sys.argv) > 5 else T
+SPEC = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+WGS, MAXE = 512, int(sys.argv[7]) if len(sys.argv) > 7 else 8192
 TICK_US = 0.01
 TR_TICKET, TR_DONE, TR_STAGE, TR_KLOOP, TR_LATE, TR_LATE_END, TR_EPI, TR_MFMAS, TR_HWID, TR_RUN = 1, 3, 10, 11, 12, 13, 14, 15, 20, 32
 TR_ST_LOADED, TR_ST_WRITTEN = 16, 17
 TR_YIELD, TR_YIELD_END = 18, 19    # a recurrent half asleep for its CU partner (round 5), inside a K loop
 PH_LSTM = 0
-PH_NAMES = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED', 'CONV_PAIR']
+PH_NAMES = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED', 'CONV_PAIR',
+            'COND', 'CONV_RAW3', 'GATES_RAW', 'EW', 'CONV_RAW3G2']
+PH_GATES_RAW = 13       # arch 3's gate GEMM: the gate-split K loop with the raw epilogue - a conv-LSTM K loop for this analysis
 
-pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2, precision=prec)).restore()
+adim = 12 if ARCH.startswith('savp') else 4
+extra = dict(arch=ARCH, adim=adim, image_height=HH, image_width=HH) if ARCH != 'cdna' or HH != 64 else {}
+if ARCH == 'savp3':
+    extra.update(zdim=8, layer_spec=SPEC)
+pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2, precision=prec, **extra)).restore()
 rs = np.random.RandomState(0)
-d = np.zeros((2, 1, 64, 64, 1), np.float32)
-d[:, 0, 32, 32, 0] = 1
-ctx = {'context_frames': rs.randint(0, 256, (2, 1, 64, 64, 3)).astype(np.uint8), 'context_actions': np.zeros((1, 4)),
+d = np.zeros((2, 1, HH, HH, 1), np.float32)
+d[:, 0, HH // 2, HH // 2, 0] = 1
+ctx = {'context_frames': rs.randint(0, 256, (2, 1, HH, HH, 3)).astype(np.uint8), 'context_actions': np.zeros((1, adim)),
        'context_states': np.zeros((2, 5)), 'context_pixel_distributions': d}
-acts = rs.normal(0, 0.05, (M, T, 4))
+acts = rs.normal(0, 0.05, (M, T, adim))
 lib = _lib.load_library()
 pred.score(ctx, {'actions': acts}, [[[16, 48]]])
 pred.set_profiling(True)
@@ -76,7 +88,7 @@ for w in range(WGS):
         elif c == TR_TICKET:
             close(v, 'wait')
         elif c >= TR_RUN:
-            lstm = (c - TR_RUN) == PH_LSTM
+            lstm = (c - TR_RUN) in (PH_LSTM, PH_GATES_RAW)
             if state == 'wait':
                 state = 'wait:' + PH_NAMES[c - TR_RUN]      # the wait in front of an item belongs to that item's type
             close(v, 'pro' if lstm else 'light:' + PH_NAMES[c - TR_RUN])

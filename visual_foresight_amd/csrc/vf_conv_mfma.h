@@ -57,7 +57,10 @@ __device__ unsigned long long g_tile_clk[32][8];
 // wait, epilogue, publish) - from which the co-residency statistics of a CU (both workgroups in their K loops / one /
 // none, and the MFMA rate in each case) are reconstructed.  One 64-bit word per event: (wall_clock64 << 8) | code, or
 // (value << 8) | code for the value-carrying codes.  The event count lives in word 5 of the LDS control block.
-constexpr int kTraceMax = 8192;
+#ifndef VF_TRACE_MAX
+#define VF_TRACE_MAX 8192
+#endif
+constexpr int kTraceMax = VF_TRACE_MAX;       // events per workgroup (-DVF_TRACE_MAX=65536 for the long launches of arch 3)
 constexpr int kTraceWgs = 512;
 __device__ unsigned long long g_trace[(size_t)kTraceWgs * kTraceMax];
 __device__ unsigned g_trace_n[kTraceWgs];
