@@ -1981,6 +1981,27 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
     return VF_OK;
 }
 
+// Write-through publish (ConvParams::wt_out: the item bumps its completion counters WITHOUT a release fence) is only sound
+// for a tile ALL of whose global stores are sc1 / agent-scope atomic stores.  This is the one place that knows which
+// (phase type, tile plan, output width) combinations dispatch such an epilogue on the device (vf_persistent.h's switch,
+// conv_epilogue's kVec predicate, lstm_gsplit_epilogue / gates_raw_epilogue): build_schedule derives wt_out from it - never
+// from the phase type alone - and vf_selftest_schedule re-checks every phase against the restated conditions.
+static bool wt_epilogue(const PhaseDesc &P) {
+    switch (P.type) {
+        case PH_LSTM:           // gate-split 128- / 64-row tiles and the 32-row tile (lstm_gsplit_epilogue), exact fp32
+            return P.prec == 0 && (P.mrep == 6 || P.mrep == 5 || P.mrep == -1);
+        case PH_CONV_RELU: case PH_CONV_RAW: case PH_CONVT_RELU: case PH_CONVT_RAW:
+            // conv_epilogue's vectorised form: one row block per wave, whole channel quads
+            return (VF_WT_DEFAULT & 2) != 0 && P.mrep == 1 && P.conv.Cout % 4 == 0;
+        case PH_CONV_RAW3: case PH_CONV_RAW3G2:     // EPI_RAW is vectorised for one and two row blocks per wave
+            return (VF_WT_DEFAULT & 2) != 0 && (P.mrep == 1 || P.mrep == 2) && P.conv.Cout % 4 == 0;
+        case PH_GATES_RAW:      // gates_raw_epilogue: sixteen 16-byte stores per lane, nothing else
+            return true;
+        default:
+            return false;
+    }
+}
+
 // ------------------------------------------------------------------ persistent schedule (host part)
 struct BuiltSchedule {
     std::vector<PhaseDesc> phases;
@@ -2062,6 +2083,8 @@ static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &
             if (q < nq) out.total_q[q] += P.n_q[q];
         }
     }
+    for (PhaseDesc &P : out.phases)
+        if (ph_is_conv(P.type)) P.conv.wt_out = (h->wt_publish && wt_epilogue(P)) ? 1 : 0;
     out.counters = counters;
     const size_t comp_lds[kMaxDesig] = {(size_t)composite_lds_floats<1, 10>() * 4, (size_t)composite_lds_floats<2, 10>() * 4,
                                         (size_t)composite_lds_floats<3, 10>() * 4, (size_t)composite_lds_floats<4, 10>() * 4};
@@ -2130,6 +2153,14 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
             }
             ok = ok && in_allocs(h, c.Wp, 16) && in_allocs(h, c.bias, 4) && in_allocs(h, c.out, 4);
             ok = ok && in_allocs(h, c.cstate, 4) && in_allocs(h, c.cstate_in, 4) && in_allocs(h, c.stats, 8);
+        }
+        // a write-through item must be one whose every store is a 16-byte sc1 store (restated here, not read from wt_epilogue)
+        if (P.conv.wt_out != 0) {
+            const bool lstm_vec = P.type == PH_LSTM && P.prec == 0 && (P.mrep == 6 || P.mrep == 5 || P.mrep == -1);
+            const bool light_vec = P.type >= PH_CONV_RELU && P.type <= PH_CONVT_RAW && P.mrep == 1 && P.conv.Cout % 4 == 0;
+            const bool raw3_vec = (P.type == PH_CONV_RAW3 || P.type == PH_CONV_RAW3G2) && (P.mrep == 1 || P.mrep == 2) && P.conv.Cout % 4 == 0;
+            if (!(lstm_vec || light_vec || raw3_vec || P.type == PH_GATES_RAW))
+                return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": write-through publish on a tile with plain stores");
         }
         if (P.type == PH_TOP_FUSED && (P.aux_base != P.cnt_base + P.B || P.aux_base + P.B > bs.counters))
             return fail(VF_ERR_INVALID, "fused phase: bad auxiliary counters");
@@ -2377,15 +2408,7 @@ static int run_persistent(vf_handle *h, const float *d_actions, int B, const int
                     P.conv.yield_budget = P.type == PH_LSTM ? yield_for(h, B) : 0;
                 }
             }
-            // the fp32 tiles with 16-byte epilogue stores (gate-split 128 / 64 rows, 32 rows) publish write-through
-            if (P.type == PH_LSTM && h->wt_publish && P.prec == 0 && (P.mrep == 6 || P.mrep == 5 || P.mrep == -1))
-                P.conv.wt_out = 1;
-            // ... and so do the light layers (conv_epilogue's vectorised form: every conv / transposed-conv tile)
-            if (P.type >= PH_CONV_RELU && P.type <= PH_CONVT_RAW && h->wt_publish && (VF_WT_DEFAULT & 2)) P.conv.wt_out = 1;
-            // arch 3: the raw epilogues store 16 bytes per lane (EPI_RAW needs whole channel quads; gates_raw_epilogue always)
-            if ((P.type == PH_CONV_RAW3 || P.type == PH_CONV_RAW3G2) && h->wt_publish && (VF_WT_DEFAULT & 2) && P.conv.Cout % 4 == 0)
-                P.conv.wt_out = 1;
-            if (P.type == PH_GATES_RAW && h->wt_publish) P.conv.wt_out = 1;
+            // (write-through publish: decided in build_schedule from the tile's epilogue, wt_epilogue())
             if (P.type == PH_CONV_PAIR) P.conv.fuse_next = &sc_host.d_phases[i].conv2;
             if (P.type != PH_TOP_FUSED) continue;
             P.conv.fuse_comp = &sc_host.d_phases[i].comp;

@@ -202,7 +202,7 @@ __device__ __forceinline__ void cond_bias_sample(const PT &p, const int b0, cons
     }
 }
 
-VF_GLOBAL void cond_bias_kernel(const CondParams p) {
+VF_GLOBAL VF_LAUNCH_BOUNDS(256) void cond_bias_kernel(const CondParams p) {
     __shared__ float sv[kCondPerItem * 32];
     const int b0 = blockIdx.x * kCondPerItem;
     cond_bias_sample(p, b0, min(b0 + kCondPerItem, p.B), sv);
