@@ -103,8 +103,9 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
         const unsigned so_ = (unsigned)(min(gt, gtN - 1) * 4 + q_) * gs_wstep_b;
         gsW[q_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gs_rsrc, gs_loff, so_, 0));
     };
+    const int ci0 = p.chunk_begin;          // (chunks in front of it multiply zeros: vf_conv_mfma.h, ConvParams::chunk_begin)
 #pragma unroll
-    for (int q_ = 0; q_ < 4; ++q_) gs_loadq(q_, 0);
+    for (int q_ = 0; q_ < 4; ++q_) gs_loadq(q_, ci0 * 25);
 
     // ---- staging of one chunk.  Element u of a thread = pixel (tid / 8) + 32 u, channel quad tid % 8.
     const unsigned magic_px = 0xFFFFFFFFu / (unsigned)tile_px + 1u, magic_lw = 0xFFFFFFFFu / (unsigned)LW + 1u;
@@ -267,7 +268,7 @@ __device__ __forceinline__ void conv_lstm_gsplit2_tile(const PT &p, const int bx
     __builtin_amdgcn_s_setprio(0);
     const f32x4 *a4 = reinterpret_cast<const f32x4 *>(smem);
     bool pf = false;                    // batch 0 of this chunk was requested under the previous K loop
-    for (int ci = 0; ci < total_chunks; ++ci) {
+    for (int ci = ci0; ci < total_chunks; ++ci) {
         if (late && ci == p.seg[0].nchunk) {         // the recurrent chunks are done: now the layer input is needed
             const int b1 = p.NI == 1 ? bimg0 + 1 : min(bimg0 + p.NI, p.B);
             if constexpr (kInLaunch) VF_TRACE_EVT(TR_LATE);

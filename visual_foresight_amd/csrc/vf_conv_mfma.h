@@ -182,6 +182,9 @@ struct ConvParams {
     // arch 2: the per-sample border-class biases of the tiled conditioning vector, [B][25][4 Cout] (cond_bias_sample,
     // vf_small_kernels.h), added to the gate pre-activations in the conv-LSTM epilogue; null: none
     const float *cond_bias;
+    // gate-split tile only: first channel chunk of the K loop.  A conv-LSTM's recurrent input is all zeros at the first step
+    // of a rollout - its chunks (segment 0) contribute nothing and are skipped (arch 3; 0 = every chunk)
+    int chunk_begin;
 };
 
 constexpr unsigned kLateSpinLimit = 1u << 26;   // polls before a mid-item wait gives up (as kSpinLimit)

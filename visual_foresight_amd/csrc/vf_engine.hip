@@ -1577,7 +1577,7 @@ struct ScheduleSink {
         max_lds = std::max(max_lds, l.lds_bytes);
         const double rows = (double)p.B * l.Hout * l.Wout;
         const double taps = l.mode == PACK_CONVT ? 9.0 / 4.0 * 4.0 : (double)l.KH * l.KW;   // real taps
-        flops += 2.0 * rows * taps * (l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0)) *
+        flops += 2.0 * rows * taps * (l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0) - p.chunk_begin * l.KC) *
                  (l.mode == PACK_LSTM ? 4.0 : (l.mode == PACK_PLAIN ? (double)l.G : 1.0)) * l.Cout;
         return add(P, P.gx * P.gy * l.nsplit, P.whole ? 1 : p.B, deps);
     }
@@ -2307,17 +2307,9 @@ static int zero_shared_state(vf_handle *h, const BatchView &sh, hipStream_t st) 
     return VF_OK;
 }
 
-// arch 3: the recurrent input of step 0 is read from parity 0 of every conv-LSTM's hidden state
-static int s3_zero_state(vf_handle *h, int B, hipStream_t st) {
-    for (int i = 0; i < h->s3->nl; ++i) {
-        const S3Layer &l = h->s3->L[i];
-        if (!l.rnn) continue;
-        const size_t per = (size_t)l.ho * l.wo * l.C;
-        for (int v = 0; v < h->ncam; ++v)
-            VF_HIP_CHECK(hipMemsetAsync(l.hst[0] + (size_t)v * h->cfg.max_batch * per, 0, (size_t)B * per * sizeof(float), st));
-    }
-    return VF_OK;
-}
+// arch 3: nothing to clear - at step 0 every conv-LSTM skips its recurrent chunks (ConvParams::chunk_begin: h(-1) = 0 would
+// only multiply zeros) and its cell item takes c(-1) = 0 from a null pointer
+static int s3_zero_state(vf_handle *, int, hipStream_t) { return VF_OK; }
 
 static int run_steps(vf_handle *h, int view, const BatchView &v, const BatchView &sh, int B,
                      const int32_t *goal_pix, hipStream_t st, bool skip_shared) {
