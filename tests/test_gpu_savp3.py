@@ -123,6 +123,32 @@ def test_savp3_launch_strategies_chunking_and_queues_are_bit_identical():
     assert pred.device_status() == 0
 
 
+def test_fused_and_four_phase_heads_both_match_the_oracle():
+    """The heads' second phase as one item per tile (EW_TOP3: scratch conv, layers, mask conv on the VALU, composition; default) and
+    as four phases through memory (``fuse_top = 0``: MFMA convs) are different summation orders of the same network: each
+    matches the oracle, and they agree with each other to fp32 rounding - not bit for bit."""
+    H, W, T, M, nd = 64, 48, 3, 6, 2
+    rs = np.random.RandomState(31)
+    ctx = _context(H, W, nd, rs)
+    actions = _actions(M, T, rs)
+    goal = rs.randint(0, 48, (1, nd, 2))
+    f, d, _ = None, None, None
+    outs = []
+    for fuse in (1, 0):
+        pred, weights = _predictor(H, W, T, nd, bs=M, fuse_top=fuse)
+        if f is None:
+            f, d, _ = _oracle(weights, ctx, actions)
+        scores, _ = pred.score(ctx, {'actions': actions}, goal)
+        got = pred(ctx, {'actions': actions})
+        assert np.abs(got['predicted_frames'] - f).max() <= 3e-5, fuse
+        dmax = d.max(axis=(3, 4), keepdims=True)
+        assert (np.abs(got['predicted_pixel_distributions'] - d) / dmax).max() <= 2e-5, fuse
+        np.testing.assert_allclose(scores, pixel_cost.eval_pixel_cost(d, goal, 10.)[0], rtol=1e-5)
+        outs.append((scores, got['predicted_frames']))
+    assert np.abs(outs[0][1] - outs[1][1]).max() <= 3e-5
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
+
+
 def test_savp3_two_views_one_launch():
     H = W = 64
     T, M, nd = 2, 5, 2

@@ -722,6 +722,10 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_mfma_kernel<2, EPI_RAW, 1>, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_RAW, 2>, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<2, EPI_RAW, 2>, n))) return rc;
+    if ((rc = allow_lds(&ew_kernel<1>, ew_lds_bytes(EW_TOP3, 1)))) return rc;
+    if ((rc = allow_lds(&ew_kernel<2>, ew_lds_bytes(EW_TOP3, 2)))) return rc;
+    if ((rc = allow_lds(&ew_kernel<3>, ew_lds_bytes(EW_TOP3, 3)))) return rc;
+    if ((rc = allow_lds(&ew_kernel<4>, ew_lds_bytes(EW_TOP3, 4)))) return rc;
     const size_t np = n + kCtlWords * sizeof(int);
     if ((rc = allow_lds(&rollout_persistent_kernel<1>, np))) return rc;
     if ((rc = allow_lds(&rollout_persistent_kernel<2>, np))) return rc;
@@ -1435,11 +1439,12 @@ struct LaunchSink {
     // element-wise items of arch 3 (vf_savp3.h): one workgroup per item
     int ew(const EwParams &p, int /*view*/, std::initializer_list<int>) {
         const int items = p.spi > 0 ? (p.B + p.spi - 1) / p.spi : p.B * p.gx;
+        const size_t lds = ew_lds_bytes(p.op, h->ND);
         switch (h->ND) {
-            case 1: hipLaunchKernelGGL(ew_kernel<1>, dim3(items), dim3(kConvThreads), 0, st, p); break;
-            case 2: hipLaunchKernelGGL(ew_kernel<2>, dim3(items), dim3(kConvThreads), 0, st, p); break;
-            case 3: hipLaunchKernelGGL(ew_kernel<3>, dim3(items), dim3(kConvThreads), 0, st, p); break;
-            default: hipLaunchKernelGGL(ew_kernel<4>, dim3(items), dim3(kConvThreads), 0, st, p); break;
+            case 1: hipLaunchKernelGGL(ew_kernel<1>, dim3(items), dim3(kConvThreads), lds, st, p); break;
+            case 2: hipLaunchKernelGGL(ew_kernel<2>, dim3(items), dim3(kConvThreads), lds, st, p); break;
+            case 3: hipLaunchKernelGGL(ew_kernel<3>, dim3(items), dim3(kConvThreads), lds, st, p); break;
+            default: hipLaunchKernelGGL(ew_kernel<4>, dim3(items), dim3(kConvThreads), lds, st, p); break;
         }
         VF_HIP_CHECK(hipGetLastError());
         return VF_OK;
@@ -1550,7 +1555,7 @@ struct ScheduleSink {
         P.type = PH_EW; P.ew = p; P.B = p.B; P.view = view;
         P.gx = p.spi > 0 ? 1 : p.gx; P.gy = 1;
         const int items = p.spi > 0 ? (p.B + p.spi - 1) / p.spi : p.B * p.gx;
-        max_lds = std::max(max_lds, (size_t)kEwLdsFloats * 4);
+        max_lds = std::max(max_lds, ew_lds_bytes(p.op, p.op == EW_TOP3 ? p.top.ND : 1));
         return add(P, items, p.B, deps);
     }
     // a two-input tile whose segment 0 comes from u_early and whose segment 1 from u_late (decoder convs: the encoder
@@ -2176,6 +2181,7 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
                 ok = ok && (q.split == 0 || (in_allocs(h, q.out2, ((size_t)(P.B - 1) * q.out_bs + hw * co) * 4) && q.C == 2 * q.split));
                 ok = ok && in_allocs(h, q.cond, q.cond ? ((size_t)(P.B - 1) * q.cond_bs + 25 * ctot) * 4 : 0);
                 ok = ok && in_allocs(h, q.g0, ctot * 4) && in_allocs(h, q.b0, ctot * 4) && q.C % q.cpi == 0 && e.gx == q.C / q.cpi;
+                ok = ok && in_allocs(h, q.tab, q.tab ? (size_t)P.B * q.C * 2 * 4 : 0);
                 if (e.op == EW_INCELL)
                     ok = ok && in_allocs(h, q.cout, ((size_t)(P.B - 1) * q.cout_bs + hw * q.C) * 4) &&
                          in_allocs(h, q.cprev, q.cprev ? ((size_t)(P.B - 1) * q.cprev_bs + hw * q.C) * 4 : 0) &&
@@ -2199,8 +2205,15 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
             } else {
                 const TopParams &q = e.top;
                 const size_t hw = (size_t)q.H * q.W;
-                ok = ok && in_allocs(h, q.trans, (size_t)P.B * hw * kTransCh * 4) && in_allocs(h, q.transd, (size_t)P.B * hw * kNumWarp3 * q.ND * 4);
-                ok = ok && in_allocs(h, q.mlog, (size_t)P.B * hw * kMaskCh * 4) && in_allocs(h, q.scr_raw, (size_t)P.B * hw * kScrCh * 4);
+                if (e.op == EW_TOP3) {
+                    ok = ok && in_allocs(h, q.hmhs_raw, (size_t)P.B * hw * 64 * 4) && in_allocs(h, q.norm_tab, (size_t)P.B * 128 * 4);
+                    ok = ok && in_allocs(h, q.w_scr, (size_t)9 * 32 * 4 * 4) && in_allocs(h, q.b_scr, 16);
+                    ok = ok && in_allocs(h, q.w_msk, (size_t)9 * kT3MaskIn * 8 * 4) && in_allocs(h, q.b_msk, 32);
+                    ok = ok && e.gx == ((q.H + kT3H - 1) / kT3H) * ((q.W + kT3W - 1) / kT3W);
+                } else {
+                    ok = ok && in_allocs(h, q.trans, (size_t)P.B * hw * kTransCh * 4) && in_allocs(h, q.transd, (size_t)P.B * hw * kNumWarp3 * q.ND * 4);
+                    ok = ok && in_allocs(h, q.mlog, (size_t)P.B * hw * kMaskCh * 4) && in_allocs(h, q.scr_raw, (size_t)P.B * hw * kScrCh * 4);
+                }
                 ok = ok && in_allocs(h, q.prev_frame, ((size_t)(P.B - 1) * q.prev_frame_bs + hw * 3) * 4);
                 ok = ok && in_allocs(h, q.prev_distrib, ((size_t)(P.B - 1) * q.prev_distrib_bs + hw * q.ND) * 4);
                 ok = ok && in_allocs(h, q.out_frame, ((size_t)(P.B - 1) * q.out_frame_bs + hw * 3) * 4);

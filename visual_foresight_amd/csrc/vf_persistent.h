@@ -222,6 +222,12 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void ew_transfor
     transform_item<ND>(const_params(p_).top, idx, b, tile_lds());
 }
 template <int ND>
+static __device__ __noinline__ __attribute__((not_tail_called)) void ew_top3_call(const EwParams *p_, int idx, int b, int view) {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
+    top3_item<ND>(const_params(p_).top, idx, b, goal, tile_lds());
+}
+template <int ND>
 static __device__ __noinline__ __attribute__((not_tail_called)) void ew_compose_call(const EwParams *p_, int idx, int b, int view) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
@@ -457,6 +463,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                         case EW_INCELL: ew_incell_call(&P.ew, idx, b0, b1); break;
                         case EW_UPSAMPLE: ew_upsample_call(&P.ew, idx, b0, b1); break;
                         case EW_TRANSFORM: ew_transform_call<ND>(&P.ew, idx, b0); break;
+                        case EW_TOP3: ew_top3_call<ND>(&P.ew, idx, b0, P.view); break;
                         default: ew_compose_call<ND>(&P.ew, idx, b0, P.view); break;
                     }
                     break;

@@ -29,7 +29,7 @@
 
 namespace vf {
 
-enum EwOp { EW_SA3 = 0, EW_COND3, EW_INORM, EW_INCELL, EW_UPSAMPLE, EW_TRANSFORM, EW_COMPOSE };
+enum EwOp { EW_SA3 = 0, EW_COND3, EW_INORM, EW_INCELL, EW_UPSAMPLE, EW_TRANSFORM, EW_COMPOSE, EW_TOP3 };
 
 constexpr int kTransCh = 32;        // floats per pixel of the materialised compositing layers (21 used: 4 warps, previous, first, scratch)
 constexpr int kMaskCh = 8;          // floats per pixel of the mask logits (7 used)
@@ -66,6 +66,8 @@ struct NormParams {
     float *out; long long out_bs;           // INORM: normalised (may alias in); INCELL: h
     float *out2; int split;                 // INORM, split > 0: channels >= split go to out2 (both outputs `split` channels
                                             // per pixel: the two heads' hidden layers leave one fused conv)
+    float *tab;                             // INORM, non-null: statistics only - (scale, shift) of every channel -> tab[B][C][2];
+                                            // the consumer (EW_TOP3) normalises while staging
     float *cout; long long cout_bs;         // INCELL: new cell state (may alias cprev)
     int H, W, C, cpi, relu;
     float eps;
@@ -93,6 +95,12 @@ struct TopParams {
     float *out_distrib; long long out_distrib_bs;
     double *out_sums;
     int goal[kMaxDesig][2];                 // per-layer launches only (the persistent kernel takes them from its launch arguments)
+    // EW_TOP3 (the heads' second phase as ONE item per 8 x 16-pixel tile): the raw hidden layers of both heads and their
+    // instance-norm tables, the heads' output convs in the layout the VALU loops read
+    const float *hmhs_raw;                  // [B][HW][64]: hm 0..31 | hs 32..63
+    const float *norm_tab;                  // [B][64][2]: scale, shift
+    const float *w_scr, *b_scr;             // [9 taps][32][4], [4]
+    const float *w_msk, *b_msk;             // [9 taps][kT3MaskIn][8], [8]: input channels hm 0..31, layers 32..52, zeros beyond
 };
 
 struct EwParams {
@@ -110,6 +118,12 @@ struct EwParams {
 
 constexpr int kEwBatch = 4;         // pixels whose loads an element-wise item keeps in flight per thread
 constexpr int kEwLdsFloats = 20 * 20 * 8 + 25 * 4 + 16 + 2 * 4 * 8 * 32;   // largest: EW_TRANSFORM halo; reductions [4][8][32] doubles
+
+// dynamic LDS of an element-wise item (host + device)
+__host__ __device__ constexpr int top3_lds_floats(int nd);
+__host__ __device__ constexpr size_t ew_lds_bytes(const int op, const int nd) {
+    return (size_t)(op == EW_TOP3 ? top3_lds_floats(nd) : kEwLdsFloats) * 4 + 16;
+}
 
 // border class of coordinate y in an image of H rows: 0, 1 | 2 = interior | 3, 4   (H >= 4)
 __device__ __forceinline__ int cls5(const int y, const int H) { return y < 2 ? y : (y >= H - 2 ? y - (H - 5) : 2); }
@@ -291,6 +305,14 @@ __device__ __forceinline__ void inorm_item(const PT &p, const int b, const int g
     const double inv_n = 1.0 / (double)HW;
 #pragma unroll
     for (int j = 0; j < 4; ++j) in_scale_shift(st[j], st[4 + j], inv_n, p.eps, p.g0[c0 + j], p.b0[c0 + j], sc[j], sh[j]);
+    if (p.tab != nullptr) {             // statistics only: the consumer applies them
+        if (ps == 0) {
+            float *t = p.tab + ((long long)b * C + c0) * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t[2 * j] = sc[j]; t[2 * j + 1] = sh[j]; }
+        }
+        return;
+    }
     for (int px0 = ps; px0 < HW; px0 += kEwBatch * ppp) {
         f32x4 v[kEwBatch];
 #pragma unroll
@@ -669,6 +691,270 @@ __device__ __forceinline__ void compose_item(const PT &p, const int tile, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------ the heads' second phase, fused
+// One item per 8 x 16-pixel tile of one sample does what four phases did - scratch conv, the seven compositing layers, the
+// mask conv over [h_masks | layers], softmax + composition - without any of their tensors touching memory:
+//   1. hs = relu(IN(raw hs)) over the tile + 2 pixels (normalised while staging, statistics from EW_INORM's table), the
+//      previous frame / distributions over the tile + 3 pixels (symmetric padding), the sample's CDNA kernels;
+//   2. over the tile + 1 pixel (what the mask conv's 3 x 3 window reaches): scratch = sigmoid(conv3x3(hs)), the four warps,
+//      previous, first -> the 21 layer channels in LDS (zeros outside the image: the mask conv's zero padding); the warped
+//      distributions of the tile's own pixels;
+//   3. hm = relu(IN(raw hm)) over the tile + 1 pixel into the LDS hs occupied;
+//   4. mask logits = conv3x3([hm | layers]) on the VALU, two threads per pixel (taps 0-4 / 5-8), weights as scalar operands;
+//   5. softmax, next frame, next distributions, cost sums per 4 x 16 block (the layout of compose_item).
+// 7 x 9 x (32 + 21 + 32 x 3 / 7 ...) FMAs per pixel on the VALU is ~1 ms of the whole chip per C5 launch: the four phases it
+// replaces were bound by their 60 000+ items per step and four trips through memory, not by arithmetic.
+constexpr int kT3H = 8, kT3W = 16;
+constexpr int kT3R1H = kT3H + 2, kT3R1W = kT3W + 2, kT3R1 = kT3R1H * kT3R1W;    // 10 x 18: layers / hm
+constexpr int kT3R2H = kT3H + 4, kT3R2W = kT3W + 4, kT3R2 = kT3R2H * kT3R2W;    // 12 x 20: hs
+constexpr int kT3RPH = kT3H + 6, kT3RPW = kT3W + 6, kT3RP = kT3RPH * kT3RPW;    // 14 x 22: previous frame
+constexpr int kT3FeatPad = 36, kT3LayPad = 28, kT3MaskIn = 56;
+__host__ __device__ constexpr int top3_lds_floats(const int nd) {
+    return kT3R2 * kT3FeatPad + kT3R1 * kT3LayPad + kT3RP * comp_px_stride(nd) + kT3H * kT3W * kNumWarp3 * nd + kTaps * 4 + 128 + 8;
+}
+
+template <int ND, class PT>
+__device__ __forceinline__ void top3_item(const PT &p, const int tile, const int b, const int *goal, float *smem) {
+    constexpr int PS = comp_px_stride(ND);
+    typedef const __attribute__((address_space(4))) float cfloat;
+    float *s_a = smem;                                  // [kT3R2][36]: hs, later hm ([kT3R1][36])
+    float *s_t = s_a + kT3R2 * kT3FeatPad;              // [kT3R1][28]: the layers
+    float *s_p = s_t + kT3R1 * kT3LayPad;               // [kT3RP][PS]: previous frame + distributions; later the partial logits
+    float *s_wd = s_p + kT3RP * PS;                     // [128][4][ND]: warped distributions of the tile's pixels
+    float *s_kern = s_wd + kT3H * kT3W * kNumWarp3 * ND;
+    float *s_tab = s_kern + kTaps * 4;                  // [64][2]
+    float *s_ds = s_tab + 128;                          // [ND]
+    const int tid = threadIdx.x;
+    const int tilesX = (p.W + kT3W - 1) / kT3W;
+    const int nblocks = sum_blocks(p.H, p.W);
+    const int ty0 = (tile / tilesX) * kT3H, tx0 = (tile % tilesX) * kT3W;
+    const long long HW = (long long)p.H * p.W;
+    top_dscale(p, b, s_ds);
+    if (tid < kTaps * kNumWarp3) s_kern[tid] = p.kern[(long long)b * kTaps * kNumWarp3 + tid];
+    if (tid < 128) s_tab[tid] = p.norm_tab[(long long)b * 128 + tid];
+    __syncthreads();
+    // ---- 1. hs over R2 (normalised + relu, zeros outside the image), previous frame over RP (symmetric padding)
+    const float *raw = p.hmhs_raw + (long long)b * HW * 64;
+    for (int e = tid; e < kT3R2 * 8; e += kConvThreads) {
+        const int px = e >> 3, q = e & 7;
+        const int ry = px / kT3R2W, rx = px - ry * kT3R2W;
+        const int y = ty0 - 2 + ry, x = tx0 - 2 + rx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+            v = ld4(raw + ((long long)y * p.W + x) * 64 + 32 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], s_tab[2 * (32 + 4 * q + j)], s_tab[2 * (32 + 4 * q + j) + 1]), 0.f);
+        }
+        st4(s_a + px * kT3FeatPad + 4 * q, v);
+    }
+    {
+        const float *pf = p.prev_frame + (long long)b * p.prev_frame_bs;
+        const float *pd = p.prev_distrib + (long long)b * p.prev_distrib_bs;
+        for (int i = tid; i < kT3RP; i += kConvThreads) {
+            const int ly = i / kT3RPW, lx = i - ly * kT3RPW;
+            const int y = reflect_sym(ty0 - 3 + ly, p.H), x = reflect_sym(tx0 - 3 + lx, p.W);
+            const long long o = (long long)y * p.W + x;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s_p[i * PS + c] = pf[o * 3 + c];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) s_p[i * PS + 3 + d] = pd[o * ND + d] * s_ds[d];
+        }
+    }
+    __syncthreads();
+    // ---- 2. the layers over R1: one thread per pixel
+    if (tid < kT3R1) {
+        const int ry = tid / kT3R1W, rx = tid - ry * kT3R1W;
+        const int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
+        float t[24];
+#pragma unroll
+        for (int c = 0; c < 24; ++c) t[c] = 0.f;
+        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+            // scratch = sigmoid(conv3x3(hs) + b): R1 pixel (ry, rx) = R2 pixel (ry + 1, rx + 1); taps reach R2 (ry + dy, rx + dx)
+            cfloat *ws = (cfloat *)(unsigned long long)p.w_scr, *bs = (cfloat *)(unsigned long long)p.b_scr;
+            float a0 = bs[0], a1 = bs[1], a2 = bs[2];
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const float *ap = s_a + ((ry + dy) * kT3R2W + rx + dx) * kT3FeatPad;
+                cfloat *wt = ws + tap * 32 * 4;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f32x4 av = ld4(ap + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = 4 * q + e;
+                        a0 = fmaf(av[e], wt[c * 4 + 0], a0); a1 = fmaf(av[e], wt[c * 4 + 1], a1); a2 = fmaf(av[e], wt[c * 4 + 2], a2);
+                    }
+                }
+            }
+            t[18] = sigmoidf_(a0); t[19] = sigmoidf_(a1); t[20] = sigmoidf_(a2);
+            // warps of the previous frame (and, for the tile's own pixels, of the distributions): R1 (ry, rx) = RP (ry + 2, rx + 2)
+            const bool inner = ry >= 1 && ry <= kT3H && rx >= 1 && rx <= kT3W;
+            float wd[kNumWarp3][ND];
+#pragma unroll
+            for (int k = 0; k < kNumWarp3; ++k)
+#pragma unroll
+                for (int d = 0; d < ND; ++d) wd[k][d] = 0.f;
+#pragma unroll 1
+            for (int dy = 0; dy < kDnaKern; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < kDnaKern; ++dx) {
+                    const f32x4 kr = ld4(s_kern + (dy * kDnaKern + dx) * 4);
+                    const int sp = (ry + dy) * kT3RPW + rx + dx;
+                    const f32x4 a = ld4(s_p + sp * PS);
+                    float di[ND];
+                    di[0] = a[3];
+                    if constexpr (ND > 1) {
+                        const f32x4 c2 = ld4(s_p + sp * PS + 4);
+#pragma unroll
+                        for (int d = 1; d < ND; ++d) di[d] = c2[d - 1];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kNumWarp3; ++k) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) t[k * 3 + c] = fmaf(kr[k], a[c], t[k * 3 + c]);
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) wd[k][d] = fmaf(kr[k], di[d], wd[k][d]);
+                    }
+                }
+            const f32x4 ctr = ld4(s_p + ((ry + 2) * kT3RPW + rx + 2) * PS);
+            const long long o = (long long)y * p.W + x;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { t[12 + c] = ctr[c]; t[15 + c] = p.first_frame[o * 3 + c]; }
+            if (inner) {
+                float *wo = s_wd + ((ry - 1) * kT3W + rx - 1) * kNumWarp3 * ND;
+#pragma unroll
+                for (int k = 0; k < kNumWarp3; ++k)
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) wo[k * ND + d] = wd[k][d];
+            }
+        }
+        float *to = s_t + tid * kT3LayPad;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) st4(to + 4 * k, f32x4{t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]});
+    }
+    __syncthreads();
+    // ---- 3. hm over R1 into the LDS hs occupied
+    for (int e = tid; e < kT3R1 * 8; e += kConvThreads) {
+        const int px = e >> 3, q = e & 7;
+        const int ry = px / kT3R1W, rx = px - ry * kT3R1W;
+        const int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+            v = ld4(raw + ((long long)y * p.W + x) * 64 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], s_tab[2 * (4 * q + j)], s_tab[2 * (4 * q + j) + 1]), 0.f);
+        }
+        st4(s_a + px * kT3FeatPad + 4 * q, v);
+    }
+    __syncthreads();
+    // ---- 4. mask logits: pixel = tid % 128, taps 0 - 4 (waves 0, 1) / 5 - 8 (waves 2, 3)
+    const int px = tid & 127, half = tid >> 7;
+    const int iy = px >> 4, ix = px & 15;
+    float m[7];
+    {
+        cfloat *wm = (cfloat *)(unsigned long long)p.w_msk, *bm = (cfloat *)(unsigned long long)p.b_msk;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) m[j] = half == 0 ? bm[j] : 0.f;
+        const int t0 = half == 0 ? 0 : 5, t1 = half == 0 ? 5 : 9;
+        for (int tap = t0; tap < t1; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int r1 = (iy + dy) * kT3R1W + ix + dx;
+            const float *ap = s_a + r1 * kT3FeatPad, *lp = s_t + r1 * kT3LayPad;
+            cfloat *wt = wm + tap * kT3MaskIn * 8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 av = ld4(ap + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) m[j] = fmaf(av[e], wt[(4 * q + e) * 8 + j], m[j]);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const f32x4 lv = ld4(lp + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * q + e >= 21) continue;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) m[j] = fmaf(lv[e], wt[(32 + 4 * q + e) * 8 + j], m[j]);
+                }
+            }
+        }
+    }
+    float *s_part = s_p;                // (the previous-frame halo is no longer read)
+    if (half == 1) {
+        st4(s_part + px * 8, f32x4{m[0], m[1], m[2], m[3]});
+        st4(s_part + px * 8 + 4, f32x4{m[4], m[5], m[6], 0.f});
+    }
+    __syncthreads();
+    // ---- 5. softmax, composition, cost sums: thread t < 128 = pixel (t / 16, t % 16); wave = one 4 x 16 block
+    double cost[2 * ND];
+#pragma unroll
+    for (int i = 0; i < 2 * ND; ++i) cost[i] = 0.0;
+    const int y = ty0 + iy, x = tx0 + ix;
+    if (half == 0 && y < p.H && x < p.W) {
+        const f32x4 q0 = ld4(s_part + px * 8), q1 = ld4(s_part + px * 8 + 4);
+        m[0] += q0[0]; m[1] += q0[1]; m[2] += q0[2]; m[3] += q0[3]; m[4] += q1[0]; m[5] += q1[1]; m[6] += q1[2];
+        float mx = m[0];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) mx = fmaxf(mx, m[j]);
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { m[j] = __expf(m[j] - mx); den += m[j]; }
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) m[j] *= inv;
+        const float *lp = s_t + ((iy + 1) * kT3R1W + ix + 1) * kT3LayPad;
+        float t[24];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const f32x4 v = ld4(lp + 4 * k);
+            t[4 * k] = v[0]; t[4 * k + 1] = v[1]; t[4 * k + 2] = v[2]; t[4 * k + 3] = v[3];
+        }
+        const long long o = (long long)y * p.W + x;
+        float *fo = p.out_frame + (long long)b * p.out_frame_bs + o * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a = m[0] * t[c];
+#pragma unroll
+            for (int j = 1; j < 7; ++j) a = fmaf(m[j], t[3 * j + c], a);
+            fo[c] = a;
+        }
+        const float *wd = s_wd + px * kNumWarp3 * ND;
+        const float *pd = p.prev_distrib + (long long)b * p.prev_distrib_bs + o * ND;
+        float *dout = p.out_distrib + (long long)b * p.out_distrib_bs + o * ND;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const float prev = pd[d] * s_ds[d];
+            float a = m[0] * wd[d];
+#pragma unroll
+            for (int k = 1; k < kNumWarp3; ++k) a = fmaf(m[k], wd[k * ND + d], a);
+            a = fmaf(m[4], prev, a);
+            a = fmaf(m[5], p.first_distrib[o * ND + d], a);
+            a = fmaf(m[6], prev, a);
+            dout[d] = a;
+            const float ry = (float)(y - goal[2 * d]), rx = (float)(x - goal[2 * d + 1]);
+            const float dist = sqrtf(fmaf(ry, ry, rx * rx));
+            cost[2 * d] = (double)a;
+            cost[2 * d + 1] = (double)a * (double)dist;
+        }
+    }
+    if (half == 0) {
+#pragma unroll
+        for (int i = 0; i < 2 * ND; ++i) cost[i] = wave_sum(cost[i]);
+        const int lane = tid & 63, wave = tid >> 6;
+        const int by = ty0 / kSumBlockH + wave, bxk = tx0 / kSumBlockW;
+        if (lane == 0 && by * kSumBlockH < p.H && tx0 < p.W) {
+            const int blk = by * sum_blocks_x(p.W) + bxk;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                double *dst = p.out_sums + (((long long)b * ND + d) * nblocks + blk) * 2;
+                dst[0] = cost[2 * d]; dst[1] = cost[2 * d + 1];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ dispatch of one item
 // `idx` = item index within its sample (spi == 0) / ignored (spi > 0: the item covers samples [b0, b1)); goal = this view's
 // goal pixels (EW_COMPOSE)
@@ -685,6 +971,7 @@ __device__ __forceinline__ void ew_item(const PT &p, const int idx, const int b0
         case EW_INCELL: incell_item(p.norm, b0, idx, smem); break;
         case EW_UPSAMPLE: upsample_item(p.up, b0, idx); break;
         case EW_TRANSFORM: transform_item<ND>(p.top, idx, b0, smem); break;
+        case EW_TOP3: top3_item<ND>(p.top, idx, b0, goal, smem); break;
         default: compose_item<ND>(p.top, idx, b0, goal, smem); break;
     }
 }
@@ -692,7 +979,7 @@ __device__ __forceinline__ void ew_item(const PT &p, const int idx, const int b0
 // per-layer launch: one workgroup per item
 template <int ND>
 VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads) void ew_kernel(const EwParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[kEwLdsFloats];
+    extern __shared__ __attribute__((aligned(16))) float smem[];        // ew_lds_bytes(op, ND) of dynamic LDS
     const int item = blockIdx.x;
     int b0, b1, idx = 0;
     if (p.spi > 0) { b0 = item * p.spi; b1 = min(b0 + p.spi, p.B); }
