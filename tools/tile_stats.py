@@ -11,14 +11,20 @@ import numpy as np
 from visual_foresight_amd import _lib
 from visual_foresight_amd.video_prediction.hip_predictor import HipVPredEvaluation
 
-M, T = int(sys.argv[1]) if len(sys.argv) > 1 else 200, 13
+# usage: tile_stats.py [M [precision [H [arch [T]]]]]
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 prec = sys.argv[2] if len(sys.argv) > 2 else 'fp32'
-pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2, precision=prec)).restore()
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+arch = sys.argv[4] if len(sys.argv) > 4 else 'cdna'
+T = int(sys.argv[5]) if len(sys.argv) > 5 else 13
+adim = 12 if arch in ('savp', 'savp2') else 4
+pred = HipVPredEvaluation('', dict(designated_pixel_count=1, run_batch_size=M, sequence_length=T + 2, precision=prec,
+                                   image_height=H, image_width=H, arch=arch, adim=adim)).restore()
 rs = np.random.RandomState(0)
-d = np.zeros((2, 1, 64, 64, 1), np.float32); d[:, 0, 32, 32, 0] = 1
-ctx = {'context_frames': rs.randint(0, 256, (2, 1, 64, 64, 3)).astype(np.uint8), 'context_actions': np.zeros((1, 4)),
+d = np.zeros((2, 1, H, H, 1), np.float32); d[:, 0, H // 2, H // 2, 0] = 1
+ctx = {'context_frames': rs.randint(0, 256, (2, 1, H, H, 3)).astype(np.uint8), 'context_actions': np.zeros((1, adim)),
        'context_states': np.zeros((2, 5)), 'context_pixel_distributions': d}
-acts = rs.normal(0, 0.05, (M, T, 4))
+acts = rs.normal(0, 0.05, (M, T, adim))
 lib = _lib.load_library()
 lib.vf_debug_tile_clocks.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int32]
 buf = (ctypes.c_uint64 * 256)()

@@ -15,7 +15,7 @@ REPO = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get('VF_LIBRARY') or os.path.join(_HERE, 'libvf_hip.so')     # override: experiments only
 SOURCES = [os.path.join(_HERE, 'csrc', f) for f in
            ('vf_engine.hip', 'vf_conv_mfma.h', 'vf_conv_gsplit.h', 'vf_small_kernels.h', 'vf_persistent.h',
-            'vf_conv_bf16x6.h', 'vf_fused_top.h', 'vf_fc_tile.h', 'vf_savp3.h', 'vf_engine_savp3.inc')] + \
+            'vf_conv_bf16x6.h', 'vf_fused_top.h', 'vf_fc_tile.h', 'vf_conv_first.h', 'vf_savp3.h', 'vf_engine_savp3.inc')] + \
           [os.path.join(REPO, 'include', 'vf_hip.h')]
 
 # every symbol include/vf_hip.h declares

@@ -218,6 +218,8 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
     int mrep;                       // MFMA row blocks per wave: the workgroup covers 128 * mrep rows;
                                     // 0 / -1 = the 64- / 32-row conv-LSTM tiles (waves split rows x gates)
     int prec = 0;                   // 1: split-bf16 tile (conv-LSTM only)
+    bool first_valu = false;        // the 5 x 5 / 2 conv on the 3-channel frame as a vector-ALU tile (vf_conv_first.h; mrep 8):
+                                    // 16 x 16 output pixels per item, canonical [tap][channel][Cout] weights
     bool gs_v2 = false;              // ... in its final form (vf_conv_gsplit.h: one rolling weight register set)
     bool gsplit = false;            // 128-row fp32 conv-LSTM tile with 32-channel chunks: the gate-split tile (wave w =
                                     // gate w of all four row blocks, weights from L2 into registers, no barrier per tap)
@@ -229,6 +231,7 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
     int stats_nparts;               // partial sums this layer's epilogue writes per sample
     size_t lds_bytes;
     size_t packed_w() const {       // floats of the packed fp32 weights (pack_weights)
+        if (first_valu) return (size_t)KH * KW * segC[0] * Cout;
         return (size_t)(nchunk[0] + nchunk[1]) * KH * KW * (KC / 8) * 2 * ((size_t)ncg * G * 32) * 4;
     }
     size_t packed_w16() const {     // bf16 values of the 3-plane split weights (pack_weights_bf16x3)
@@ -682,6 +685,21 @@ static void init_layer(ConvLayer &l, const char *name, PackMode mode, int Hin, i
     l.nsplit = 1; l.n_valid = Cout;
     plan_geometry(l, stats, fc);
     l.chunks_per_split = l.nchunk[0] + l.nchunk[1];
+    // the first conv of the encoder (3-channel frame in, exact statistics out): one thread per output pixel on the vector
+    // ALUs instead of a K = 75 GEMM padded to 200 on the matrix pipe (vf_conv_first.h)
+    bool first = mode == PACK_PLAIN && !fc && stats && l.nseg == 1 && c0 == vf::kFirstCin && KH == vf::kFirstK &&
+                 KW == vf::kFirstK && stride == vf::kFirstStride && prec == 0 && (Cout == 16 || Cout == 32);
+#ifdef VF_DEBUG_KNOBS
+    if (const char *e = getenv("VF_FIRST_VALU")) first = first && atoi(e) != 0;
+#endif
+    if (first) {
+        l.first_valu = true; l.mrep = 8;
+        l.TW = std::min(Wout, 16); l.TH = std::min(Hout, vf::kConvThreads / l.TW);
+        l.tilesX = (Wout + l.TW - 1) / l.TW; l.tilesY = (Hout + l.TH - 1) / l.TH;
+        l.NI = 1; l.RPI = l.TH * l.TW;
+        l.stats_nparts = l.tilesY * l.tilesX;
+        l.lds_bytes = vf::first_lds_floats(l.TH, l.TW) * 4 + 64;
+    }
 }
 
 // every kernel instance may be asked for up to h->max_lds bytes of dynamic LDS; the attribute is
@@ -1243,6 +1261,9 @@ int vf_load_weights(vf_handle *h, const float *blob_all, size_t n_floats) {
                 // only the enc2 rows go through the GEMM; the action/state rows become a per-sample bias
                 wp = pack_weights(l, blob + w->offset, 1, 1, w->shape[2], w->shape[3]);
                 bp = pack_bias(l, blob + b->offset);
+            } else if (l.first_valu) {      // canonical [5][5][3][Cout] as it is
+                wp.assign(blob + w->offset, blob + w->offset + w->size());
+                bp = pack_bias(l, blob + b->offset);
             } else {
                 wp = pack_weights(l, blob + w->offset, w->shape[0], w->shape[1], w->shape[2], w->shape[3]);
                 bp = pack_bias(l, blob + b->offset);
@@ -1422,7 +1443,15 @@ struct LaunchSink {
                 return r;
             }
             case PH_CONV_RELU: return launch_conv_t<1, EPI_BIAS_RELU>(l, p, st);
-            case PH_CONV_RAW: return launch_conv_t<1, EPI_RAW_STATS>(l, p, st);
+            case PH_CONV_RAW:
+                if (l.first_valu) {
+                    const dim3 grid(p.B * l.tilesY * l.tilesX);
+                    if (l.Cout == 16) hipLaunchKernelGGL(conv_first_kernel<16>, grid, dim3(kConvThreads), l.lds_bytes, st, p);
+                    else hipLaunchKernelGGL(conv_first_kernel<32>, grid, dim3(kConvThreads), l.lds_bytes, st, p);
+                    VF_HIP_CHECK(hipGetLastError());
+                    return VF_OK;
+                }
+                return launch_conv_t<1, EPI_RAW_STATS>(l, p, st);
             case PH_CONVT_RELU: return launch_conv_t<4, EPI_CONVT_RELU>(l, p, st);
             case PH_CONVT_RAW: return launch_conv_t<4, EPI_CONVT_RAW_STATS>(l, p, st);
             case PH_CONV_RAW3: return l.mrep == 2 ? launch_conv_m<1, EPI_RAW, 2>(l, p, st) : launch_conv_m<1, EPI_RAW, 1>(l, p, st);
@@ -1996,8 +2025,9 @@ static bool wt_epilogue(const PhaseDesc &P) {
         case PH_LSTM:           // gate-split 128- / 64-row tiles and the 32-row tile (lstm_gsplit_epilogue), exact fp32
             return P.prec == 0 && (P.mrep == 6 || P.mrep == 5 || P.mrep == -1);
         case PH_CONV_RELU: case PH_CONV_RAW: case PH_CONVT_RELU: case PH_CONVT_RAW:
-            // conv_epilogue's vectorised form: one row block per wave, whole channel quads
-            return (VF_WT_DEFAULT & 2) != 0 && P.mrep == 1 && P.conv.Cout % 4 == 0;
+            // conv_epilogue's vectorised form: one row block per wave, whole channel quads; the vector-ALU first conv
+            // (mrep 8, vf_conv_first.h: Cout / 4 16-byte stores per pixel + an atomic-store partial)
+            return (VF_WT_DEFAULT & 2) != 0 && (P.mrep == 1 || (P.type == PH_CONV_RAW && P.mrep == 8)) && P.conv.Cout % 4 == 0;
         case PH_CONV_RAW3: case PH_CONV_RAW3G2:     // EPI_RAW is vectorised for one and two row blocks per wave
             return (VF_WT_DEFAULT & 2) != 0 && (P.mrep == 1 || P.mrep == 2) && P.conv.Cout % 4 == 0;
         case PH_GATES_RAW:      // gates_raw_epilogue: sixteen 16-byte stores per lane, nothing else
@@ -2162,7 +2192,8 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
         // a write-through item must be one whose every store is a 16-byte sc1 store (restated here, not read from wt_epilogue)
         if (P.conv.wt_out != 0) {
             const bool lstm_vec = P.type == PH_LSTM && P.prec == 0 && (P.mrep == 6 || P.mrep == 5 || P.mrep == -1);
-            const bool light_vec = P.type >= PH_CONV_RELU && P.type <= PH_CONVT_RAW && P.mrep == 1 && P.conv.Cout % 4 == 0;
+            const bool light_vec = P.type >= PH_CONV_RELU && P.type <= PH_CONVT_RAW && P.conv.Cout % 4 == 0 &&
+                                   (P.mrep == 1 || (P.mrep == 8 && P.type == PH_CONV_RAW && (P.conv.Cout == 16 || P.conv.Cout == 32)));
             const bool raw3_vec = (P.type == PH_CONV_RAW3 || P.type == PH_CONV_RAW3G2) && (P.mrep == 1 || P.mrep == 2) && P.conv.Cout % 4 == 0;
             if (!(lstm_vec || light_vec || raw3_vec || P.type == PH_GATES_RAW))
                 return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": write-through publish on a tile with plain stores");

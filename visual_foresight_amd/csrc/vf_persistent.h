@@ -23,6 +23,7 @@
 #include "vf_conv_gsplit.h"
 #include "vf_fused_top.h"
 #include "vf_fc_tile.h"
+#include "vf_conv_first.h"
 #include "vf_savp3.h"
 
 namespace vf {
@@ -187,6 +188,10 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void lstm_gsplit
 template <int MREP>
 static __device__ __noinline__ __attribute__((not_tail_called)) void lstm_bf16x6_tile_call(const ConvParams *p, int bx, int by) {
     conv_lstm_bf16x6_tile<MREP>(const_params(p), bx, by, tile_lds());
+}
+template <int CO>
+static __device__ __noinline__ __attribute__((not_tail_called)) void conv_first_tile_call(const ConvParams *p, int bx) {
+    conv_first_tile<CO>(const_params(p), bx, tile_lds());
 }
 static __device__ __noinline__ __attribute__((not_tail_called)) void fc_wide_tile_call(const ConvParams *p, int bx, int bz) {
     fc_wide_tile(const_params(p), bx, bz, tile_lds());
@@ -421,7 +426,11 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                     else conv_tile_call<4, EPI_LSTM, 1>(&P.conv, bx, by, 0);
                     break;
                 case PH_CONV_RELU: conv_tile_call<1, EPI_BIAS_RELU, 1>(&P.conv, bx, by, 0); break;
-                case PH_CONV_RAW: conv_tile_call<1, EPI_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
+                case PH_CONV_RAW:
+                    // (mrep 8: the first conv of the encoder - 3-channel frame, 5 x 5 / 2 - on the vector ALUs, vf_conv_first.h)
+                    if (P.mrep == 8) { if (P.conv.Cout == 16) conv_first_tile_call<16>(&P.conv, bx); else conv_first_tile_call<32>(&P.conv, bx); }
+                    else conv_tile_call<1, EPI_RAW_STATS, 1>(&P.conv, bx, by, 0);
+                    break;
                 case PH_CONVT_RELU: conv_tile_call<4, EPI_CONVT_RELU, 1>(&P.conv, bx, by, 0); break;
                 case PH_CONVT_RAW: conv_tile_call<4, EPI_CONVT_RAW_STATS, 1>(&P.conv, bx, by, 0); break;
                 case PH_FC_PARTIAL:

@@ -180,51 +180,59 @@ __device__ __forceinline__ void cond3_item(const PT &p, const int b0, const int 
         sv[t] = (s < ns && c < nc) ? p.condvec[(long long)(b0 + s) * nc + c] : 0.f;
     }
     __syncthreads();
+    // all four samples of the item per pass over the layer's conditioning weights (they are the item's memory traffic: up to
+    // 2.5 MB per layer), eight weight loads in flight per thread
+    static_assert(kCond3PerItem == 4, "cond3_item: four samples per pass");
     for (int col = t; col < p.Ctot; col += 256) {
-        for (int s0 = 0; s0 < ns; s0 += 2) {
-            float acc[2][25];
+        float acc[4][25];
 #pragma unroll
-            for (int i = 0; i < 25; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-            for (int ty = 0; ty < KH; ++ty) {
-                float tt[2][6];
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 25; ++i) acc[s][i] = 0.f;
+        for (int ty = 0; ty < KH; ++ty) {
+            float tt[4][6];
+#pragma unroll
+            for (int tx = 0; tx < 6; ++tx) {
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+                if (tx < KH) {
+                    const float *wp = p.w + ((long long)(ty * KH + tx) * nc) * p.Ctot + col;
+                    for (int c0 = 0; c0 < nc; c0 += 8) {
+                        float w[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) w[j] = c0 + j < nc ? wp[(long long)(c0 + j) * p.Ctot] : 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) a[s] = fmaf(sv[s * 32 + c0 + j], w[j], a[s]);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) tt[s][tx] = a[s];
+            }
+            float fy[5];
+#pragma unroll
+            for (int ry = 0; ry < 5; ++ry) fy[ry] = p.f[ry][ty];
+#pragma unroll
+            for (int rx = 0; rx < 5; ++rx) {
+                float r[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int tx = 0; tx < 6; ++tx) {
-                    float a0 = 0.f, a1 = 0.f;
-                    if (tx < KH) {
-                        const float *wp = p.w + ((long long)(ty * KH + tx) * nc) * p.Ctot + col;
-                        for (int c = 0; c < nc; ++c) {
-                            const float w = wp[(long long)c * p.Ctot];
-                            a0 = fmaf(sv[s0 * 32 + c], w, a0);
-                            a1 = fmaf(sv[(s0 + 1) * 32 + c], w, a1);
-                        }
-                    }
-                    tt[0][tx] = a0; tt[1][tx] = a1;
+                    const float fx = p.f[rx][tx];       // (zero beyond the kernel)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) r[s] = fmaf(fx, tt[s][tx], r[s]);
                 }
-                float fy[5];
 #pragma unroll
-                for (int ry = 0; ry < 5; ++ry) fy[ry] = p.f[ry][ty];
+                for (int ry = 0; ry < 5; ++ry)
 #pragma unroll
-                for (int rx = 0; rx < 5; ++rx) {
-                    float r0 = 0.f, r1 = 0.f;
-#pragma unroll
-                    for (int tx = 0; tx < 6; ++tx) {
-                        const float fx = p.f[rx][tx];       // (zero beyond the kernel)
-                        r0 = fmaf(fx, tt[0][tx], r0); r1 = fmaf(fx, tt[1][tx], r1);
-                    }
-#pragma unroll
-                    for (int ry = 0; ry < 5; ++ry) {
-                        acc[0][ry * 5 + rx] = fmaf(fy[ry], r0, acc[0][ry * 5 + rx]);
-                        acc[1][ry * 5 + rx] = fmaf(fy[ry], r1, acc[1][ry * 5 + rx]);
-                    }
-                }
+                    for (int s = 0; s < 4; ++s) acc[s][ry * 5 + rx] = fmaf(fy[ry], r[s], acc[s][ry * 5 + rx]);
             }
+        }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (s0 + s >= ns) break;
-                float *o = p.out + (long long)(b0 + s0 + s) * 25 * p.Ctot + col;
+        for (int s = 0; s < 4; ++s) {
+            if (s >= ns) break;
+            float *o = p.out + (long long)(b0 + s) * 25 * p.Ctot + col;
 #pragma unroll
-                for (int i = 0; i < 25; ++i) o[(long long)i * p.Ctot] = acc[s][i];
-            }
+            for (int i = 0; i < 25; ++i) o[(long long)i * p.Ctot] = acc[s][i];
         }
     }
 }
