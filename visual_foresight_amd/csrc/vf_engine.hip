@@ -243,8 +243,10 @@ struct ConvLayer {          // geometry only: shared by every view; the packed w
 // can the top transposed conv `l` be fused with the compositing (vf_fused_top.h)?  One image and one channel
 // group per tile, an output region of whole 4 x 16 cost-sum blocks, and the LDS of the fused epilogue
 static bool top_fusable(const ConvLayer &l, int ND) {
+    // (whole 4 x 16 cost-sum blocks in the image too: the fused epilogue stores a block row as 16-byte pieces)
     return l.NI == 1 && l.ncg == 1 && l.Cout == 32 && l.nsplit == 1 && l.TH * l.TW <= 128 &&
            (2 * l.TH) % kSumBlockH == 0 && (2 * l.TW) % kSumBlockW == 0 &&
+           (2 * l.Hout) % kSumBlockH == 0 && (2 * l.Wout) % kSumBlockW == 0 &&
            fused_top_lds_floats(l.TH, l.TW, ND) * 4 <= 78 * 1024;
 }
 
@@ -2032,6 +2034,8 @@ static bool wt_epilogue(const PhaseDesc &P) {
             return (VF_WT_DEFAULT & 2) != 0 && (P.mrep == 1 || P.mrep == 2) && P.conv.Cout % 4 == 0;
         case PH_GATES_RAW:      // gates_raw_epilogue: sixteen 16-byte stores per lane, nothing else
             return true;
+        case PH_TOP_FUSED:      // fused_top_body: blocks turned over in LDS into 16-byte stores, partials and sums as atomic stores
+            return (VF_WT_DEFAULT & 2) != 0;
         default:
             return false;
     }
@@ -2119,7 +2123,7 @@ static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &
         }
     }
     for (PhaseDesc &P : out.phases)
-        if (ph_is_conv(P.type)) P.conv.wt_out = (h->wt_publish && wt_epilogue(P)) ? 1 : 0;
+        if (ph_is_conv(P.type) || P.type == PH_TOP_FUSED) P.conv.wt_out = (h->wt_publish && wt_epilogue(P)) ? 1 : 0;
     out.counters = counters;
     const size_t comp_lds[kMaxDesig] = {(size_t)composite_lds_floats<1, 10>() * 4, (size_t)composite_lds_floats<2, 10>() * 4,
                                         (size_t)composite_lds_floats<3, 10>() * 4, (size_t)composite_lds_floats<4, 10>() * 4};
@@ -2195,7 +2199,7 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
             const bool light_vec = P.type >= PH_CONV_RELU && P.type <= PH_CONVT_RAW && P.conv.Cout % 4 == 0 &&
                                    (P.mrep == 1 || (P.mrep == 8 && P.type == PH_CONV_RAW && (P.conv.Cout == 16 || P.conv.Cout == 32)));
             const bool raw3_vec = (P.type == PH_CONV_RAW3 || P.type == PH_CONV_RAW3G2) && (P.mrep == 1 || P.mrep == 2) && P.conv.Cout % 4 == 0;
-            if (!(lstm_vec || light_vec || raw3_vec || P.type == PH_GATES_RAW))
+            if (!(lstm_vec || light_vec || raw3_vec || P.type == PH_GATES_RAW || P.type == PH_TOP_FUSED))
                 return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": write-through publish on a tile with plain stores");
         }
         if (P.type == PH_TOP_FUSED && (P.aux_base != P.cnt_base + P.B || P.aux_base + P.B > bs.counters))

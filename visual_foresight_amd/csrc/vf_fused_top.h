@@ -4,7 +4,7 @@
 // transposed conv and read back by the compositing tiles: 1 - 4 MB per sample-step of HBM traffic and two items
 // with their fixed costs.  Fused, one item = one transposed-conv tile (128 input pixels -> 512 output pixels):
 //   1. the K loop of conv_tile<4, EPI_CONVT_FUSED> leaves the tile in the accumulators;
-//   2. bias, the tile's exact LayerNorm partial (integers), published with a release + a per-sample counter;
+//   2. bias, the tile's exact LayerNorm partial (integers), published as write-through atomic stores + a per-sample counter;
 //   3. the haloed previous frame / distributions of the tile's output region and the sample's CDNA kernels go to LDS;
 //   4. the item WAITS until the sample's other tiles have published their partials (they are adjacent tickets of the
 //      same queue, drawn within microseconds of each other): LayerNorm needs the statistics of the whole image;
@@ -89,8 +89,12 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
         long long su = 0, sq = 0;
         for (int w = 0; w < 4; ++w) { su += red[2 * w]; sq += red[2 * w + 1]; }
         long long *dst = p.stats + ((long long)b * p.stats_nparts + tile_id) * 2;
-        dst[0] = su; dst[1] = sq;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // The partial is the only thing the mates need from this tile: it leaves as two agent-scope atomic (write-through)
+        // stores, drained before the counter is bumped - no release fence, which would write back whatever the other
+        // workgroups of this XCD have dirtied in L2 (the frames of their compose passes) for 1.7 - 6.5 us (CDNA guide,
+        // section 6 G16, recipe R1; the mates read the partials with agent-scope atomic loads)
+        __hip_atomic_store(dst, su, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(p.fuse_ready + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -255,18 +259,65 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
         double cost[2 * ND];
 #pragma unroll
         for (int i = 0; i < 2 * ND; ++i) cost[i] = 0.0;
+        float of[3] = {0.f, 0.f, 0.f}, od[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) od[d] = 0.f;
         if (valid)
-            composite_pixel<ND, K, FIRST>(c, b, y, x, &s_enc[tid * kCompEncPad], mean, rstd, s_px, s_kern, HW_,
-                                          hy, hx, goal, cost);
+            composite_pixel_values<ND, K, FIRST>(c, y, x, &s_enc[tid * kCompEncPad], mean, rstd, s_px, s_kern, HW_,
+                                                 hy, hx, goal, cost, of, od);
+        const int y_blk = oy0 + byl * kSumBlockH, x_blk = ox0 + bxl * kSumBlockW;
+        const bool blk_ok = blk < nblk && y_blk < c.H && x_blk < c.W;
+        // The block's 64 pixels leave as whole 16-byte pieces: the wave turns them over in its own 64 feature rows (dead now:
+        // every lane has its pixel) - a block row is 16 pixels = 48 consecutive floats of the frame and 16 ND of the
+        // distributions (top_fusable: whole blocks only, rows 16-byte aligned) - so that a lane has ONE frame store instead
+        // of three 4-byte ones, and the stores can be sc1 (ConvParams::wt_out: the item then publishes without a release
+        // fence, which would write back whatever the XCD's L2 holds dirty; 4-byte sc1 stores would cost six times as much per
+        // byte).  Same values.
+        {
+            float *slab = s_enc + (wave * 64) * kCompEncPad;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) slab[lane * 3 + ch] = of[ch];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) slab[192 + lane * ND + d] = od[d];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool wt = p.wt_out != 0;
+            const unsigned fr_bytes = (unsigned)(c.H * c.W * 3) * 4u, di_bytes = (unsigned)(c.H * c.W * ND) * 4u;
+            const __amdgpu_buffer_rsrc_t r_fr = __builtin_amdgcn_make_buffer_rsrc(
+                c.out_frame + (long long)b * c.out_frame_bstride, 0, blk_ok ? (int)fr_bytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_di = __builtin_amdgcn_make_buffer_rsrc(
+                c.out_distrib + (long long)b * c.out_distrib_bstride, 0, blk_ok ? (int)di_bytes : 0, 0x00020000);
+            if (lane < 48) {
+                const int row = lane / 12, q = lane - row * 12;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(slab + row * 48 + 4 * q);
+                const unsigned off = (unsigned)(((y_blk + row) * c.W + x_blk) * 3 + 4 * q) * 4u;
+                if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r_fr, off, 0, 16);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r_fr, off, 0, 0);
+            }
+            for (int j = lane; j < 16 * ND; j += 64) {
+                const int row = j / (4 * ND), q = j - row * (4 * ND);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(slab + 192 + row * 16 * ND + 4 * q);
+                const unsigned off = (unsigned)(((y_blk + row) * c.W + x_blk) * ND + 4 * q) * 4u;
+                if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r_di, off, 0, 16);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r_di, off, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 2 * ND; ++i) cost[i] = wave_sum(cost[i]);
-        const int y_blk = oy0 + byl * kSumBlockH, x_blk = ox0 + bxl * kSumBlockW;
-        if (lane == 0 && blk < nblk && y_blk < c.H && x_blk < c.W) {
+        if (lane == 0 && blk_ok) {
             const int gblk = (y_blk / kSumBlockH) * sum_blocks_x(c.W) + x_blk / kSumBlockW;
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 double *dst = c.out_sums + (((long long)b * ND + d) * nblocks + gblk) * 2;
-                dst[0] = cost[2 * d]; dst[1] = cost[2 * d + 1];
+                if (p.wt_out != 0) {
+                    __hip_atomic_store(dst, cost[2 * d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, cost[2 * d + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    dst[0] = cost[2 * d]; dst[1] = cost[2 * d + 1];
+                }
             }
         }
     }

@@ -495,7 +495,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
         if (wave == 0) {
             // write-through items (ConvParams::wt_out: every global store of the tile was an sc1 / atomic store, drained
             // above by every wave) need no L2 write-back in front of their counters - CDNA guide section 6 G16, recipe R1
-            if (lane == 0 && !(ph_is_conv(P.type) && P.conv.wt_out != 0)) {
+            if (lane == 0 && !((ph_is_conv(P.type) || P.type == PH_TOP_FUSED) && P.conv.wt_out != 0)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }

@@ -288,6 +288,11 @@ template <int ND, int K, bool FIRST, class PT>
 __device__ __forceinline__ void composite_finish(const PT &p, const int b, const int y, const int x, float (&o_rgb)[3],
                                                  float (&o_m)[K + 1], const float *s_px, const float *s_kern, const int halo_w,
                                                  const int hy, const int hx, const int *goal, double (&cost)[2 * ND]);
+template <int ND, int K, bool FIRST, class PT>
+__device__ __forceinline__ void composite_values(const PT &p, const int y, const int x, float (&o_rgb)[3],
+                                                 float (&o_m)[K + 1], const float *s_px, const float *s_kern, const int halo_w,
+                                                 const int hy, const int hx, const int *goal, double (&cost)[2 * ND],
+                                                 float (&of)[3], float (&od)[ND]);
 
 // One output pixel (y, x) of sample b: LN + relu of its 32 features (a row of the LDS feature tile), the two 1x1
 // heads, softmax, the effective 5x5 flow kernel over the haloed previous frame / distributions in LDS
@@ -306,12 +311,40 @@ __device__ __forceinline__ void composite_pixel(const PT &p, const int b, const 
     composite_heads<K>(p, feat, mean, rstd, 0, o_rgb, o_m);
     composite_finish<ND, K, FIRST>(p, b, y, x, o_rgb, o_m, s_px, s_kern, halo_w, hy, hx, goal, cost);
 }
+// ... its next-frame pixel and distributions returned instead of stored (the fused top turns a block over in LDS and
+// stores whole 16-byte pieces write-through: vf_fused_top.h) - the same expressions, the same bits
+template <int ND, int K, bool FIRST, class PT>
+__device__ __forceinline__ void composite_pixel_values(const PT &p, const int y, const int x, const float *feat,
+                                                       const float mean, const float rstd, const float *s_px,
+                                                       const float *s_kern, const int halo_w, const int hy, const int hx,
+                                                       const int *goal, double (&cost)[2 * ND], float (&of)[3], float (&od)[ND]) {
+    constexpr int NM = K + 1;
+    float o_rgb[3], o_m[NM];
+    composite_head_bias<K>(p, o_rgb, o_m);
+    composite_heads<K>(p, feat, mean, rstd, 0, o_rgb, o_m);
+    composite_values<ND, K, FIRST>(p, y, x, o_rgb, o_m, s_px, s_kern, halo_w, hy, hx, goal, cost, of, od);
+}
 
 // the part of a pixel behind its head outputs: softmax, effective flow kernel, next frame / distributions, cost terms
 template <int ND, int K, bool FIRST, class PT>
 __device__ __forceinline__ void composite_finish(const PT &p, const int b, const int y, const int x, float (&o_rgb)[3],
                                                  float (&o_m)[K + 1], const float *s_px, const float *s_kern, const int halo_w,
                                                  const int hy, const int hx, const int *goal, double (&cost)[2 * ND]) {
+    float of[3], od[ND];
+    composite_values<ND, K, FIRST>(p, y, x, o_rgb, o_m, s_px, s_kern, halo_w, hy, hx, goal, cost, of, od);
+    const long long o = (long long)y * p.W + x;
+    float *fo = p.out_frame + (long long)b * p.out_frame_bstride + o * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) fo[c] = of[c];
+    float *dout = p.out_distrib + (long long)b * p.out_distrib_bstride + o * ND;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) dout[d] = od[d];
+}
+template <int ND, int K, bool FIRST, class PT>
+__device__ __forceinline__ void composite_values(const PT &p, const int y, const int x, float (&o_rgb)[3],
+                                                 float (&o_m)[K + 1], const float *s_px, const float *s_kern, const int halo_w,
+                                                 const int hy, const int hx, const int *goal, double (&cost)[2 * ND],
+                                                 float (&of)[3], float (&od)[ND]) {
     constexpr int NM = K + 1;
     constexpr int PS = comp_px_stride(ND);
     auto load_px = [&](const int sp, float (&fr)[3], float (&di)[ND]) {
@@ -335,7 +368,6 @@ __device__ __forceinline__ void composite_finish(const PT &p, const int b, const
 
     // ---- per-pixel effective flow kernel: keff[tap] = sum_k mask[k+2] * kern[tap][k]
     // (arch 1: mask 2 weighs the first context frame, the warps use masks 3.. and kernels 0..K-3)
-    float of[3], od[ND];
     const int ctr = (hy + 2) * halo_w + (hx + 2);
     {
         float fr[3], di[ND];
@@ -383,14 +415,8 @@ __device__ __forceinline__ void composite_finish(const PT &p, const int b, const
             for (int d = 0; d < ND; ++d) od[d] = fmaf(ke, di[d], od[d]);
         }
     }
-    const long long o = (long long)y * p.W + x;
-    float *fo = p.out_frame + (long long)b * p.out_frame_bstride + o * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) fo[c] = of[c];
-    float *dout = p.out_distrib + (long long)b * p.out_distrib_bstride + o * ND;
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
-        dout[d] = od[d];
         const float ry = (float)(y - goal[2 * d]), rx = (float)(x - goal[2 * d + 1]);
         const float dist = sqrtf(fmaf(ry, ry, rx * rx));
         cost[2 * d] = (double)od[d];
