@@ -2024,6 +2024,11 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
 // from the phase type alone - and vf_selftest_schedule re-checks every phase against the restated conditions.
 static bool wt_epilogue(const PhaseDesc &P) {
     switch (P.type) {
+        case PH_EW:             // vf_savp3.h: the items whose every output is a 16-byte store (OutBuf / the block turn-over of the
+                                // fused heads, which needs whole 4 x 16 blocks) or an atomic store
+            if ((VF_WT_DEFAULT & 2) == 0) return false;
+            if (P.ew.op == EW_INORM || P.ew.op == EW_INCELL || P.ew.op == EW_UPSAMPLE) return true;
+            return P.ew.op == EW_TOP3 && P.ew.top.H % kSumBlockH == 0 && P.ew.top.W % kSumBlockW == 0;
         case PH_LSTM:           // gate-split 128- / 64-row tiles and the 32-row tile (lstm_gsplit_epilogue), exact fp32
             return P.prec == 0 && (P.mrep == 6 || P.mrep == 5 || P.mrep == -1);
         case PH_CONV_RELU: case PH_CONV_RAW: case PH_CONVT_RELU: case PH_CONVT_RAW:
@@ -2122,8 +2127,10 @@ static int build_schedule(vf_handle *h, int B, bool skip_shared, BuiltSchedule &
             if (q < nq) out.total_q[q] += P.n_q[q];
         }
     }
-    for (PhaseDesc &P : out.phases)
+    for (PhaseDesc &P : out.phases) {
         if (ph_is_conv(P.type) || P.type == PH_TOP_FUSED) P.conv.wt_out = (h->wt_publish && wt_epilogue(P)) ? 1 : 0;
+        if (P.type == PH_EW) P.ew.wt = (h->wt_publish && wt_epilogue(P)) ? 1 : 0;
+    }
     out.counters = counters;
     const size_t comp_lds[kMaxDesig] = {(size_t)composite_lds_floats<1, 10>() * 4, (size_t)composite_lds_floats<2, 10>() * 4,
                                         (size_t)composite_lds_floats<3, 10>() * 4, (size_t)composite_lds_floats<4, 10>() * 4};
@@ -2201,6 +2208,12 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
             const bool raw3_vec = (P.type == PH_CONV_RAW3 || P.type == PH_CONV_RAW3G2) && (P.mrep == 1 || P.mrep == 2) && P.conv.Cout % 4 == 0;
             if (!(lstm_vec || light_vec || raw3_vec || P.type == PH_GATES_RAW || P.type == PH_TOP_FUSED))
                 return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": write-through publish on a tile with plain stores");
+        }
+        if (P.type == PH_EW && P.ew.wt != 0) {
+            const int op = P.ew.op;
+            const bool vec = op == EW_INORM || op == EW_INCELL || op == EW_UPSAMPLE ||
+                             (op == EW_TOP3 && P.ew.top.H % 4 == 0 && P.ew.top.W % 16 == 0);
+            if (!vec) return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": write-through publish on an item with plain stores");
         }
         if (P.type == PH_TOP_FUSED && (P.aux_base != P.cnt_base + P.B || P.aux_base + P.B > bs.counters))
             return fail(VF_ERR_INVALID, "fused phase: bad auxiliary counters");

@@ -213,9 +213,9 @@ static __device__ __noinline__ __attribute__((not_tail_called)) void gates_raw_t
         CALL_;                                                                                                          \
     }
 VF_EW_BODY(ew_cond3_call, cond3_item(p.cond, b0, b1, tile_lds()))
-VF_EW_BODY(ew_inorm_call, inorm_item(p.norm, b0, idx, tile_lds()))
-VF_EW_BODY(ew_incell_call, incell_item(p.norm, b0, idx, tile_lds()))
-VF_EW_BODY(ew_upsample_call, upsample_item(p.up, b0, idx))
+VF_EW_BODY(ew_inorm_call, inorm_item(p.norm, b0, idx, p.wt != 0, tile_lds()))
+VF_EW_BODY(ew_incell_call, incell_item(p.norm, b0, idx, p.wt != 0, tile_lds()))
+VF_EW_BODY(ew_upsample_call, upsample_item(p.up, b0, idx, p.wt != 0))
 #undef VF_EW_BODY
 static __device__ __noinline__ __attribute__((not_tail_called)) void ew_sa3_call(const EwParams *p_, int b0, int b1) {
     const VF_CONST_AS EwParams &p = const_params(p_);
@@ -230,7 +230,7 @@ template <int ND>
 static __device__ __noinline__ __attribute__((not_tail_called)) void ew_top3_call(const EwParams *p_, int idx, int b, int view) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int *goal = reinterpret_cast<const int *>(smem_all) + kCtlGoal + view * ND * 2;
-    top3_item<ND>(const_params(p_).top, idx, b, goal, tile_lds());
+    top3_item<ND>(const_params(p_).top, idx, b, goal, const_params(p_).wt != 0, tile_lds());
 }
 template <int ND>
 static __device__ __noinline__ __attribute__((not_tail_called)) void ew_compose_call(const EwParams *p_, int idx, int b, int view) {
@@ -495,7 +495,8 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
         if (wave == 0) {
             // write-through items (ConvParams::wt_out: every global store of the tile was an sc1 / atomic store, drained
             // above by every wave) need no L2 write-back in front of their counters - CDNA guide section 6 G16, recipe R1
-            if (lane == 0 && !((ph_is_conv(P.type) || P.type == PH_TOP_FUSED) && P.conv.wt_out != 0)) {
+            const bool wt_item = ((ph_is_conv(P.type) || P.type == PH_TOP_FUSED) && P.conv.wt_out != 0) || (P.type == PH_EW && P.ew.wt != 0);
+            if (lane == 0 && !wt_item) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }

@@ -107,6 +107,8 @@ struct EwParams {
     int op, B;
     int gx;             // items per sample (spi == 0)
     int spi;            // > 0: an item covers spi consecutive samples (EW_SA3, EW_COND3)
+    int wt;             // the item's outputs leave as 16-byte sc1 / atomic stores: it publishes without a release fence
+                        // (persistent schedule only, set by build_schedule; ConvParams::wt_out has the reasoning)
     union {
         Sa3Params sa;
         Cond3Params cond;
@@ -130,6 +132,18 @@ __device__ __forceinline__ int cls5(const int y, const int H) { return y < 2 ? y
 
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void st4(float *p, const f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+// An output tensor of one sample as a raw buffer (wave-uniform base; byte offsets below 2^31): a 16-byte store that is plain
+// or - write-through items - sc1
+struct OutBuf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ OutBuf out_buf(const float *base) {
+    OutBuf o;
+    o.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7FFFFFFF, 0x00020000);
+    return o;
+}
+__device__ __forceinline__ void st4o(const OutBuf &o, const bool wt, const unsigned byte_off, const f32x4 v) {
+    if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), o.r, byte_off, 0, 16);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), o.r, byte_off, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------------ state FC + rnn_z + conditioning vector
 // one sample per wave; s = 128 floats of LDS scratch for this wave
@@ -272,16 +286,17 @@ __device__ __forceinline__ void in_scale_shift(const double su, const double sq,
 
 // relu(IN(x + class bias)) of the channels [grp * cpi, (grp + 1) * cpi) of sample b, all pixels
 template <class PT>
-__device__ __forceinline__ void inorm_item(const PT &p, const int b, const int grp, float *smem) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void inorm_item(const PT &p, const int b_, const int grp, const bool wt, float *smem) {
+    const int tid = threadIdx.x, b = __builtin_amdgcn_readfirstlane(b_);
     const int nq = p.cpi >> 2, nq_log2 = 31 - __builtin_clz((unsigned)nq);
     const int q = tid & (nq - 1), ps = tid >> nq_log2, ppp = kConvThreads >> nq_log2;
     const int HW = p.H * p.W, C = p.C, c0 = grp * p.cpi + 4 * q;
     const float *in = p.in + (long long)b * p.in_bs + c0;
     const float *cond = p.cond ? p.cond + (long long)b * p.cond_bs + c0 : nullptr;
     const int Co = p.split > 0 ? p.split : C;       // channels per pixel of the output tensor(s)
-    float *out = (p.split > 0 && c0 >= p.split) ? p.out2 + (long long)b * p.out_bs + (c0 - p.split)
-                                                : p.out + (long long)b * p.out_bs + c0;
+    const bool second = p.split > 0 && c0 >= p.split;
+    const OutBuf o1 = out_buf(p.out + (long long)b * p.out_bs), o2 = out_buf((p.split > 0 ? p.out2 : p.out) + (long long)b * p.out_bs);
+    const unsigned c_off = (unsigned)(second ? c0 - p.split : c0) * 4u;
     const TileDiv div_w(p.W);
     auto value = [&](const int px) {
         f32x4 v = ld4(in + (long long)px * C);
@@ -315,9 +330,9 @@ __device__ __forceinline__ void inorm_item(const PT &p, const int b, const int g
     for (int j = 0; j < 4; ++j) in_scale_shift(st[j], st[4 + j], inv_n, p.eps, p.g0[c0 + j], p.b0[c0 + j], sc[j], sh[j]);
     if (p.tab != nullptr) {             // statistics only: the consumer applies them
         if (ps == 0) {
-            float *t = p.tab + ((long long)b * C + c0) * 2;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { t[2 * j] = sc[j]; t[2 * j + 1] = sh[j]; }
+            const OutBuf ot = out_buf(p.tab + (long long)b * C * 2);
+            st4o(ot, wt, (unsigned)(c0 * 2) * 4u, f32x4{sc[0], sh[0], sc[1], sh[1]});
+            st4o(ot, wt, (unsigned)(c0 * 2 + 4) * 4u, f32x4{sc[2], sh[2], sc[3], sh[3]});
         }
         return;
     }
@@ -334,7 +349,8 @@ __device__ __forceinline__ void inorm_item(const PT &p, const int b, const int g
                 v[u][j] = fmaf(v[u][j], sc[j], sh[j]);
                 if (p.relu) v[u][j] = fmaxf(v[u][j], 0.f);
             }
-            st4(out + (long long)px * Co, v[u]);
+            const unsigned off = (unsigned)(px * Co) * 4u + c_off;
+            if (second) st4o(o2, wt, off, v[u]); else st4o(o1, wt, off, v[u]);
         }
     }
 }
@@ -344,8 +360,8 @@ __device__ __forceinline__ void inorm_item(const PT &p, const int b, const int g
 // Three passes over the item's own elements; c_new and sigmoid(o) rest in the c / h buffers between passes 2 and 3
 // (a thread re-reads only what it wrote itself).
 template <class PT>
-__device__ __forceinline__ void incell_item(const PT &p, const int b, const int grp, float *smem) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void incell_item(const PT &p, const int b_, const int grp, const bool wt, float *smem) {
+    const int tid = threadIdx.x, b = __builtin_amdgcn_readfirstlane(b_);
     const int nq = p.cpi >> 2, nq_log2 = 31 - __builtin_clz((unsigned)nq);
     const int q = tid & (nq - 1), ps = tid >> nq_log2, ppp = kConvThreads >> nq_log2;
     const int HW = p.H * p.W, C = p.C, C4 = 4 * C, c0 = grp * p.cpi + 4 * q;
@@ -354,6 +370,7 @@ __device__ __forceinline__ void incell_item(const PT &p, const int b, const int 
     const float *cprev = p.cprev ? p.cprev + (long long)b * p.cprev_bs + c0 : nullptr;
     float *hout = p.out + (long long)b * p.out_bs + c0;
     float *cout = p.cout + (long long)b * p.cout_bs + c0;
+    const OutBuf o_h = out_buf(p.out + (long long)b * p.out_bs), o_c = out_buf(p.cout + (long long)b * p.cout_bs);
     const TileDiv div_w(p.W);
     double *red = reinterpret_cast<double *>(smem);
     auto gates = [&](const int px, f32x4 (&g)[4]) {
@@ -452,8 +469,9 @@ __device__ __forceinline__ void incell_item(const PT &p, const int b, const int 
                 cn[u][j] = fmaf(cn[u][j], csc[j], csh[j]);
                 hn[j] = tanhf_(cn[u][j]) * so[u][j];
             }
-            st4(cout + (long long)px * C, cn[u]);
-            st4(hout + (long long)px * C, hn);
+            // (the final values: sc1 stores in a write-through item; pass 2 parked its intermediates with plain ones)
+            st4o(o_c, wt, (unsigned)(px * C + c0) * 4u, cn[u]);
+            st4o(o_h, wt, (unsigned)(px * C + c0) * 4u, hn);
         }
     }
 }
@@ -462,18 +480,19 @@ __device__ __forceinline__ void incell_item(const PT &p, const int b, const int 
 // out(2i + a, 2j + b) = sum over the two source rows / columns the transposed convolution with the kernel
 // [.25, .75, .75, .25] (stride 2, SAME) reaches: a = 0: .25 s[i-1] + .75 s[i];  a = 1: .75 s[i] + .25 s[i+1];  zero outside.
 template <class PT>
-__device__ __forceinline__ void upsample_item(const PT &p, const int b, const int band) {
+__device__ __forceinline__ void upsample_item(const PT &p, const int b_, const int band, const bool wt) {
+    const int b = __builtin_amdgcn_readfirstlane(b_);
     const int C = p.C0 + p.C1, Cq = C >> 2, OW = 2 * p.w, OH = 2 * p.h;
     const int y_begin = band * p.rows, n_rows = min(p.rows, OH - y_begin);
     const int total = n_rows * OW * Cq;
     const TileDiv div_cq(Cq), div_ow(OW);
-    float *out = p.out + (long long)b * p.out_bs;
+    const OutBuf ob = out_buf(p.out + (long long)b * p.out_bs);
     // two output elements per thread and pass: their eight source loads are issued back to back (clamped addresses, zeros
     // by select: no branch between the loads)
     for (int e0 = threadIdx.x; e0 < total; e0 += 2 * kConvThreads) {
         f32x4 v[2][4];
         float wgt[2][4];
-        long long dst[2];
+        unsigned dst[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = min(e0 + u * kConvThreads, total - 1);
@@ -496,7 +515,7 @@ __device__ __forceinline__ void upsample_item(const PT &p, const int b, const in
             wgt[u][1] = (r0ok && q1ok) ? wy0 * wx1 : 0.f;
             wgt[u][2] = (r1ok && q0ok) ? wy1 * wx0 : 0.f;
             wgt[u][3] = (r1ok && q1ok) ? wy1 * wx1 : 0.f;
-            dst[u] = ((long long)Y * OW + X) * C + c;
+            dst[u] = (unsigned)((Y * OW + X) * C + c) * 4u;
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -505,7 +524,7 @@ __device__ __forceinline__ void upsample_item(const PT &p, const int b, const in
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 o[k] = fmaf(wgt[u][3], v[u][3][k], fmaf(wgt[u][2], v[u][2][k], fmaf(wgt[u][1], v[u][1][k], wgt[u][0] * v[u][0][k])));
-            st4(out + dst[u], o);
+            st4o(ob, wt, dst[u], o);
         }
     }
 }
@@ -722,7 +741,8 @@ __host__ __device__ constexpr int top3_lds_floats(const int nd) {
 }
 
 template <int ND, class PT>
-__device__ __forceinline__ void top3_item(const PT &p, const int tile, const int b, const int *goal, float *smem) {
+__device__ __forceinline__ void top3_item(const PT &p, const int tile, const int b_, const int *goal, const bool wt, float *smem) {
+    const int b = __builtin_amdgcn_readfirstlane(b_);
     constexpr int PS = comp_px_stride(ND);
     typedef const __attribute__((address_space(4))) float cfloat;
     float *s_a = smem;                                  // [kT3R2][36]: hs, later hm ([kT3R1][36])
@@ -900,7 +920,12 @@ __device__ __forceinline__ void top3_item(const PT &p, const int tile, const int
 #pragma unroll
     for (int i = 0; i < 2 * ND; ++i) cost[i] = 0.0;
     const int y = ty0 + iy, x = tx0 + ix;
-    if (half == 0 && y < p.H && x < p.W) {
+    float of[3] = {0.f, 0.f, 0.f}, od[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) od[d] = 0.f;
+    const bool live = half == 0 && y < p.H && x < p.W;
+    const long long o = (long long)y * p.W + x;
+    if (live) {
         const f32x4 q0 = ld4(s_part + px * 8), q1 = ld4(s_part + px * 8 + 4);
         m[0] += q0[0]; m[1] += q0[1]; m[2] += q0[2]; m[3] += q0[3]; m[4] += q1[0]; m[5] += q1[1]; m[6] += q1[2];
         float mx = m[0];
@@ -919,18 +944,15 @@ __device__ __forceinline__ void top3_item(const PT &p, const int tile, const int
             const f32x4 v = ld4(lp + 4 * k);
             t[4 * k] = v[0]; t[4 * k + 1] = v[1]; t[4 * k + 2] = v[2]; t[4 * k + 3] = v[3];
         }
-        const long long o = (long long)y * p.W + x;
-        float *fo = p.out_frame + (long long)b * p.out_frame_bs + o * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float a = m[0] * t[c];
 #pragma unroll
             for (int j = 1; j < 7; ++j) a = fmaf(m[j], t[3 * j + c], a);
-            fo[c] = a;
+            of[c] = a;
         }
         const float *wd = s_wd + px * kNumWarp3 * ND;
         const float *pd = p.prev_distrib + (long long)b * p.prev_distrib_bs + o * ND;
-        float *dout = p.out_distrib + (long long)b * p.out_distrib_bs + o * ND;
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const float prev = pd[d] * s_ds[d];
@@ -940,11 +962,54 @@ __device__ __forceinline__ void top3_item(const PT &p, const int tile, const int
             a = fmaf(m[4], prev, a);
             a = fmaf(m[5], p.first_distrib[o * ND + d], a);
             a = fmaf(m[6], prev, a);
-            dout[d] = a;
+            od[d] = a;
             const float ry = (float)(y - goal[2 * d]), rx = (float)(x - goal[2 * d + 1]);
             const float dist = sqrtf(fmaf(ry, ry, rx * rx));
             cost[2 * d] = (double)a;
             cost[2 * d + 1] = (double)a * (double)dist;
+        }
+    }
+    if (!wt) {
+        if (live) {
+            float *fo = p.out_frame + (long long)b * p.out_frame_bs + o * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fo[c] = of[c];
+            float *dout = p.out_distrib + (long long)b * p.out_distrib_bs + o * ND;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) dout[d] = od[d];
+        }
+    } else if (half == 0) {
+        // write-through item (whole 4 x 16 blocks: the host checks H % 4 == 0, W % 16 == 0): the wave turns its block over in
+        // the dead feature tile - a block row is 48 consecutive floats of the frame and 16 ND of the distributions - and
+        // every lane stores 16-byte sc1 pieces (vf_fused_top.h has the same turn-over)
+        const int lane = tid & 63, wave = tid >> 6;
+        float *slab = s_a + wave * (64 * (3 + ND));
+        const int y_blk = ty0 + wave * kSumBlockH;
+        const bool blk_ok = y_blk < p.H && tx0 < p.W;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) slab[lane * 3 + c] = of[c];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) slab[192 + lane * ND + d] = od[d];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const __amdgpu_buffer_rsrc_t r_fr = __builtin_amdgcn_make_buffer_rsrc(
+            p.out_frame + (long long)b * p.out_frame_bs, 0, blk_ok ? (int)((unsigned)(p.H * p.W * 3) * 4u) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_di = __builtin_amdgcn_make_buffer_rsrc(
+            p.out_distrib + (long long)b * p.out_distrib_bs, 0, blk_ok ? (int)((unsigned)(p.H * p.W * ND) * 4u) : 0, 0x00020000);
+        if (lane < 48) {
+            const int row = lane / 12, q = lane - row * 12;
+            const f32x4 v = ld4(slab + row * 48 + 4 * q);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r_fr,
+                                                   (unsigned)(((y_blk + row) * p.W + tx0) * 3 + 4 * q) * 4u, 0, 16);
+        }
+        for (int j = lane; j < 16 * ND; j += 64) {
+            const int row = j / (4 * ND), q = j - row * (4 * ND);
+            const f32x4 v = ld4(slab + 192 + row * 16 * ND + 4 * q);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r_di,
+                                                   (unsigned)(((y_blk + row) * p.W + tx0) * ND + 4 * q) * 4u, 0, 16);
         }
     }
     if (half == 0) {
@@ -957,7 +1022,12 @@ __device__ __forceinline__ void top3_item(const PT &p, const int tile, const int
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 double *dst = p.out_sums + (((long long)b * ND + d) * nblocks + blk) * 2;
-                dst[0] = cost[2 * d]; dst[1] = cost[2 * d + 1];
+                if (wt) {
+                    __hip_atomic_store(dst, cost[2 * d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, cost[2 * d + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    dst[0] = cost[2 * d]; dst[1] = cost[2 * d + 1];
+                }
             }
         }
     }
@@ -975,11 +1045,11 @@ __device__ __forceinline__ void ew_item(const PT &p, const int idx, const int b0
             break;
         }
         case EW_COND3: cond3_item(p.cond, b0, b1, smem); break;
-        case EW_INORM: inorm_item(p.norm, b0, idx, smem); break;
-        case EW_INCELL: incell_item(p.norm, b0, idx, smem); break;
-        case EW_UPSAMPLE: upsample_item(p.up, b0, idx); break;
+        case EW_INORM: inorm_item(p.norm, b0, idx, p.wt != 0, smem); break;
+        case EW_INCELL: incell_item(p.norm, b0, idx, p.wt != 0, smem); break;
+        case EW_UPSAMPLE: upsample_item(p.up, b0, idx, p.wt != 0); break;
         case EW_TRANSFORM: transform_item<ND>(p.top, idx, b0, smem); break;
-        case EW_TOP3: top3_item<ND>(p.top, idx, b0, goal, smem); break;
+        case EW_TOP3: top3_item<ND>(p.top, idx, b0, goal, p.wt != 0, smem); break;
         default: compose_item<ND>(p.top, idx, b0, goal, smem); break;
     }
 }
