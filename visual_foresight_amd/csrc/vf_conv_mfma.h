@@ -87,6 +87,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 
+// the acquire behind an observed completion counter (TIMING ONLY, wrong results: -DVF_TIMING_NO_ACQUIRE drops it - what the
+// invalidations cost a launch, EXPERIMENTS.md)
+#ifdef VF_TIMING_NO_ACQUIRE
+#define VF_ACQUIRE_AGENT() do { } while (0)
+#else
+#define VF_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#endif
 constexpr int kConvThreads = 256;
 constexpr int kConvRows = 256;      // GEMM rows per workgroup at MREP = 2 (128 at MREP = 1)
 constexpr float kLnEps = 1e-12f;
@@ -282,7 +289,7 @@ __device__ __forceinline__ bool late_wait(const PT &p, const int b0, const int b
         } while (!ok);
         if (lane == 0) {
             *flag = ok ? 1 : 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            VF_ACQUIRE_AGENT();
         }
     }
     cu_publish(p, 1);                   // the layer input is there: from here on this item is on its sample's chain

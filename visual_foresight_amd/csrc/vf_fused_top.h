@@ -199,7 +199,7 @@ __device__ __forceinline__ void fused_top_body(const PT &p, const CT &c, f32x16 
                 if (++spins > kFusedSpinLimit ||
                     __hip_atomic_load(p.fuse_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            VF_ACQUIRE_AGENT();
             *s_flag = ok;
         }
         __builtin_amdgcn_wave_barrier();

@@ -387,7 +387,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
             } while (!ok);
             if (lane == 0) {
                 s_ctl[1] = ok ? 1 : 0;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                VF_ACQUIRE_AGENT();
             }
         } else if (tid == 0) {
             s_ctl[1] = 1;
