@@ -784,6 +784,9 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 // behind xch.  Same expressions on the same values, hence the same bits, as conv_epilogue.
 // (MR = 8, the 256-row tile: the same in two rounds of four row blocks - wave w finishes row blocks w and 4 + w)
 constexpr int kGsXchFloats = 4 * 4 * 16 * 64;
+// arch 2: LDS floats of a 128-row gate-split tile whose epilogue adds the conditioning biases through its class tables
+// (exchange buffer, reduction scratch, [25][128] values, [128] classes)
+constexpr int kGsCondFloats = kGsXchFloats + 16 + 25 * 128 + 128;
 template <int MR, class PT>
 __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[MR][1], const int bx, const int by,
                                                      float *smem) {
@@ -857,7 +860,34 @@ __device__ __forceinline__ void lstm_gsplit_epilogue(const PT &p, f32x16 (&acc)[
             c_old[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_cin, off_c, 0, 0));
         }
         __syncthreads();                    // the operand tile / the previous round's gates are no longer read
-        if (p.cond_bias != nullptr) {
+        if (MR == 4 && ni1 && p.cond_bias != nullptr) {
+            // arch 2, one image per 128-row tile: + the conditioning bias of each row's border class through two small LDS
+            // tables behind the exchange buffer (kGsCondFloats, planned by init_layer) - this lane's 25 class values of its
+            // gate column and the class of each of the 128 rows - instead of a row geometry and a 4-byte global load per
+            // accumulator element (64 per lane: 10 us of a 36-us epilogue at the C5 shard).  The same addends: the same bits.
+            const int C4 = 4 * p.Cout, col = wave * p.Cout + ch;
+            float *ctab = reinterpret_cast<float *>(red + 8);           // [25][128]
+            int *ccls = reinterpret_cast<int *>(ctab + 25 * 128);       // [128]
+            const float *cb = p.cond_bias + (long long)bimg0 * (25 * C4) + col;
+            for (int cls = kh; cls < 25; cls += 2) ctab[cls * 128 + wave * 32 + n] = cb[(long long)cls * C4];
+            if (tid < 128) {
+                const int yy = div_tw.div(tid);
+                const int y = ty0 + yy, x = tx0 + tid - yy * p.TW;
+                const bool ok = n_here > 0 && tid < p.TH * p.TW && y < p.Hout && x < p.Wout;
+                const int cy = y < 2 ? y : (y >= p.Hout - 2 ? y - (p.Hout - 5) : 2);
+                const int cx = x < 2 ? x : (x >= p.Wout - 2 ? x - (p.Wout - 5) : 2);
+                ccls[tid] = ok ? cy * 5 + cx : -1;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < RBR; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = ccls[(half * RBR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
+                    const float add = cl >= 0 ? ctab[cl * 128 + wave * 32 + n] : 0.f;
+                    acc[half * RBR + m][0][r] = acc[half * RBR + m][0][r] + add;
+                }
+        } else if (p.cond_bias != nullptr) {
             // arch 2: + the conditioning bias of each row's border class (lane = gate column wave * Cout + ch; the class
             // is uniform over each half of the wave, the 32 lanes of a half read 128 consecutive bytes)
             const int C4 = 4 * p.Cout, col = wave * p.Cout + ch;

@@ -687,6 +687,8 @@ static void init_layer(ConvLayer &l, const char *name, PackMode mode, int Hin, i
     l.nsplit = 1; l.n_valid = Cout;
     plan_geometry(l, stats, fc);
     l.chunks_per_split = l.nchunk[0] + l.nchunk[1];
+    // (arch 2: the 128-row gate-split tile adds the conditioning biases through two LDS tables behind its exchange buffer)
+    if (cond_ch > 0 && l.gs_v2) l.lds_bytes = std::max(l.lds_bytes, (size_t)vf::kGsCondFloats * 4 + 64);
     // the first conv of the encoder (3-channel frame in, exact statistics out): one thread per output pixel on the vector
     // ALUs instead of a K = 75 GEMM padded to 200 on the matrix pipe (vf_conv_first.h)
     bool first = mode == PACK_PLAIN && !fc && stats && l.nseg == 1 && c0 == vf::kFirstCin && KH == vf::kFirstK &&
