@@ -544,7 +544,7 @@ class Bench(object):
         r = {'bound': 'mfma',
              'kernel': 'rollout_persistent_kernel (one launch per rollout of one rank\'s shard: every conv-LSTM / '
                        'conv / transposed-conv / FC tile of all steps and views; FLOPs = the MFMA work the launch '
-                       'executes, context step counted once)',
+                       'executes, context step counted once; the 3-channel first conv runs on the vector ALUs and is not counted)',
              'achieved': tf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
              'frac': tf / PEAK_FP32_MFMA_TFLOPS if tf else None, 'traffic': None,
              'traffic_measured_in_run': False,

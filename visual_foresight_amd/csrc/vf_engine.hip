@@ -1615,8 +1615,9 @@ struct ScheduleSink {
         max_lds = std::max(max_lds, l.lds_bytes);
         const double rows = (double)p.B * l.Hout * l.Wout;
         const double taps = l.mode == PACK_CONVT ? 9.0 / 4.0 * 4.0 : (double)l.KH * l.KW;   // real taps
-        flops += 2.0 * rows * taps * (l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0) - p.chunk_begin * l.KC) *
-                 (l.mode == PACK_LSTM ? 4.0 : (l.mode == PACK_PLAIN ? (double)l.G : 1.0)) * l.Cout;
+        if (!l.first_valu)      // (the first conv runs on the vector ALUs: not matrix work, not counted)
+            flops += 2.0 * rows * taps * (l.segC[0] + (l.nseg > 1 ? l.segC[1] : 0) - p.chunk_begin * l.KC) *
+                     (l.mode == PACK_LSTM ? 4.0 : (l.mode == PACK_PLAIN ? (double)l.G : 1.0)) * l.Cout;
         return add(P, P.gx * P.gy * l.nsplit, P.whole ? 1 : p.B, deps);
     }
     int sa(const SaParams &p, std::initializer_list<int> deps) {
