@@ -17,7 +17,7 @@ done
 [ -f $O/kernel_stats_c5_savp3.txt ] && cp $O/kernel_stats_c5_savp3.txt profiles/${2:-r06}_kernel_stats_c5_savp3.txt
 [ -f $O/gputests.log ] && cp $O/gputests.log profiles/${2:-r06}_gpu_tests.log
 [ -f $O/fingerprint.txt ] && grep -v amdgpu.ids $O/fingerprint.txt > profiles/${2:-r06}_fingerprints.txt
-for f in cu_trace_200 cu_trace_200_timeline cu_trace_25 chain_25 chain_200 mfma_shadow_ubench hbm_calib sq_mix precision_check; do
+for f in cu_trace_200 cu_trace_200_timeline cu_trace_25 chain_25 chain_200 mfma_shadow_ubench hbm_calib sq_mix precision_check stress_repeat soak; do
   [ -f $O/$f.txt ] && cp $O/$f.txt profiles/${2:-r06}_$f.txt
 done
 python3 - <<PY

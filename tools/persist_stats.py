@@ -30,7 +30,7 @@ N = 2000
 types, items, wr = (ctypes.c_int32 * N)(), (ctypes.c_int32 * N)(), (ctypes.c_uint64 * (2 * N))()
 n = lib.vf_debug_phase_stats(pred._handle, N, types, items, wr)
 names = {i: n for i, n in enumerate(['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED',
-                                     'CONV_PAIR', 'COND', 'CONV_RAW3', 'GATES_RAW', 'EW', 'CONV_RAW3G2'])}
+                                     'CONV_PAIR', 'COND', 'CONV_RAW3', 'GATES_RAW', 'EW', 'CONV_RAW3G2', 'CONV_RAW3G4'])}
 names.update({100 + i: n for i, n in enumerate(['EW_SA3', 'EW_COND3', 'EW_INORM', 'EW_INCELL', 'EW_UPSAMPLE', 'EW_TRANSFORM', 'EW_COMPOSE', 'EW_TOP3'])})
 tick = 1e-8     # wall_clock64: 100 MHz
 agg = {}

@@ -24,3 +24,6 @@ cd $R
 db=$(ls $O/ktrace_s3/*.db 2>/dev/null | head -1)
 [ -n "$db" ] && python3 tools/rocprof_summary.py $db > $O/kernel_stats_c5_savp3.txt && head -6 $O/kernel_stats_c5_savp3.txt
 rm -rf $O/ktrace_s3
+# the same planning calls many times (must reproduce themselves bit for bit) and long bench loops, arch 3 included
+timeout 1500 python tools/stress_repeat.py 60 2>&1 | grep -v amdgpu.ids > $O/stress_repeat.txt; tail -1 $O/stress_repeat.txt
+timeout 1400 bash tools/soak.sh > $O/soak.txt 2>&1

@@ -36,7 +36,7 @@ TR_ST_LOADED, TR_ST_WRITTEN = 16, 17
 TR_YIELD, TR_YIELD_END = 18, 19    # a recurrent half asleep for its CU partner (round 5), inside a K loop
 PH_LSTM = 0
 PH_NAMES = ['LSTM', 'CONV_RELU', 'CONV_RAW', 'CONVT_RELU', 'CONVT_RAW', 'FC', 'SA', 'FIN', 'COMPOSITE', 'TOP_FUSED', 'CONV_PAIR',
-            'COND', 'CONV_RAW3', 'GATES_RAW', 'EW', 'CONV_RAW3G2']
+            'COND', 'CONV_RAW3', 'GATES_RAW', 'EW', 'CONV_RAW3G2', 'CONV_RAW3G4']
 PH_GATES_RAW = 13       # arch 3's gate GEMM: the gate-split K loop with the raw epilogue - a conv-LSTM K loop for this analysis
 
 adim = 12 if ARCH.startswith('savp') else 4

@@ -538,7 +538,9 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
         constexpr bool kStats = EPI == EPI_RAW_STATS || EPI == EPI_CONVT_RAW_STATS;
         const bool ni1 = p.NI == 1;
         const int n_here = ni1 ? (bimg0 < p.B ? 1 : 0) : min(p.NI, p.B - bimg0);
-        // (EPI_RAW with G > 1, arch 3's two heads as one item: gate g = output channels [g Cout, (g + 1) Cout) of every pixel)
+        // (EPI_RAW with G > 1, arch 3: the item's G "gates" are G consecutive 32-channel groups of a plain conv with
+        // kGS * Cout output channels - gate g of column group cg = channels [(cg G + g) 32, +32) of every pixel, the order
+        // of the plain layer's packed weights and bias)
         constexpr int kGS = (EPI == EPI_RAW) ? G : 1;
         const long long out_elems = (long long)(kT ? 4 : kGS) * p.Hout * p.Wout * p.Cout;
         const unsigned out_bytes = (unsigned)out_elems * 4u;
@@ -580,9 +582,9 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
             if (!ni1) { img = div_rpi.div(row); rem = row - img * p.RPI; }
             const int yy = div_tw.div(rem);
             const int y = ty0 + yy, x = tx0 + rem - yy * p.TW;
-            const bool ok = img < n_here && rem < px_per_img && y < p.Hout && x < p.Wout && cg * 32 + 4 * cq < p.Cout;
+            const bool ok = img < n_here && rem < px_per_img && y < p.Hout && x < p.Wout && (kGS > 1 || cg * 32 + 4 * cq < p.Cout);
             const unsigned in_img = kT ? (unsigned)(((2 * y) * (2 * p.Wout) + 2 * x) * p.Cout + cg * 32 + 4 * cq) * 4u
-                                       : (unsigned)((y * p.Wout + x) * (kGS * p.Cout) + cg * 32 + 4 * cq) * 4u;
+                                       : (unsigned)((y * p.Wout + x) * (kGS * p.Cout) + cg * (kGS * 32) + 4 * cq) * 4u;
             off_o[m][k] = ok ? (unsigned)img * out_bytes + in_img : 0xFFFFFFFFu;
         }
         __syncthreads();                    // every wave is done reading the operand tile: its LDS becomes the slabs
@@ -597,7 +599,7 @@ __device__ __forceinline__ void conv_epilogue(const PT &p, f32x16 (&acc)[MREP][G
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const unsigned par = kT ? (unsigned)(((g >> 1) * (2 * p.Wout) + (g & 1)) * p.Cout) * 4u
-                                    : (kGS > 1 ? (unsigned)(g * p.Cout) * 4u : 0u);
+                                    : (kGS > 1 ? (unsigned)(g * 32) * 4u : 0u);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const f32x4 q = *reinterpret_cast<const f32x4 *>(T + (pl + 8 * k) * 36 + 4 * cq);

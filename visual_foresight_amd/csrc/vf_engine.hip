@@ -744,6 +744,7 @@ static int configure_kernels(vf_handle *h) {
     if ((rc = allow_lds(&conv_mfma_kernel<2, EPI_RAW, 1>, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<1, EPI_RAW, 2>, n))) return rc;
     if ((rc = allow_lds(&conv_mfma_kernel<2, EPI_RAW, 2>, n))) return rc;
+    if ((rc = allow_lds(&conv_mfma_kernel<4, EPI_RAW, 1>, n))) return rc;
     if ((rc = allow_lds(&ew_kernel<1>, ew_lds_bytes(EW_TOP3, 1)))) return rc;
     if ((rc = allow_lds(&ew_kernel<2>, ew_lds_bytes(EW_TOP3, 2)))) return rc;
     if ((rc = allow_lds(&ew_kernel<3>, ew_lds_bytes(EW_TOP3, 3)))) return rc;
@@ -1460,6 +1461,7 @@ struct LaunchSink {
             case PH_CONVT_RAW: return launch_conv_t<4, EPI_CONVT_RAW_STATS>(l, p, st);
             case PH_CONV_RAW3: return l.mrep == 2 ? launch_conv_m<1, EPI_RAW, 2>(l, p, st) : launch_conv_m<1, EPI_RAW, 1>(l, p, st);
             case PH_CONV_RAW3G2: return l.mrep == 2 ? launch_conv_m<2, EPI_RAW, 2>(l, p, st) : launch_conv_m<2, EPI_RAW, 1>(l, p, st);
+            case PH_CONV_RAW3G4: return launch_conv_m<4, EPI_RAW, 1>(l, p, st);
             case PH_GATES_RAW: {
                 const int tiles = l.NI == 1 ? p.B * l.tilesY * l.tilesX : (p.B + l.NI - 1) / l.NI;
                 hipLaunchKernelGGL(conv_gates_raw_kernel, dim3(tiles, l.ncg), dim3(kConvThreads), l.lds_bytes, st, p);
@@ -2038,7 +2040,7 @@ static bool wt_epilogue(const PhaseDesc &P) {
             // conv_epilogue's vectorised form: one row block per wave, whole channel quads; the vector-ALU first conv
             // (mrep 8, vf_conv_first.h: Cout / 4 16-byte stores per pixel + an atomic-store partial)
             return (VF_WT_DEFAULT & 2) != 0 && (P.mrep == 1 || (P.type == PH_CONV_RAW && P.mrep == 8)) && P.conv.Cout % 4 == 0;
-        case PH_CONV_RAW3: case PH_CONV_RAW3G2:     // EPI_RAW is vectorised for one and two row blocks per wave
+        case PH_CONV_RAW3: case PH_CONV_RAW3G2: case PH_CONV_RAW3G4:     // EPI_RAW is vectorised for one and two row blocks per wave
             return (VF_WT_DEFAULT & 2) != 0 && (P.mrep == 1 || P.mrep == 2) && P.conv.Cout % 4 == 0;
         case PH_GATES_RAW:      // gates_raw_epilogue: sixteen 16-byte stores per lane, nothing else
             return true;
@@ -2208,7 +2210,8 @@ extern "C" int vf_selftest_schedule(vf_handle *h, int32_t B, int32_t skip_shared
             const bool lstm_vec = P.type == PH_LSTM && P.prec == 0 && (P.mrep == 6 || P.mrep == 5 || P.mrep == -1);
             const bool light_vec = P.type >= PH_CONV_RELU && P.type <= PH_CONVT_RAW && P.conv.Cout % 4 == 0 &&
                                    (P.mrep == 1 || (P.mrep == 8 && P.type == PH_CONV_RAW && (P.conv.Cout == 16 || P.conv.Cout == 32)));
-            const bool raw3_vec = (P.type == PH_CONV_RAW3 || P.type == PH_CONV_RAW3G2) && (P.mrep == 1 || P.mrep == 2) && P.conv.Cout % 4 == 0;
+            const bool raw3_vec = (P.type == PH_CONV_RAW3 || P.type == PH_CONV_RAW3G2 || P.type == PH_CONV_RAW3G4) &&
+                                  (P.mrep == 1 || P.mrep == 2) && P.conv.Cout % 4 == 0;
             if (!(lstm_vec || light_vec || raw3_vec || P.type == PH_GATES_RAW || P.type == PH_TOP_FUSED))
                 return fail(VF_ERR_INVALID, "phase " + std::to_string(i) + ": write-through publish on a tile with plain stores");
         }

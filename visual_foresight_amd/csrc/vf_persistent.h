@@ -38,11 +38,13 @@ enum PhaseType {
     PH_CONV_RAW3,           // conv, acc + bias (EPI_RAW)
     PH_GATES_RAW,           // conv-LSTM gate GEMM on the gate-split 128-row tile, raw gate pre-activations (gates_raw_epilogue)
     PH_EW,                  // state FC / class biases / instance norm / cell / up-sampling / compositing layers (EwParams::op)
-    PH_CONV_RAW3G2          // two 32-channel convs of the same input as the two "gates" of one item (the hidden layers of the
-                            // mask and scratch heads): conv_tile<2, EPI_RAW>, output [pixel][2 x 32]
+    PH_CONV_RAW3G2,         // two 32-channel groups of a conv as the two "gates" of one item (the hidden layers of the mask and
+                            // scratch heads; every 64-channel conv): conv_tile<2, EPI_RAW>, output [pixel][.. 2 x 32 ..]
+    PH_CONV_RAW3G4          // four 32-channel groups per item (convs of 128 / 256 channels: the input tile is staged once for
+                            // 128 output channels instead of once per 32): conv_tile<4, EPI_RAW, 1>
 };
 __host__ __device__ constexpr bool ph_is_conv(const int t) {
-    return t <= PH_CONVT_RAW || t == PH_CONV_RAW3 || t == PH_GATES_RAW || t == PH_CONV_RAW3G2;
+    return t <= PH_CONVT_RAW || t == PH_CONV_RAW3 || t == PH_GATES_RAW || t == PH_CONV_RAW3G2 || t == PH_CONV_RAW3G4;
 }
 
 constexpr int kMaxDeps = 3;
@@ -462,6 +464,7 @@ VF_GLOBAL VF_LAUNCH_BOUNDS(kConvThreads, 2) void rollout_persistent_kernel(
                     if (P.mrep == 2) conv_tile_call<2, EPI_RAW, 2>(&P.conv, bx, by, 0);
                     else conv_tile_call<2, EPI_RAW, 1>(&P.conv, bx, by, 0);
                     break;
+                case PH_CONV_RAW3G4: conv_tile_call<4, EPI_RAW, 1>(&P.conv, bx, by, 0); break;
                 case PH_GATES_RAW: gates_raw_tile_call(&P.conv, bx, by); break;
                 case PH_EW: {
                     const int idx = P.ew.spi > 0 ? 0 : local - b0 * P.gx;
