@@ -397,6 +397,9 @@ class Bench(object):
         a, torch = self.args, self.torch
         ctrl = self.build_controller(precision)
         pred = ctrl.predictor
+        for opt in ('yield_budget', 'write_through'):   # A/B runs only: timing-only scheduler options
+            if os.environ.get('VF_BENCH_' + opt.upper()) is not None:
+                (getattr(pred, 'predictor', pred)).set_sched_option(opt, int(os.environ['VF_BENCH_' + opt.upper()]))
         score_time = [0.0]
         inner_score = pred.score
 
