@@ -1791,7 +1791,7 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
 #define VF_EMIT_SH(var, shared, expr) VF_EMIT(var, ((shared) && skip_shared) ? Sink::skipped() : (expr))
 
     int last = -1;      // terminal unit of the previous step
-    int u_sa_prev = -1; // state FC of the previous step (arch 2: producer of the state the conditioning biases read)
+    int u_cond_next[7] = {-1, -1, -1, -1, -1, -1, -1};     // arch 2: the conditioning-bias units of the coming step (emitted a step ahead)
     int u_prev[7] = {-1, -1, -1, -1, -1, -1, -1};   // conv-LSTM k of the previous step
     for (int s = 0; s < h->S; ++s) {
         const int cur = s & 1, nxt = cur ^ 1;
@@ -1817,22 +1817,37 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         sp.sbias = D.sbias;
         VF_EMIT_SH(u_sa, all_sh, sink.sa(sp, {last}))
 
-        // ---- arch 2: the conditioning biases of this step's seven conv-LSTMs (inputs: this step's action / latent and
-        // the state the PREVIOUS step's state FC produced - so they run a step ahead of their consumers' epilogues)
-        int u_cond[7] = {-1, -1, -1, -1, -1, -1, -1};
-        if (h->cond) {
+        // ---- arch 2: the conditioning biases of the seven conv-LSTMs of step `sc` (inputs: that step's action / latent and
+        // the state the state FC of step sc - 1 produced; two buffers by step parity).  Step 0's are emitted here; those of
+        // step s + 1 are emitted in the MIDDLE of step s, behind lstm5 (below): their only producer, this step's state FC, is
+        // long done there, the phases around the 8 x 8 bottleneck are the narrow ones of a step (slots idle), and the head of
+        // step s + 1 - state FC, first convs, lstm1: every sample's chain starts there - no longer queues behind 1100 bias items
+        int u_cond[7];
+        for (int k = 0; k < 7; ++k) u_cond[k] = u_cond_next[k];
+        auto emit_cond = [&](const int sc, const int u_state, int (&out)[7]) -> int {
+            for (int k = 0; k < 7; ++k) out[k] = -1;
+            if (!h->cond || sc >= h->S) return VF_OK;
+            const float *act, *sta; long long act_bs, sta_bs;
+            if (sc < nc - 1) { act = h->ctx_actions + (size_t)sc * c.adim; act_bs = 0; }
+            else { act = v.actions + (size_t)(sc - (nc - 1)) * c.adim; act_bs = (long long)T * c.adim; }
+            if (sc < nc) { sta = h->ctx_states + (size_t)sc * c.sdim; sta_bs = 0; }
+            else { sta = v.states_all + (size_t)(sc - nc) * c.sdim; sta_bs = (long long)T * c.sdim; }
             for (int k = 0; k < 7; ++k) {
-                const bool shd = lstm_shared(k, s);
+                const bool shd = lstm_shared(k, sc);
                 CondParams cq; memset(&cq, 0, sizeof(cq));
-                cq.action = sp.action; cq.action_bstride = sp.action_bstride;
-                cq.state = sp.state; cq.state_bstride = sp.state_bstride;
+                cq.action = act; cq.action_bstride = act_bs;
+                cq.state = sta; cq.state_bstride = sta_bs;
                 cq.adim = c.adim; cq.sdim = c.sdim; cq.B = shd ? 1 : B;
                 cq.w = vd.w_cond[k]; cq.C4 = 4 * L[k];
-                cq.out = (shd ? sh : v).cond_bias[k][s & 1];
-                VF_EMIT_SH(u_ck, shd, sink.cond(cq, {u_sa_prev}))
-                u_cond[k] = u_ck;
+                cq.out = (shd ? sh : v).cond_bias[k][sc & 1];
+                VF_EMIT_SH(u_ck, shd, sink.cond(cq, {u_state}))
+                out[k] = u_ck;
             }
-            u_sa_prev = u_sa;
+            return VF_OK;
+        };
+        if (s == 0) {
+            const int rc0 = emit_cond(0, -1, u_cond);
+            if (Sink::failed(rc0)) return rc0;
         }
 
         // ---- encoder
@@ -1929,6 +1944,10 @@ static int emit_rollout(vf_handle *h, int view, const BatchView &v, const BatchV
         const ConvLayer &convt1_l = light_plan(h->convt1, h->convt1_one, BD);
         p = params(convt1_l, BD, h5n, nullptr);
         p.out = D.enc4_o;
+        {   // (arch 2) the conditioning biases of the NEXT step: see the head of the step
+            const int rcn = emit_cond(s + 1, u_sa, u_cond_next);
+            if (Sink::failed(rcn)) return rcn;
+        }
         VF_EMIT_SH(u_t1, all_sh, sink.conv(PH_CONVT_RELU, convt1_l, p, {u_l5}))
         VF_EMIT_SH(u_l6, lstm_shared(5, s), sink.lstm(lstm_plan(5, lstm_shared(5, s) ? 1 : B),
                                 lstm_params(5, plain(D.enc4_o, bs(all_sh, (long long)H4 * W4 * L[4]))), u_prev[5], u_t1, u_cond[5]))
